@@ -1,0 +1,225 @@
+"""Host-side (CPU, tiny) parts of the hot path: the ego-pose track, path distances, horizon eviction,
+BEV heading, trajectory clipping and the polynomial warp.
+
+These are O(#frames) or O(#trajectory vertices) per call and stay on the host exactly as in the
+reference; the per-point work is in the HIP library.  Every numpy expression that feeds a value the
+device consumes (pose origin, rotation matrix) is evaluated with the same numpy calls as the
+reference so that the f64 bit patterns agree.
+
+Reference behaviour restated (file:line relative to the reference root):
+  sem_pc_accum.py:156-165   update_poses           -> PoseTrack.apply_transform
+  sem_pc_accum.py:185-209   remove_observations    -> PoseTrack.push_segment_and_evict
+  sem_pc_accum.py:211-228   comp_incr_path_dist    -> incremental_path_dists
+  sem_pc_accum.py:404-415   dist                   -> pose_dist
+  bev_generator/bev_generator.py:87-93    heading  -> heading_rot_ang
+  bev_generator/bev_generator.py:207-237  geometric_transform(is_traj=True) -> transform_traj
+  bev_generator/bev_generator.py:257-371  crop_trajectory / cal_intersec_pnt
+  bev_generator/bev_generator.py:482-698  warp family
+"""
+import math
+import random
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------------------------
+#  poses / path distances
+# ----------------------------------------------------------------------------------------------
+def pose_dist(p0, p1):
+    """Euclidean distance over all stored components (xyz, despite the reference docstring)."""
+    return np.sqrt(np.sum((p1 - p0)**2))
+
+
+def incremental_path_dists(seg_dists):
+    """Cumulative path length as lower-triangular-ones @ d (NOT np.cumsum: last bits differ)."""
+    d = np.array(seg_dists)
+    return np.matmul(np.tri(len(d)), d)
+
+
+class PoseTrack:
+    """Ego poses of the live frames (python lists of 3 floats) and the segment distances between them."""
+
+    def __init__(self):
+        self.poses = []
+        self.seg_dists = []
+
+    def apply_transform(self, T):
+        """Every stored pose p <- (T @ [p,1])[:3]; (4,4)@(4,1) products, one per pose."""
+        moved = []
+        for p in self.poses:
+            col = np.matmul(T, np.array([p + [1]]).T)
+            moved.append(list(col[:, 0][:-1]))
+        self.poses = moved
+
+    def append(self, pose):
+        self.poses.append(pose)
+
+    def push_segment(self):
+        """Appends the distance between the two newest poses; returns the total path length."""
+        self.seg_dists.append(pose_dist(np.array(self.poses[-1]), np.array(self.poses[-2])))
+        return np.sum(self.seg_dists)
+
+    def evict_beyond(self, horizon_dist, path_length):
+        """Number of oldest frames to drop so that the remaining path fits the horizon (0 if it fits)."""
+        if not path_length > horizon_dist:
+            return 0
+        incr = incremental_path_dists(self.seg_dists)
+        incr -= path_length - horizon_dist
+        k = int((incr > 0.).argmax())
+        self.poses = self.poses[k:]
+        self.seg_dists = self.seg_dists[k:]
+        return k
+
+
+# ----------------------------------------------------------------------------------------------
+#  BEV frame
+# ----------------------------------------------------------------------------------------------
+def rotation_matrix_3d(ang):
+    c, s = np.cos(ang), np.sin(ang)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+
+def heading_rot_ang(ego_traj_present):
+    """Rotation that points the last present ego step 'up' in the BEV."""
+    ang = 0.5 * np.pi
+    if len(ego_traj_present) > 1:
+        dx = ego_traj_present[-1][0] - ego_traj_present[-2][0]
+        dy = ego_traj_present[-1][1] - ego_traj_present[-2][1]
+        ang += np.arctan2(dy, dx)
+    return np.pi - ang
+
+
+def pos2grid_inplace(mat, view, px):
+    mat[:, 0:2] = np.floor(mat[:, 0:2] / view * px + 0.5 * px)
+    return mat
+
+
+# ----------------------------------------------------------------------------------------------
+#  trajectories
+# ----------------------------------------------------------------------------------------------
+def _inside(x, y, b0x, b0y, b1x, b1y):
+    return (b0x < x and x < b1x) and (b0y < y and y < b1y)
+
+
+def bisect_box_crossing(x0, y0, x1, y1, bbox, thresh=1e-4):
+    """Midpoint refinement of the point where segment (p0,p1) crosses the box; exactly one end inside."""
+    b0x, b0y, b1x, b1y = bbox
+    gap = np.inf
+    iters = 0
+    while gap > thresh:
+        xm = 0.5 * (x0 + x1)
+        ym = 0.5 * (y0 + y1)
+        p0_in = _inside(x0, y0, b0x, b0y, b1x, b1y)
+        mid_in = _inside(xm, ym, b0x, b0y, b1x, b1y)
+        # the midpoint replaces whichever end lies on its own side of the border
+        if mid_in == p0_in:
+            gap = np.sqrt((xm - x0)**2 + (ym - y0)**2)
+            x0, y0 = xm, ym
+        else:
+            gap = np.sqrt((xm - x1)**2 + (ym - y1)**2)
+            x1, y1 = xm, ym
+        iters += 1
+    return xm, ym, iters
+
+
+def crop_trajectory(traj, view, thresh=1e-4):
+    """Clips a polyline to the open view box.  Walks EDGES, so the final vertex is never emitted on its
+    own (reference behaviour) and every emitted point carries the z of the edge's first vertex."""
+    h = 0.5 * view
+    bbox = [-h, -h, h, h]
+    kept = []
+    for k in range(traj.shape[0] - 1):
+        ax, ay = list(traj[k][:2])
+        bx, by = list(traj[k + 1][:2])
+        az = traj[k][2]
+        a_in = _inside(ax, ay, *bbox)
+        b_in = _inside(bx, by, *bbox)
+        if a_in:
+            kept.append([ax, ay, az])
+            if not b_in:
+                ix, iy, _ = bisect_box_crossing(ax, ay, bx, by, bbox)
+                kept.append([ix, iy, az])
+        elif b_in:
+            ix, iy, _ = bisect_box_crossing(ax, ay, bx, by, bbox, thresh)
+            kept.append([ix, iy, az])
+    if not kept:
+        return np.zeros((0, 3))
+    return np.array(kept)
+
+
+def transform_traj(traj, rot_mat, dx, dy, view, px):
+    """rotate -> translate -> clip -> grid coordinates, for one (k,3) trajectory.  Mutates `traj` like the
+    reference (bev_generator.py:226-231)."""
+    traj[:, :3] = np.matmul(rot_mat, traj[:, :3].T).T
+    traj[:, 0] += dx
+    traj[:, 1] += dy
+    return pos2grid_inplace(crop_trajectory(traj, view), view, px)
+
+
+# ----------------------------------------------------------------------------------------------
+#  polynomial warp (data augmentation, --bev_do_warp)
+# ----------------------------------------------------------------------------------------------
+def cal_warp_params(idx_0, idx_1, idx_max):
+    a_1 = (idx_1 - idx_0**2 / idx_max) / (idx_0 * (1.0 - idx_0 / idx_max))
+    a_2 = (1.0 - a_1) / idx_max
+    return (a_1, a_2)
+
+
+def get_random_warp_params(mean_ratio, max_ratio, I, J):
+    max_val = max_ratio * (I / 2.0)
+    mean_val = mean_ratio * max_val
+    i_warp = np.random.normal(mean_val, max_val)
+    j_warp = np.random.normal(mean_val, max_val)
+    if abs(i_warp) > max_val:
+        i_warp = max_val
+    if abs(j_warp) > max_val:
+        j_warp = max_val
+    if random.random() < 0.5:
+        i_warp = -i_warp
+    if random.random() < 0.5:
+        j_warp = -j_warp
+    return (int(I / 2) + i_warp, int(J / 2) + j_warp)
+
+
+def warp_source_index(coef_1, coef_2, n):
+    """Source index for every warped index 0..n-1: clamp(rint(c1*k + c2*k^2))."""
+    k = np.arange(n, dtype=np.float64)
+    src = np.rint(coef_1 * k + coef_2 * (k * k)).astype(np.int64)
+    return np.clip(src, 0, n - 1)
+
+
+def warp_dense_probmaps(maps, a_1, a_2, b_1, b_2):
+    """out[:, jw, iw] = maps[:, j(jw), i(iw)] -- vectorised gather form of the reference's 2-D loop
+    (note the reference's transposed write, bev_generator.py:523)."""
+    _, I, J = maps.shape
+    i_src = warp_source_index(a_1, a_2, I)
+    j_src = warp_source_index(b_1, b_2, J)
+    # reference loops i_warp over range(I) (clamped to I) and j_warp over range(J) (clamped to J) and
+    # writes B[:, j_warp, i_warp] = A[:, j, i]
+    out = np.zeros(maps.shape)
+    out[:, :J, :I] = maps[:, j_src[:, None], i_src[None, :]]
+    return out
+
+
+def warp_point(x, y, a_1, a_2, b_1, b_2, I, J):
+    if math.isclose(a_2, 0.0, abs_tol=1e-6):
+        xw = x
+    else:
+        xw = int(np.rint((-a_1 + np.sqrt(a_1**2 + 4.0 * a_2 * x)) / (2 * a_2)))
+    if math.isclose(b_2, 0.0, abs_tol=1e-6):
+        yw = y
+    else:
+        yw = int(np.rint((-b_1 + np.sqrt(b_1**2 + 4.0 * b_2 * y)) / (2 * b_2)))
+    xw = 0 if xw < 0 else (I - 1 if xw >= I else xw)
+    yw = 0 if yw < 0 else (J - 1 if yw >= J else yw)
+    return (xw, yw)
+
+
+def warp_sparse_points(pnts, a_1, a_2, j_warp, j_mid, px):
+    """Inverse warp of trajectory vertices; the j axis uses the mirrored warp centre."""
+    b_1r, b_2r = cal_warp_params(px - j_warp, j_mid, px - 1)
+    for k in range(pnts.shape[0]):
+        xw, yw = warp_point(pnts[k, 0], pnts[k, 1], a_1, a_2, b_1r, b_2r, px, px)
+        pnts[k, 0] = xw
+        pnts[k, 1] = yw
+    return pnts
