@@ -1,0 +1,168 @@
+/*
+ * pca.h -- C ABI of the MI355X (gfx950) semantic point-cloud accumulator + BEV rasteriser.
+ *
+ * The reference (robin-karlsson0/pc-accumulation-lib) is pure Python and has no FFI layer: its
+ * "plugin interface" for this path is the Python classes in sem_pc_accum.py / bev_generator/.  This
+ * header is the boundary a maintainer binds underneath those classes (ctypes stub: INTEGRATION.md);
+ * every entry point names the reference code it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *   - all pointers marked "dev" are device (HBM) pointers, everything else is host memory read
+ *     synchronously during the call;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work and
+ *     never synchronise unless stated;
+ *   - return value 0 = ok, negative = error (text via pca_last_error); no exceptions cross the boundary;
+ *   - one pca_ctx per host thread / GPU; calls on one ctx must target one stream at a time.
+ *
+ * Point store (HBM layout): structure-of-arrays, 37 B per stored point
+ *     x,y,z      f64   reference sem_pc columns 0..2
+ *     intensity  f32   RAW lidar intensity; column 3 = raw (KITTI) or raw/255. (NuScenes), the division
+ *                      is applied by consumers (pca_bev_params.intensity_div255) exactly as the reference's
+ *                      f64 division would
+ *     rgbs       u32   r | g<<8 | b<<16 | sem<<24 (columns 4..7, small non-negative integers)
+ *     inst       i32   column 8
+ *     dyn        u8    column 9
+ * Frames are contiguous segments; `frame_off` (dev, int64[max_frames+1]) holds the segment boundaries
+ * and lives on the device so that integrate() never has to read a count back.
+ */
+#ifndef PCA_H
+#define PCA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCA_VERSION 1
+
+typedef struct pca_ctx pca_ctx;
+
+typedef struct {
+    double *x, *y, *z;   /* dev */
+    float *intensity;    /* dev */
+    uint32_t *rgbs;      /* dev */
+    int32_t *inst;       /* dev */
+    uint8_t *dyn;        /* dev */
+    int64_t capacity;    /* points */
+} pca_store;
+
+/* status bits accumulated on the device, read back with pca_status() */
+#define PCA_STATUS_STORE_OVERFLOW 1u /* a kernel wanted to write past store.capacity (points dropped)     */
+#define PCA_STATUS_UV_OUT_OF_IMAGE 2u /* NuScenes: pixel coords outside (1, wh-1): reference AssertionError */
+
+int pca_version(void);
+int pca_ctx_create(int device, pca_ctx **out);
+void pca_ctx_destroy(pca_ctx *ctx);
+const char *pca_last_error(pca_ctx *ctx);
+/* Synchronises `stream`, returns the OR of PCA_STATUS_* bits raised since the last call and clears them. */
+int pca_status(pca_ctx *ctx, void *stream, uint32_t *status_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  KITTI-360 fused  project -> frustum mask -> nearest sample (rgb + semseg) -> class filter ->
+ *     stable compaction -> append.   Replaces, per frame,
+ *       sem_pc_accum.py:347-402 (velo2frame, velo2img), :323-345 (gen_semantic_pc, called twice from
+ *       kitti360_sem_pc_accum.py:132-135), :317-321 (filter_semseg_pc), kitti360_sem_pc_accum.py:136-156.
+ *     One launch handles a BATCH of frames (frame k appends into slot first_slot+k); kept points keep
+ *     their input order (the reference's boolean-mask compaction is stable).
+ *     If frame.sem_gt != NULL the use_gt_sem branch (kitti360_sem_pc_accum.py:139-144) is taken:
+ *     no projection, rgb = 0, class = sem_gt[p].
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float *pts;      /* dev [n,4] f32 x,y,z,intensity                                    */
+    const uint8_t *rgb;    /* dev [H,W,3] u8, or NULL with sem_gt                              */
+    const uint8_t *sem;    /* dev [H,W]   u8 class map, or NULL with sem_gt                    */
+    const uint8_t *sem_gt; /* dev [n] u8 per-point class, or NULL                              */
+    int32_t n;             /* points in this frame                                             */
+    int32_t tile0;         /* index of the frame's first tile in the launch: sum of pca_kitti_tiles(n_j), j<k */
+} pca_kitti_frame;
+
+int pca_kitti_tile_points(void);            /* points per tile (launch granularity)             */
+int pca_kitti_tiles(int32_t n);             /* tiles a frame of n points occupies (>= 1)        */
+
+/* frames: HOST array of n_frames descriptors (copied into the launch).  P: 3x4 row-major f64
+ * (P_velo_frame).  filter_mask: 256-bit class set.  frame_off[first_slot] must hold the append position;
+ * frame_off[first_slot+k+1] is written for every frame k. */
+int pca_kitti_project_sample_filter(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames, const double P[12],
+                                    int H, int W, const uint64_t filter_mask[4], const pca_store *store,
+                                    int64_t *frame_off /*dev*/, int first_slot, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1n NuScenes (oracle pose)  nearest sample from 6 camera images -> invalid / class filter ->
+ *     stable compaction -> ego->world transform -> append.
+ *     Replaces nuscenes_oracle_sem_pc_accum.py:457-501 and datasets/nuscenes_utils.py:181-214 ('nearest').
+ *     pc: dev [n,7] f64 rows x,y,z,intensity,u,v,inst;  cam_idx: dev [n] int64 (-1: on no image);
+ *     imgs: dev [ncam,H,W,3] u8; sems: dev [ncam,H,W] u8;  T: 4x4 row-major f64 (T_ego_world).
+ * ------------------------------------------------------------------------------------------------ */
+int pca_nusc_sample_filter_transform(pca_ctx *ctx, const double *pc, const int64_t *cam_idx, int32_t n,
+                                     const uint8_t *imgs, const uint8_t *sems, int ncam, int H, int W,
+                                     const double T[16], const uint64_t filter_mask[4], const pca_store *store,
+                                     int64_t *frame_off /*dev*/, int slot, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K0n NuScenes lidar -> ego -> global -> N cameras, pinhole projection, last camera wins.
+ *     Replaces obs_dataloaders/nuscenes_obs_dataloader.py:162-202 and
+ *     datasets/nuscenes_utils.py:46-60, :112-136 (view_points = nuscenes-devkit, restated).
+ *     pc_lidar dev [n,3] f64.  T_cam_from_glob [ncam,16], K [ncam,9], wh [ncam,2] host arrays.
+ *     Outputs dev: pc_in_ego [n,3], uv [n,2] f64, cam_idx [n] int64.
+ * ------------------------------------------------------------------------------------------------ */
+int pca_nusc_project_cams(pca_ctx *ctx, const double *pc_lidar, int32_t n, const double T_ego_from_lidar[16],
+                          const double T_glob_from_ego[16], const double *T_cam_from_glob, const double *K,
+                          const double *wh, int ncam, double *pc_in_ego, double *uv, int64_t *cam_idx,
+                          void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  in-place rigid re-transform of every stored point of frames [slot_begin, slot_end).
+ *     Replaces sem_pc_accum.py:167-183 (update_sem_pcs).  Ts: n_T 4x4 row-major matrices applied one
+ *     after the other (n_T = 1 is the reference's per-step call; n_T > 1 applies a backlog of steps in
+ *     one pass over HBM with identical roundings).
+ * ------------------------------------------------------------------------------------------------ */
+int pca_retransform(pca_ctx *ctx, const pca_store *store, const int64_t *frame_off /*dev*/, int slot_begin,
+                    int slot_end, const double *Ts, int n_T, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3  dyn[p] = 1 where inst[p] == inst_idx, for n_pairs (slot, inst_idx) pairs.
+ *     Replaces nuscenes_oracle_sem_pc_accum.py:223-229, :243-250.
+ * ------------------------------------------------------------------------------------------------ */
+int pca_mark_dynamic(pca_ctx *ctx, const pca_store *store, const int64_t *frame_off /*dev*/, const int32_t *slots,
+                     const int32_t *inst_idx, int n_pairs, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4-K7  BEV rasteriser: window [slot_begin, slot_end), 'present' = [slot_begin, slot_split),
+ *     'future' = [slot_split, slot_end), 'full' = both.  Replaces
+ *       kitti360_sem_pc_accum.py:189-213 / nuscenes_oracle_sem_pc_accum.py:535-581 (window assembly, origin),
+ *       bev_generator/bev_generator.py:127-160, :207-255, :737-747 (rotate, translate, crop, height, floor),
+ *       bev_generator/sem_bev.py:57-118 (static partition, maps), :535-554 (min z), :619-669 (rgb median),
+ *       bev_generator/bev_generator.py:373-480 (counts, dirichlet, intensity), sem_bev.py:593-617, :204-257 (fp16).
+ *     Output (dev): planes f64 [21,px,px] and/or planes_f16 [21,px,px] (either may be NULL), order
+ *       set-major {present,future,full} x {road,intensity,r,g,b,dynamic,elevation}.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    double origin[3];         /* bev_frame_coords                                                   */
+    double R[9];              /* rotation_matrix_3d(rot_ang) evaluated on the host (np.cos/np.sin)  */
+    double dx, dy;            /* augmentation translation                                           */
+    double view;              /* zoom_scalar * view_size                                            */
+    double height_filter;     /* keep z < height_filter; NaN disables                               */
+    double int_scaler, int_sep_scaler, int_mid_threshold;
+    double rgb_fill;          /* value of an empty cell before /255                                 */
+    int32_t px;
+    int32_t road_class;
+    uint64_t dynobj_mask[4];  /* classes counted in the 'dynamic' plane                             */
+    int32_t intensity_div255;
+    int32_t pad;
+} pca_bev_params;
+
+/* bytes of scratch the rasteriser needs for a window of at most max_points and a px x px grid */
+int64_t pca_bev_workspace_bytes(int64_t max_points, int px);
+
+/* intensity64 (dev, may be NULL): f64 intensities indexed like the store, overriding store.intensity
+ * (for callers whose column 3 is not f32-representable).  max_points bounds the window size. */
+int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensity64,
+                     const int64_t *frame_off /*dev*/, int slot_begin, int slot_split, int slot_end,
+                     int64_t max_points, const pca_bev_params *prm, void *workspace /*dev*/,
+                     int64_t workspace_bytes, double *planes /*dev*/, uint16_t *planes_f16 /*dev*/, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCA_H */

@@ -1,0 +1,160 @@
+"""Semantic BEV generator -- drop-in for the reference's ``bev_generator.sem_bev.SemBEVGenerator``.
+
+All 21 planes (7 per point set) come out of one device launch sequence (csrc/pca_bev.hip); this class
+only frames the problem (heading, augmentation), handles trajectories / optional warp on the host and
+packs the reference's output dict (README.md:60-99 of the reference: keys, shapes, float16).
+"""
+import numpy as np
+
+from .bev_generator import PLANES, SETS, BEVGenerator, WindowPart
+
+
+class SemBEVGenerator(BEVGenerator):
+
+    def __init__(self,
+                 sem_idxs: dict,
+                 view_size: int,
+                 pixel_size: int,
+                 max_trans_radius: float = 0.,
+                 zoom_thresh: float = 0.,
+                 do_warp: bool = False,
+                 int_scaler: float = 1.,
+                 int_sep_scaler: float = 1.,
+                 int_mid_threshold: float = 0.5,
+                 height_filter=None,
+                 rgb_fill: int = 0):
+        super().__init__(view_size, pixel_size, max_trans_radius, zoom_thresh, do_warp, int_scaler, int_sep_scaler,
+                         int_mid_threshold, height_filter)
+        self.sem_idxs = sem_idxs     # semantic name -> class index ('road', 'car', 'truck', 'bus', 'motorcycle')
+        self.dyn_idx = 9             # column of the dynamic flag
+        self.rgb_fill = rgb_fill
+        self._frame = None
+
+    # ------------------------------------------------------------------------------------------
+    def generate_bev_device(self, pc_present, pc_future, pc_full, want_f64=False):
+        """Device tensors only: (planes_f16, planes_f64|None), [21,px,px].  Used by the sharded runner and
+        the benchmark, where BEVs stay in HBM until they are gathered."""
+        if self._frame is None:
+            rot_mat, dx, dy, view = np.eye(3), 0., 0., float(self.view_size)
+        else:
+            rot_mat, dx, dy, view = self._frame
+        return self.rasterise(pc_present, pc_future, pc_full, rot_mat, dx, dy, view, want_f64)
+
+    def generate_bev(self, pc_present, pc_future, pc_full, trajs_present, trajs_future, trajs_full,
+                     gt_lane_trajs=None):
+        """Inputs are what ``generate`` hands over: device window parts or host arrays in BEV-frame metres
+        (the rotation/crop/grid steps the reference runs before this call are part of the device pipeline)."""
+        if not isinstance(pc_present, WindowPart) and self._frame is None:
+            # called directly with the reference's pre-gridded rows: put every point at its cell centre
+            pc_present, pc_future, pc_full = (self._grid_rows_to_metres(p) for p in (pc_present, pc_future, pc_full))
+        p16, p64 = self.generate_bev_device(pc_present, pc_future, pc_full, want_f64=self.do_warp)
+        self._frame = None
+        if self.do_warp:
+            px = self.pixel_size
+            i_mid = j_mid = int(px / 2)
+            i_warp, j_warp = self.get_random_warp_params(0.15, 0.30, px, px)
+            a_1, a_2 = self.cal_warp_params(i_warp, i_mid, px - 1)
+            b_1, b_2 = self.cal_warp_params(j_warp, j_mid, px - 1)
+            maps = self.warp_dense_probmaps(p64.cpu().numpy(), a_1, a_2, b_1, b_2)
+            args = (a_1, a_2, b_1, b_2, i_mid, j_mid, i_warp, j_warp)
+            trajs_present = self.warp_trajs(trajs_present, *args)
+            trajs_future = self.warp_trajs(trajs_future, *args)
+            trajs_full = self.warp_trajs(trajs_full, *args)
+            if gt_lane_trajs is not None:
+                gt_lane_trajs = self.warp_trajs(gt_lane_trajs, *args)
+            planes = maps.astype(np.float16)
+        else:
+            planes = p16.cpu().numpy()
+        return self.pack_bev(planes, trajs_present, trajs_future, trajs_full, gt_lane_trajs)
+
+    @staticmethod
+    def pack_bev(planes, trajs_present, trajs_future, trajs_full, gt_lane_trajs=None):
+        """planes: float16 [21,px,px] set-major -> the reference's dict."""
+        bev = {}
+        trajs = {'present': trajs_present, 'future': trajs_future, 'full': trajs_full}
+        for s, name in enumerate(SETS):
+            p = planes[7 * s:7 * s + 7]
+            bev[f'road_{name}'] = p[0]
+            bev[f'trajs_{name}'] = trajs[name]
+            bev[f'intensity_{name}'] = p[1]
+            bev[f'rgb_{name}'] = p[2:5]
+            bev[f'dynamic_{name}'] = p[5]
+            bev[f'elevation_{name}'] = p[6]
+        if gt_lane_trajs is not None:
+            bev['gt_lanes'] = gt_lane_trajs
+        return bev
+
+    # ------------------------------------------------------------------------------------------
+    def _grid_rows_to_metres(self, rows):
+        rows = np.array(rows, dtype=np.float64)
+        px, view = self.pixel_size, float(self.view_size)
+        rows[:, 0:2] = (rows[:, 0:2] + 0.5 - 0.5 * px) * view / px
+        return rows
+
+    def _planes_from_grid_rows(self, pc):
+        rows = self._grid_rows_to_metres(pc)
+        rows[:, 9] = 0                       # these helpers reduce whatever rows they are given
+        hf, self.height_filter = self.height_filter, None
+        try:
+            empty = np.zeros((0, 10))
+            _, p64 = self.rasterise(rows, empty, empty, np.eye(3), 0., 0., float(self.view_size), want_f64=True)
+        finally:
+            self.height_filter = hf
+        return p64[:7].cpu().numpy()
+
+    def get_elevation_map(self, pc: np.array):
+        """pc: pre-gridded rows (columns 0,1 = cell indices).  Returns (min-z map, observed mask)."""
+        p = self._planes_from_grid_rows(pc)
+        mask = np.zeros((self.pixel_size, self.pixel_size), dtype=bool)
+        ij = np.asarray(pc)[:, :2].astype(int)
+        mask[self.pixel_size - 1 - ij[:, 1], ij[:, 0]] = True
+        return p[6], mask
+
+    def get_rgb_maps(self, pc: np.array):
+        """Per-cell channel medians (0..255 scale) of pre-gridded rows; empty cells hold rgb_fill."""
+        p = self._planes_from_grid_rows(pc)
+        return p[2] * 255., p[3] * 255., p[4] * 255.
+
+    def road_marking_transform(self, intensity_map, int_scaler, int_sep_scaler, int_mid_threshold):
+        out = int_scaler * self.sigmoid(int_sep_scaler * (intensity_map - int_mid_threshold))
+        out[out > 1.] = 1.
+        return out
+
+    @staticmethod
+    def sigmoid(z):
+        return 1 / (1 + np.exp(-z))
+
+    # ------------------------------------------------------------------------------------------
+    def viz_bev(self, bev, file_path, rgbs=[], semsegs=[]):
+        """Writes a PNG overview of one BEV sample (plot layout is not part of the parity contract)."""
+        import matplotlib
+        matplotlib.use('Agg')
+        import matplotlib.pyplot as plt
+        sets = [s for s in SETS if f'road_{s}' in bev]
+        cols = ('road', 'intensity', 'rgb', 'dynamic', 'elevation')
+        n_img = len(rgbs)
+        rows = len(sets) + (1 if n_img else 0)
+        fig, axes = plt.subplots(rows, max(len(cols), n_img, 1), figsize=(3 * max(len(cols), n_img, 1), 3 * rows),
+                                 squeeze=False)
+        for ax in axes.ravel():
+            ax.axis('off')
+        for r, s in enumerate(sets):
+            for c, key in enumerate(cols):
+                img = np.asarray(bev[f'{key}_{s}'], dtype=np.float32)
+                ax = axes[r][c]
+                if key == 'rgb':
+                    ax.imshow(np.clip(np.transpose(img, (1, 2, 0)), 0, 1))
+                else:
+                    ax.imshow(img, vmin=None if key == 'elevation' else 0, vmax=None if key == 'elevation' else 1)
+                ax.set_title(f'{key}_{s}', fontsize=8)
+                if key == 'road':
+                    H = self.pixel_size
+                    for t in bev.get(f'trajs_{s}', []):
+                        t = np.asarray(t)
+                        if t.shape[0]:
+                            ax.plot(t[:, 0], H - 1 - t[:, 1], 'r-', linewidth=1)
+        for k in range(n_img):
+            axes[rows - 1][k].imshow(np.asarray(rgbs[k]))
+        fig.tight_layout()
+        fig.savefig(file_path)
+        plt.close(fig)

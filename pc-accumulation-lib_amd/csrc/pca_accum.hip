@@ -1,0 +1,487 @@
+// pca_accum.hip -- per-frame "integrate" kernels for gfx950 (MI355X):
+//   K1  kitti_project_sample_filter      K1n nusc_sample_filter_transform    K0n nusc_project_cams
+//   K2  retransform                      K3  mark_dynamic
+// All are HBM-bound streaming kernels (no MFMA: the only contractions are 3x4 / 4x4 per point).
+#include "pca_common.h"
+
+#define TILE_PTS 1024      // points per tile
+#define BLK 256            // threads per workgroup (4 waves)
+#define PPT 4              // points per thread; point (k, t) of a tile is tile*1024 + k*256 + t
+
+// ---------------------------------------------------------------------------------------------
+// Stable block-level compaction: given keep[k] for the PPT points of each thread (point order =
+// k-major, then thread), returns the position of each kept point among the tile's kept points and
+// the global exclusive prefix of the tile obtained by decoupled look-back.
+// ---------------------------------------------------------------------------------------------
+struct TileScan {
+    uint32_t local[PPT];   // rank of the point inside the tile (valid where keep)
+    uint32_t total;        // kept points of the tile
+    uint64_t excl;         // kept points of all earlier tiles of the launch
+};
+
+__device__ __forceinline__ TileScan tile_compact(const bool keep[PPT], uint64_t *state, int tile, uint32_t epoch)
+{
+    __shared__ uint32_t s_wtot[PPT][BLK / PCA_WAVE];
+    __shared__ uint64_t s_excl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t lane_rank[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const uint64_t b = __ballot(keep[k]);
+        lane_rank[k] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wtot[k][wave] = (uint32_t)__popcll(b);
+    }
+    __syncthreads();
+    TileScan r;
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k)
+#pragma unroll
+        for (int w = 0; w < BLK / PCA_WAVE; ++w) {
+            if (w == wave) r.local[k] = run + lane_rank[k];
+            run += s_wtot[k][w];
+        }
+    r.total = run;
+    if (wave == 0) {
+        const uint64_t e = lb_exclusive_prefix(state, tile, (uint64_t)run, epoch);
+        if (lane == 0) s_excl = e;
+    }
+    __syncthreads();
+    r.excl = s_excl;
+    return r;
+}
+
+__device__ __forceinline__ int draw_tile(uint32_t *ticket, int total_tiles)
+{
+    __shared__ int s_tile;
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(ticket, 1u);
+        if ((int)t == total_tiles - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_tile = (int)t;
+    }
+    __syncthreads();
+    return s_tile;
+}
+
+// =============================================================================================
+// K1  KITTI-360: project + frustum mask + nearest sample + class filter + stable append
+// =============================================================================================
+struct K1Args {
+    const pca_kitti_frame *frames;   // dev array, or nullptr -> `one`
+    pca_kitti_frame one;
+    int n_frames, total_tiles;
+    Mat34 P;
+    int H, W;
+    ClassMask filt;
+    pca_store st;
+    int64_t *frame_off;
+    int first_slot;
+    uint64_t *state;
+    uint32_t *ticket;   // [0] ticket, [1] status
+    uint32_t epoch;
+};
+
+__global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a)
+{
+    const int tile = draw_tile(a.ticket, a.total_tiles);
+    // frame of this tile (wave-uniform scalar search; batches are at most a few hundred frames)
+    int f = 0;
+    pca_kitti_frame fr = a.one;
+    if (a.frames) {
+        int lo = 0, hi = a.n_frames - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.frames[mid].tile0 <= tile) lo = mid; else hi = mid - 1;
+        }
+        f = lo;
+        fr = a.frames[f];
+    }
+    const int tin = tile - fr.tile0;                       // tile index inside the frame
+    const int ftiles = fr.n > 0 ? (fr.n + TILE_PTS - 1) / TILE_PTS : 1;
+    const int64_t base_pt = (int64_t)tin * TILE_PTS;
+
+    bool keep[PPT];
+    float4 q[PPT];
+    uint32_t packed[PPT];
+    const float4 *pts = reinterpret_cast<const float4 *>(fr.pts);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int64_t p = base_pt + k * BLK + threadIdx.x;
+        keep[k] = false;
+        packed[k] = 0;
+        q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < fr.n) q[k] = pts[p];                       // 16 B / lane, fully coalesced
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int64_t p = base_pt + k * BLK + threadIdx.x;
+        if (p >= fr.n) continue;
+        if (fr.sem_gt) {                                   // use_gt_sem: no projection, rgb = 0
+            const unsigned c = fr.sem_gt[p];
+            keep[k] = !in_mask(a.filt, c);
+            packed[k] = (uint32_t)c << 24;
+            continue;
+        }
+        const double x = (double)q[k].x, y = (double)q[k].y, z = (double)q[k].z;
+        const double fx = row4(a.P.m + 0, x, y, z);
+        const double fy = row4(a.P.m + 4, x, y, z);
+        double d = row4(a.P.m + 8, x, y, z);
+        if (d == 0.0) d = -1e-6;
+        const double ad = fabs(d);
+        const double uf = rint(fx / ad);
+        const double vf = rint(fy / ad);
+        const bool ok = (uf >= 0.0) && (uf < (double)a.W) && (vf >= 0.0) && (vf < (double)a.H) && (d > 0.0) &&
+                        (d < __builtin_huge_val());
+        if (!ok) continue;
+        const int64_t pix = (int64_t)(int)vf * a.W + (int)uf;
+        const unsigned c = fr.sem[pix];
+        if (in_mask(a.filt, c)) continue;
+        const uint8_t *px = fr.rgb + pix * 3;
+        packed[k] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)c << 24);
+        keep[k] = true;
+    }
+
+    const TileScan sc = tile_compact(keep, a.state, tile, a.epoch);
+    const int64_t origin = a.frame_off[a.first_slot];      // written by an earlier launch (stream order)
+    const int64_t tile_base = origin + (int64_t)sc.excl;
+    bool overflow = false;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        if (!keep[k]) continue;
+        const int64_t o = tile_base + sc.local[k];
+        if (o >= a.st.capacity) { overflow = true; continue; }
+        a.st.x[o] = (double)q[k].x;
+        a.st.y[o] = (double)q[k].y;
+        a.st.z[o] = (double)q[k].z;
+        a.st.intensity[o] = q[k].w;
+        a.st.rgbs[o] = packed[k];
+        a.st.inst[o] = 0;
+        a.st.dyn[o] = 0;
+    }
+    if (overflow) atomicOr(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
+    if (threadIdx.x == 0 && tin == ftiles - 1)             // last tile of the frame closes its segment
+        a.frame_off[a.first_slot + f + 1] = tile_base + sc.total;
+}
+
+// =============================================================================================
+// K1n NuScenes oracle: nearest sample (6 cameras) + invalid/filter + stable append + ego->world
+// =============================================================================================
+struct K1nArgs {
+    const double *pc;          // [n,7]
+    const int64_t *cam_idx;    // [n]
+    int n, total_tiles;
+    const uint8_t *imgs;       // [ncam,H,W,3]
+    const uint8_t *sems;       // [ncam,H,W]
+    int ncam, H, W;
+    Mat44 T;
+    ClassMask filt;
+    pca_store st;
+    int64_t *frame_off;
+    int slot;
+    uint64_t *state;
+    uint32_t *ticket;
+    uint32_t epoch;
+};
+
+__global__ __launch_bounds__(BLK) void k1n_nusc(const K1nArgs a)
+{
+    const int tile = draw_tile(a.ticket, a.total_tiles);
+    const int64_t base_pt = (int64_t)tile * TILE_PTS;
+    bool keep[PPT];
+    uint32_t packed[PPT];
+    bool bad_uv = false;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int64_t p = base_pt + k * BLK + threadIdx.x;
+        keep[k] = false;
+        packed[k] = 0;
+        if (p >= a.n) continue;
+        const int64_t c = a.cam_idx[p];
+        if (c < 0 || c >= a.ncam) continue;                // features stay -1 -> invalid
+        const double u = a.pc[p * 7 + 4], v = a.pc[p * 7 + 5];
+        if (!(u > 1.0 && u < (double)a.W - 1.0 && v > 1.0 && v < (double)a.H - 1.0)) { bad_uv = true; continue; }
+        const int ui = (int)rint(u), vi = (int)rint(v);
+        const int64_t pix = ((int64_t)c * a.H + vi) * a.W + ui;
+        const unsigned s = a.sems[pix];
+        if (in_mask(a.filt, s)) continue;
+        const uint8_t *px = a.imgs + pix * 3;
+        packed[k] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)s << 24);
+        keep[k] = true;
+    }
+    if (bad_uv) atomicOr(a.ticket + 1, PCA_STATUS_UV_OUT_OF_IMAGE);
+
+    const TileScan sc = tile_compact(keep, a.state, tile, a.epoch);
+    const int64_t tile_base = a.frame_off[a.slot] + (int64_t)sc.excl;
+    bool overflow = false;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        if (!keep[k]) continue;
+        const int64_t p = base_pt + k * BLK + threadIdx.x;
+        const int64_t o = tile_base + sc.local[k];
+        if (o >= a.st.capacity) { overflow = true; continue; }
+        const double *row = a.pc + p * 7;
+        const double x = row[0], y = row[1], z = row[2];
+        a.st.x[o] = row4(a.T.m + 0, x, y, z);
+        a.st.y[o] = row4(a.T.m + 4, x, y, z);
+        a.st.z[o] = row4(a.T.m + 8, x, y, z);
+        a.st.intensity[o] = (float)row[3];
+        a.st.rgbs[o] = packed[k];
+        a.st.inst[o] = (int32_t)row[6];
+        a.st.dyn[o] = 0;
+    }
+    if (overflow) atomicOr(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
+    if (threadIdx.x == 0 && tile == a.total_tiles - 1) a.frame_off[a.slot + 1] = tile_base + sc.total;
+}
+
+// =============================================================================================
+// K0n NuScenes: lidar -> ego -> global -> cameras, pinhole projection, last camera wins
+// =============================================================================================
+#define MAX_CAMS 8
+struct K0nArgs {
+    const double *pc;   // [n,3]
+    int n, ncam;
+    Mat44 T_ego_from_lidar, T_glob_from_ego;
+    Mat44 T_cam_from_glob[MAX_CAMS];
+    double K[MAX_CAMS][9];
+    double wh[MAX_CAMS][2];
+    double *pc_in_ego;  // [n,3]
+    double *uv;         // [n,2]
+    int64_t *cam_idx;   // [n]
+};
+
+__global__ __launch_bounds__(BLK) void k0n_project(const K0nArgs a)
+{
+    for (int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x; p < a.n; p += (int64_t)gridDim.x * BLK) {
+        const double x = a.pc[3 * p], y = a.pc[3 * p + 1], z = a.pc[3 * p + 2];
+        const double ex = row4(a.T_ego_from_lidar.m + 0, x, y, z);
+        const double ey = row4(a.T_ego_from_lidar.m + 4, x, y, z);
+        const double ez = row4(a.T_ego_from_lidar.m + 8, x, y, z);
+        a.pc_in_ego[3 * p] = ex; a.pc_in_ego[3 * p + 1] = ey; a.pc_in_ego[3 * p + 2] = ez;
+        const double gx = row4(a.T_glob_from_ego.m + 0, ex, ey, ez);
+        const double gy = row4(a.T_glob_from_ego.m + 4, ex, ey, ez);
+        const double gz = row4(a.T_glob_from_ego.m + 8, ex, ey, ez);
+        double ou = 0.0, ov = 0.0;
+        int64_t oc = -1;
+        for (int j = 0; j < a.ncam; ++j) {
+            const double *Tc = a.T_cam_from_glob[j].m;
+            const double cx = row4(Tc + 0, gx, gy, gz), cy = row4(Tc + 4, gx, gy, gz), cz = row4(Tc + 8, gx, gy, gz);
+            if (!(cz > 1e-3)) continue;
+            const double *Kj = a.K[j];
+            // viewpad row . [x y z 1] with a zero fourth coefficient
+            double px = Kj[0] * cx; px = fma(Kj[1], cy, px); px = fma(Kj[2], cz, px); px = fma(0.0, 1.0, px);
+            double py = Kj[3] * cx; py = fma(Kj[4], cy, py); py = fma(Kj[5], cz, py); py = fma(0.0, 1.0, py);
+            double pz = Kj[6] * cx; pz = fma(Kj[7], cy, pz); pz = fma(Kj[8], cz, pz); pz = fma(0.0, 1.0, pz);
+            const double u = px / pz, v = py / pz;
+            if (u > 1.0 && u < a.wh[j][0] - 1.0 && v > 1.0 && v < a.wh[j][1] - 1.0) { ou = u; ov = v; oc = j; }
+        }
+        a.uv[2 * p] = ou; a.uv[2 * p + 1] = ov;
+        a.cam_idx[p] = oc;
+    }
+}
+
+// =============================================================================================
+// K2  in-place re-transform of stored frames (chain of n_T rigid transforms, applied in order)
+// =============================================================================================
+#define MAX_CHAIN 16
+struct K2Args {
+    double *x, *y, *z;
+    const int64_t *frame_off;
+    int slot_begin, slot_end;
+    int n_T;
+    Mat34 T[MAX_CHAIN];     // top three rows of each 4x4
+};
+
+__device__ __forceinline__ void apply_chain(const K2Args &a, double &x, double &y, double &z)
+{
+    for (int t = 0; t < a.n_T; ++t) {
+        const double *m = a.T[t].m;
+        const double nx = row4(m + 0, x, y, z), ny = row4(m + 4, x, y, z), nz = row4(m + 8, x, y, z);
+        x = nx; y = ny; z = nz;
+    }
+}
+
+__global__ __launch_bounds__(BLK) void k2_retransform(const K2Args a)
+{
+    const int64_t lo = a.frame_off[a.slot_begin], hi = a.frame_off[a.slot_end];
+    // 16-byte vector body over even-aligned pairs, scalar head/tail
+    const int64_t lo2 = (lo + 1) & ~1ll, hi2 = hi & ~1ll;
+    const int64_t gtid = (int64_t)blockIdx.x * BLK + threadIdx.x, gsz = (int64_t)gridDim.x * BLK;
+    if (gtid == 0) {
+        if (lo < lo2 && lo < hi) { double x = a.x[lo], y = a.y[lo], z = a.z[lo]; apply_chain(a, x, y, z); a.x[lo] = x; a.y[lo] = y; a.z[lo] = z; }
+        if (hi2 < hi && hi2 >= lo2) { double x = a.x[hi2], y = a.y[hi2], z = a.z[hi2]; apply_chain(a, x, y, z); a.x[hi2] = x; a.y[hi2] = y; a.z[hi2] = z; }
+    }
+    double2 *X = reinterpret_cast<double2 *>(a.x), *Y = reinterpret_cast<double2 *>(a.y),
+            *Z = reinterpret_cast<double2 *>(a.z);
+    for (int64_t i = lo2 / 2 + gtid; i < hi2 / 2; i += gsz) {
+        double2 vx = X[i], vy = Y[i], vz = Z[i];
+        apply_chain(a, vx.x, vy.x, vz.x);
+        apply_chain(a, vx.y, vy.y, vz.y);
+        X[i] = vx; Y[i] = vy; Z[i] = vz;
+    }
+}
+
+// =============================================================================================
+// K3  flag points of an instance as dynamic
+// =============================================================================================
+#define MAX_PAIRS 32
+struct K3Args {
+    const int32_t *inst;
+    uint8_t *dyn;
+    const int64_t *frame_off;
+    int n_pairs;
+    int32_t slot[MAX_PAIRS];
+    int32_t inst_idx[MAX_PAIRS];
+};
+
+__global__ __launch_bounds__(BLK) void k3_mark_dynamic(const K3Args a)
+{
+    const int pr = blockIdx.y;
+    const int64_t lo = a.frame_off[a.slot[pr]], hi = a.frame_off[a.slot[pr] + 1];
+    const int32_t want = a.inst_idx[pr];
+    for (int64_t p = lo + (int64_t)blockIdx.x * BLK + threadIdx.x; p < hi; p += (int64_t)gridDim.x * BLK)
+        if (a.inst[p] == want) a.dyn[p] = 1;
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int pca_kitti_tile_points(void) { return TILE_PTS; }
+int pca_kitti_tiles(int32_t n) { return n > 0 ? (n + TILE_PTS - 1) / TILE_PTS : 1; }
+
+int pca_kitti_project_sample_filter(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames, const double P[12],
+                                    int H, int W, const uint64_t filter_mask[4], const pca_store *store,
+                                    int64_t *frame_off, int first_slot, void *stream)
+{
+    if (!ctx) return -1;
+    if (!frames || n_frames <= 0 || !store || !frame_off) { ctx->err = "k1: bad arguments"; return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    int total = 0;
+    for (int k = 0; k < n_frames; ++k) {
+        if (frames[k].tile0 != total) { ctx->err = "k1: frames[k].tile0 must be the running sum of pca_kitti_tiles"; return -1; }
+        if (frames[k].n < 0 || (frames[k].n > 0 && !frames[k].pts)) { ctx->err = "k1: bad frame"; return -1; }
+        if (!frames[k].sem_gt && frames[k].n > 0 && (!frames[k].rgb || !frames[k].sem)) { ctx->err = "k1: frame needs rgb+sem or sem_gt"; return -1; }
+        total += pca_kitti_tiles(frames[k].n);
+    }
+    if (pca_ctx_reserve_tiles(ctx, total, s)) return -1;
+    K1Args a;
+    a.frames = nullptr;
+    a.one = frames[0];
+    if (n_frames > 1) {
+        if (n_frames > ctx->frames_cap) {
+            PCA_CHECK(ctx, hipStreamSynchronize(s));
+            if (ctx->frames_dev) PCA_CHECK(ctx, hipFree(ctx->frames_dev));
+            ctx->frames_cap = n_frames * 2;
+            PCA_CHECK(ctx, hipMalloc(&ctx->frames_dev, sizeof(pca_kitti_frame) * ctx->frames_cap));
+        }
+        // pageable source: the runtime stages it before returning, stream order protects the device copy
+        PCA_CHECK(ctx, hipMemcpyAsync(ctx->frames_dev, frames, sizeof(pca_kitti_frame) * n_frames,
+                                      hipMemcpyHostToDevice, s));
+        a.frames = ctx->frames_dev;
+    }
+    a.n_frames = n_frames;
+    a.total_tiles = total;
+    for (int i = 0; i < 12; ++i) a.P.m[i] = P[i];
+    a.H = H; a.W = W;
+    for (int i = 0; i < 4; ++i) a.filt.w[i] = filter_mask ? filter_mask[i] : 0;
+    a.st = *store;
+    a.frame_off = frame_off;
+    a.first_slot = first_slot;
+    a.state = ctx->tile_state;
+    a.ticket = ctx->ticket;
+    a.epoch = pca_ctx_next_epoch(ctx, s);
+    hipLaunchKernelGGL(k1_kitti, dim3(total), dim3(BLK), 0, s, a);
+    PCA_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+int pca_nusc_sample_filter_transform(pca_ctx *ctx, const double *pc, const int64_t *cam_idx, int32_t n,
+                                     const uint8_t *imgs, const uint8_t *sems, int ncam, int H, int W,
+                                     const double T[16], const uint64_t filter_mask[4], const pca_store *store,
+                                     int64_t *frame_off, int slot, void *stream)
+{
+    if (!ctx) return -1;
+    if (n < 0 || (n > 0 && (!pc || !cam_idx || !imgs || !sems)) || !store || !frame_off) { ctx->err = "k1n: bad arguments"; return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    const int total = pca_kitti_tiles(n);
+    if (pca_ctx_reserve_tiles(ctx, total, s)) return -1;
+    K1nArgs a;
+    a.pc = pc; a.cam_idx = cam_idx; a.n = n; a.total_tiles = total;
+    a.imgs = imgs; a.sems = sems; a.ncam = ncam; a.H = H; a.W = W;
+    for (int i = 0; i < 16; ++i) a.T.m[i] = T[i];
+    for (int i = 0; i < 4; ++i) a.filt.w[i] = filter_mask ? filter_mask[i] : 0;
+    a.st = *store; a.frame_off = frame_off; a.slot = slot;
+    a.state = ctx->tile_state; a.ticket = ctx->ticket;
+    a.epoch = pca_ctx_next_epoch(ctx, s);
+    hipLaunchKernelGGL(k1n_nusc, dim3(total), dim3(BLK), 0, s, a);
+    PCA_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+int pca_nusc_project_cams(pca_ctx *ctx, const double *pc_lidar, int32_t n, const double T_ego_from_lidar[16],
+                          const double T_glob_from_ego[16], const double *T_cam_from_glob, const double *K,
+                          const double *wh, int ncam, double *pc_in_ego, double *uv, int64_t *cam_idx, void *stream)
+{
+    if (!ctx) return -1;
+    if (ncam < 0 || ncam > MAX_CAMS) { ctx->err = "k0n: ncam out of range"; return -1; }
+    if (n <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    K0nArgs a;
+    a.pc = pc_lidar; a.n = n; a.ncam = ncam;
+    for (int i = 0; i < 16; ++i) { a.T_ego_from_lidar.m[i] = T_ego_from_lidar[i]; a.T_glob_from_ego.m[i] = T_glob_from_ego[i]; }
+    for (int j = 0; j < ncam; ++j) {
+        for (int i = 0; i < 16; ++i) a.T_cam_from_glob[j].m[i] = T_cam_from_glob[16 * j + i];
+        for (int i = 0; i < 9; ++i) a.K[j][i] = K[9 * j + i];
+        a.wh[j][0] = wh[2 * j]; a.wh[j][1] = wh[2 * j + 1];
+    }
+    a.pc_in_ego = pc_in_ego; a.uv = uv; a.cam_idx = cam_idx;
+    const int grid = (n + BLK - 1) / BLK < 2048 ? (n + BLK - 1) / BLK : 2048;
+    hipLaunchKernelGGL(k0n_project, dim3(grid), dim3(BLK), 0, s, a);
+    PCA_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+int pca_retransform(pca_ctx *ctx, const pca_store *store, const int64_t *frame_off, int slot_begin, int slot_end,
+                    const double *Ts, int n_T, void *stream)
+{
+    if (!ctx) return -1;
+    if (!store || !frame_off || !Ts || n_T < 0 || slot_end < slot_begin) { ctx->err = "k2: bad arguments"; return -1; }
+    if (n_T == 0 || slot_end == slot_begin) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    for (int t0 = 0; t0 < n_T; t0 += MAX_CHAIN) {
+        K2Args a;
+        a.x = store->x; a.y = store->y; a.z = store->z;
+        a.frame_off = frame_off; a.slot_begin = slot_begin; a.slot_end = slot_end;
+        a.n_T = (n_T - t0) < MAX_CHAIN ? (n_T - t0) : MAX_CHAIN;
+        for (int t = 0; t < a.n_T; ++t)
+            for (int i = 0; i < 12; ++i) a.T[t].m[i] = Ts[(int64_t)(t0 + t) * 16 + i];
+        hipLaunchKernelGGL(k2_retransform, dim3(2048), dim3(BLK), 0, s, a);
+        PCA_CHECK(ctx, hipGetLastError());
+    }
+    return 0;
+}
+
+int pca_mark_dynamic(pca_ctx *ctx, const pca_store *store, const int64_t *frame_off, const int32_t *slots,
+                     const int32_t *inst_idx, int n_pairs, void *stream)
+{
+    if (!ctx) return -1;
+    if (!store || !frame_off || n_pairs < 0 || (n_pairs > 0 && (!slots || !inst_idx))) { ctx->err = "k3: bad arguments"; return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    for (int p0 = 0; p0 < n_pairs; p0 += MAX_PAIRS) {
+        K3Args a;
+        a.inst = store->inst; a.dyn = store->dyn; a.frame_off = frame_off;
+        a.n_pairs = (n_pairs - p0) < MAX_PAIRS ? (n_pairs - p0) : MAX_PAIRS;
+        for (int i = 0; i < a.n_pairs; ++i) { a.slot[i] = slots[p0 + i]; a.inst_idx[i] = inst_idx[p0 + i]; }
+        hipLaunchKernelGGL(k3_mark_dynamic, dim3(64, a.n_pairs), dim3(BLK), 0, s, a);
+        PCA_CHECK(ctx, hipGetLastError());
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,148 @@
+// pca_common.h -- shared host/device helpers of the gfx950 library (not part of the C ABI).
+//
+// Numerics contract: numpy's small matmuls are f64 FMA chains in k order -> explicit
+// fma(); everything else is un-fused -> this library is compiled with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/pca.h"
+
+#define PCA_WAVE 64
+
+struct pca_ctx {
+    int device = 0;
+    std::string err;
+    // decoupled look-back workspace (stable compaction / scans)
+    uint64_t *tile_state = nullptr;   // dev [tile_cap]
+    int64_t tile_cap = 0;
+    uint32_t *ticket = nullptr;       // dev [2]: [0] ticket counter, [1] status bits
+    uint32_t epoch = 0;               // 22-bit launch tag of tile_state entries
+    pca_kitti_frame *frames_dev = nullptr;
+    int frames_cap = 0;
+    uint32_t *status_host = nullptr;  // pinned
+};
+
+#define PCA_CHECK(ctx, expr)                                                                   \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                    \
+            return -1;                                                                         \
+        }                                                                                      \
+    } while (0)
+
+// internal (pca_api.hip)
+int pca_ctx_reserve_tiles(pca_ctx *ctx, int64_t tiles, hipStream_t s);
+uint32_t pca_ctx_next_epoch(pca_ctx *ctx, hipStream_t s);
+
+struct Mat34 { double m[12]; };
+struct Mat44 { double m[16]; };
+struct ClassMask { uint64_t w[4]; };
+
+__device__ __forceinline__ bool in_mask(const ClassMask &m, unsigned c) { return (m.w[c >> 6] >> (c & 63)) & 1ull; }
+
+// row . [x y z 1], k order, fma chain  (== OpenBLAS dgemm for K = 4)
+__device__ __forceinline__ double row4(const double *r, double x, double y, double z)
+{
+    double a = r[0] * x;
+    a = fma(r[1], y, a);
+    a = fma(r[2], z, a);
+    a = fma(r[3], 1.0, a);
+    return a;
+}
+
+// f64 -> f16 bits, round-to-nearest-even straight from the double (numpy astype(np.float16))
+__device__ __forceinline__ uint16_t f64_to_f16_bits(double d)
+{
+    uint64_t b = (uint64_t)__double_as_longlong(d);
+    uint16_t sign = (uint16_t)((b >> 48) & 0x8000u);
+    uint64_t absb = b & 0x7fffffffffffffffull;
+    if (absb >= 0x7ff0000000000000ull)
+        return (uint16_t)(sign | 0x7c00u | ((absb > 0x7ff0000000000000ull) ? 0x200u : 0u));
+    if (absb == 0) return sign;
+    int e = (int)(absb >> 52) - 1023;
+    if (e >= 16) return (uint16_t)(sign | 0x7c00u);
+    uint64_t man = (absb & 0xfffffffffffffull) | 0x10000000000000ull;
+    int shift, he;
+    if (e >= -14) { shift = 42; he = e + 15; }
+    else { shift = 42 + (-14 - e); he = 0; }
+    if (shift > 63) return sign;
+    uint64_t keep = man >> shift;
+    uint64_t rem = man & ((1ull << shift) - 1);
+    uint64_t half = 1ull << (shift - 1);
+    if (rem > half || (rem == half && (keep & 1))) keep++;
+    uint32_t h = (he > 0) ? (uint32_t)((he - 1) << 10) + (uint32_t)keep : (uint32_t)keep;
+    if (h >= 0x7c00u) h = 0x7c00u;
+    return (uint16_t)(sign | h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decoupled look-back (single-pass chained scan).  Tiles are handed out by an atomic ticket so a
+// tile only ever waits on tiles whose workgroups are already running (no dispatch-order assumption).
+// State word (one 8-byte granule, relaxed agent-scope atomic store / load, so flag and value can
+// never be seen torn and no separate payload needs a release/acquire):
+//     [63:62] flag (0 invalid, 1 aggregate, 2 inclusive prefix)  [61:40] epoch  [39:0] value
+// `epoch` tags the launch, so the array never has to be cleared between launches.
+// ---------------------------------------------------------------------------------------------
+#define LB_FLAG_AGG 1ull
+#define LB_FLAG_PFX 2ull
+#define LB_VAL_MASK ((1ull << 40) - 1)
+
+__device__ __forceinline__ uint64_t lb_pack(uint64_t flag, uint32_t epoch, uint64_t v)
+{
+    return (flag << 62) | ((uint64_t)(epoch & 0x3fffffu) << 40) | (v & LB_VAL_MASK);
+}
+
+__device__ __forceinline__ void lb_store(uint64_t *p, uint64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint64_t lb_load(const uint64_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by ALL lanes of ONE wave (the first wave of the block).  Publishes this tile's aggregate,
+// walks back over predecessors, publishes the inclusive prefix, returns the exclusive prefix.
+__device__ __forceinline__ uint64_t lb_exclusive_prefix(uint64_t *state, int tile, uint64_t aggregate, uint32_t epoch)
+{
+    const int lane = threadIdx.x & 63;
+    if (tile == 0) {
+        if (lane == 0) lb_store(&state[0], lb_pack(LB_FLAG_PFX, epoch, aggregate));
+        return 0;
+    }
+    if (lane == 0) lb_store(&state[tile], lb_pack(LB_FLAG_AGG, epoch, aggregate));
+    uint64_t excl = 0;
+    int hi = tile - 1;                      // newest predecessor of the current window
+    while (true) {
+        const int idx = hi - lane;          // lane 0 looks at the closest predecessor
+        uint64_t w = 0;
+        bool valid = true, pfx = false;
+        if (idx >= 0) {
+            w = lb_load(&state[idx]);
+            const uint64_t flag = w >> 62;
+            const bool mine = (uint32_t)((w >> 40) & 0x3fffffu) == (epoch & 0x3fffffu);
+            valid = mine && flag != 0;
+            pfx = valid && flag == LB_FLAG_PFX;
+        }
+        const uint64_t pfx_mask = __ballot(pfx);
+        const uint64_t inv_mask = __ballot(!valid);
+        // lanes below the first prefix (or all 64) must be valid before the window can be consumed
+        const int first_pfx = pfx_mask ? (int)__ffsll((unsigned long long)pfx_mask) - 1 : 64;
+        const uint64_t need = (first_pfx >= 64) ? ~0ull : ((1ull << first_pfx) - 1) | (1ull << first_pfx);
+        if (inv_mask & need) {              // somebody has not published yet: poll again
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        uint64_t v = (idx >= 0 && lane <= first_pfx) ? (w & LB_VAL_MASK) : 0;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        excl += v;
+        if (first_pfx < 64 || hi - 64 < 0) break;
+        hi -= 64;
+    }
+    if (lane == 0) lb_store(&state[tile], lb_pack(LB_FLAG_PFX, epoch, excl + aggregate));
+    return excl;
+}

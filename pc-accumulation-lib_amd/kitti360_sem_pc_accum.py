@@ -1,0 +1,111 @@
+"""KITTI-360 accumulator -- drop-in for the reference's
+``kitti360_sem_pc_accum.Kitti360SemanticPointCloudAccumulator``.
+
+Per frame (reference kitti360_sem_pc_accum.py:41-88): estimate T_new_prev, re-express every stored point
+and pose in the new ego frame (K2, device), append the new frame's projected / sampled / class-filtered
+points (K1, device, fused), evict frames beyond the path horizon.  Nothing is read back from the GPU.
+
+Pose source: the reference calls Open3D point-to-plane ICP (an external C++ library that only FEEDS the
+hot path a 4x4 matrix).  ``pose_provider`` is the hook for that input: a callable ``pc (N,4) -> T_new_prev``.
+The default provider issues the same Open3D call when ``open3d`` is importable and raises otherwise.
+"""
+import numpy as np
+
+from sem_pc_accum import SemanticPointCloudAccumulator
+
+
+class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
+
+    def __init__(self, horizon_dist: float, calib_params: dict, icp_threshold: float, semseg_onnx_path: str,
+                 semseg_filters: list, sem_idxs: dict, use_gt_sem: bool, bev_params: dict):
+        super().__init__(horizon_dist, icp_threshold, semseg_onnx_path, semseg_filters, sem_idxs, use_gt_sem,
+                         bev_params)
+        self.H_velo_cam = calib_params['h_velo_cam']
+        self.P_cam_frame = calib_params['p_cam_frame']
+        self.P_velo_frame = calib_params['p_velo_frame']
+        self.pose_provider = self._icp_pose
+
+    # ---- pose input ----------------------------------------------------------------------------
+    def _icp_pose(self, pc):
+        try:
+            import open3d as o3d
+        except ImportError as e:
+            raise RuntimeError('no pose source: open3d is not installed; set '
+                               '`accumulator.pose_provider = fn(pc) -> 4x4 T_new_prev` (e.g. from GT poses)') from e
+        pcd_new = self.pc2pcd(pc)
+        if self.pcd_prev is None:
+            self.pcd_prev = pcd_new
+        reg = o3d.pipelines.registration.registration_icp(
+            self.pcd_prev, pcd_new, self.icp_threshold, self.icp_trans_init,
+            o3d.pipelines.registration.TransformationEstimationPointToPlane())
+        self.pcd_prev = pcd_new
+        return reg.transformation
+
+    # ---- device inputs -------------------------------------------------------------------------
+    def _frame_tensors(self, rgb, pc, sem_gt):
+        """Uploads one observation (or passes cuda tensors through).  Returns (frame dict, semseg, H, W)."""
+        import torch
+        dev = self.store.device
+
+        def up(a, dtype):
+            if isinstance(a, torch.Tensor):
+                return a.to(device=dev, dtype=dtype).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype_np[dtype])).to(dev)
+
+        dtype_np = {torch.float32: np.float32, torch.uint8: np.uint8}
+        frame = {'pts': up(pc, torch.float32)}
+        semseg = None
+        if sem_gt is None:
+            semseg = self.semseg_model.pred(rgb)[0, 0]
+            img = rgb if isinstance(rgb, torch.Tensor) else np.array(rgb)
+            frame['rgb'] = up(img, torch.uint8)
+            frame['sem'] = up(semseg, torch.uint8)
+            H, W = frame['sem'].shape
+        else:
+            sg = sem_gt if isinstance(sem_gt, torch.Tensor) else np.asarray(sem_gt)[:, -1]
+            frame['sem_gt'] = up(sg, torch.uint8)       # trainIds 0..18 and 255
+            H = W = 1
+        return frame, semseg, H, W
+
+    # ---- integrate -----------------------------------------------------------------------------
+    def integrate(self, observations: list):
+        rgb, pc, sem_gt = observations[0]
+        if not self.use_gt_sem:
+            sem_gt = None
+        T_new_prev = np.asarray(self.pose_provider(pc), dtype=np.float64)
+        self.T_prev_origin = np.matmul(self.T_prev_origin, T_new_prev)
+        frame, semseg, H, W = self._frame_tensors(rgb, pc, sem_gt)
+
+        if len(self.poses) > 0:          # move everything stored so far into the new ego frame
+            self.update_poses(T_new_prev)
+            self.update_sem_pcs(T_new_prev)
+        self.store.append_kitti([frame], self.P_velo_frame, H, W, self.semseg_filters)
+        self.poses.append([0., 0., 0.])
+        self.rgbs.append(rgb)
+        self.semsegs.append(semseg)
+
+        idx = 0
+        if len(self.poses) > 1:
+            idx, path_length = self.remove_observations()
+            print(f'    #pc {self.store.n_frames} |', f'path length {path_length:.2f}')
+        return idx
+
+    def obs2sem_vec_space(self, rgb, pc, sem_gt=None) -> tuple:
+        """Host-array form of one observation: ((M,10) rows, pose, semseg, T_new_prev).  integrate() does
+        not go through here (it keeps the rows on the device)."""
+        from pca_amd.device_store import DeviceStore
+        T_new_prev = np.asarray(self.pose_provider(pc), dtype=np.float64)
+        self.T_prev_origin = np.matmul(self.T_prev_origin, T_new_prev)
+        main, self._store = self._store, DeviceStore(capacity=max(len(pc), 1), max_frames=2)
+        try:
+            frame, semseg, H, W = self._frame_tensors(rgb, pc, sem_gt)
+            self._store.append_kitti([frame], self.P_velo_frame, H, W, self.semseg_filters)
+            rows = self._store.rows(0)
+        finally:
+            self._store = main
+        return rows, [0., 0., 0.], semseg, T_new_prev
+
+    # ---- BEV -----------------------------------------------------------------------------------
+    def generate_bev(self, present_idx: int = None, bev_num: int = 1, gen_future: bool = False):
+        pcs, trajs = self._window_inputs(present_idx, gen_future)
+        return self._run_bev(pcs, trajs, bev_num)

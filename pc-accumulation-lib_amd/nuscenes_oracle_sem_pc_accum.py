@@ -1,0 +1,164 @@
+"""NuScenes accumulator with oracle (ground-truth) ego poses -- drop-in for the reference's
+``nuscenes_oracle_sem_pc_accum.NuScenesOracleSemanticPointCloudAccumulator``.
+
+Per frame (reference :139-270): sample rgb + semseg of the camera each point was projected on, drop
+invalid / filtered points, transform ego -> world (K1n, one fused device kernel), run the GT-box tracker
+on the host and flag points of moving instances -- retroactively in all stored frames -- with K3.
+"""
+import numpy as np
+
+from pca_amd.tracker import InstanceTracker
+from sem_pc_accum import SemanticPointCloudAccumulator
+
+
+def homo_transform(tf, points):
+    from datasets.nuscenes_utils import homo_transform as _h
+    return _h(tf, points)
+
+
+class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
+
+    def __init__(self,
+                 semseg_onnx_path=None,
+                 semseg_filters=None,
+                 sem_idxs=None,
+                 use_gt_sem=None,
+                 bev_params=None,
+                 loc=None,
+                 get_gt_lanes=False,
+                 dataroot=None):
+        super().__init__(None, None, semseg_onnx_path, semseg_filters, sem_idxs, use_gt_sem, bev_params)
+        if use_gt_sem:
+            raise NotImplementedError()
+        self.ts = 0
+        self.xyz_idx, self.int_idx, self.rgb_idx, self.sem_idx, self.inst_idx, self.dyn_idx = 0, 3, 4, 7, 8, 9
+        self._store_args = dict(intensity_div255=True, capacity=1 << 22)
+        self.T_global_world = None      # 'global' (map) -> 'world' (first ego frame), set by the first frame
+        self.ego_pose_z = 1.            # lift the ego pose from the road surface
+
+        self._tracker = InstanceTracker(track_classes=[0, 1, 2, 3, 5], trans_thresh=1.0)
+        self.track_inst_clss = self._tracker.track_classes
+        self.dyn_obj_trans_thresh = self._tracker.trans_thresh
+
+        self.map = loc
+        self.ego_global_xs = []
+        self.ego_global_ys = []
+        self.get_gt_lanes = get_gt_lanes
+        if self.get_gt_lanes:
+            from datasets.nuscenes_lanemap import get_centerlines
+            self.gt_lane_poses = get_centerlines(dataroot, loc)
+
+    # tracker state under the reference's attribute names
+    @property
+    def instances(self):
+        return self._tracker.observations
+
+    @property
+    def dyn_instances(self):
+        return self._tracker.dynamic
+
+    @property
+    def token2idx(self):
+        return [dict(t, ts=k) for k, t in enumerate(self._tracker.index_at)]
+
+    # ---- integrate -----------------------------------------------------------------------------
+    def integrate(self, observations: list):
+        obs = observations[0]
+        T_ego_global = obs['ego_at_lidar_ts']
+        if self.T_global_world is None:
+            self.T_global_world = np.linalg.inv(T_ego_global)
+            if self.get_gt_lanes:
+                self.gt_lane_poses = [homo_transform(self.T_global_world, lane) for lane in self.gt_lane_poses]
+
+        pose, semsegs = self._append_frame(obs['images'], obs['pc'], obs['pc_cam_idx'], T_ego_global,
+                                           self.ego_pose_z)
+        self.poses.append(pose)
+        self.rgbs.append(obs['images'])
+        self.semsegs.append(semsegs)
+        self.ego_global_xs.append(obs['ego_global_x'])
+        self.ego_global_ys.append(obs['ego_global_y'])
+
+        # fake detector + tracker on GT boxes: host decides, device flags
+        centers = [homo_transform(self.T_global_world, np.expand_dims(c, 0))[0] for c in obs['inst_center']]
+        marks = self._tracker.observe(self.ts, obs['inst_tokens'], obs['inst_cls'], centers)
+        self.store.mark_dynamic(marks)
+
+        if len(self.poses) > 1:
+            path_length = self._track.push_segment()
+        else:
+            path_length = 0
+        print(f'    ts {self.ts} | #pc {self.store.n_frames} |', f'path length {path_length:.2f}')
+        self.ts += 1
+
+    def _ego_world(self, T_ego_global, ego_pose_z):
+        T_ego_world = self.T_global_world @ T_ego_global
+        pose = T_ego_world[:3, -1].tolist()
+        pose[2] += ego_pose_z
+        return T_ego_world, pose
+
+    def _append_frame(self, rgbs, pc, pc_cam_idx, T_ego_global, ego_pose_z):
+        import torch
+        T_ego_world, pose = self._ego_world(T_ego_global, ego_pose_z)
+        dev = self.store.device
+        semsegs = [self.semseg_model.pred(rgb)[0, 0] for rgb in rgbs]
+
+        def up(a, np_dtype, t_dtype):
+            if isinstance(a, torch.Tensor):
+                return a.to(device=dev, dtype=t_dtype).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np_dtype)).to(dev)
+
+        if isinstance(rgbs, torch.Tensor):
+            imgs = up(rgbs, np.uint8, torch.uint8)
+        else:
+            imgs = up(np.stack([np.array(rgb) for rgb in rgbs]), np.uint8, torch.uint8)
+        if isinstance(semsegs[0], torch.Tensor):
+            sems = torch.stack([s.to(device=dev, dtype=torch.uint8) for s in semsegs]).contiguous()
+        else:
+            sems = up(np.stack(semsegs), np.uint8, torch.uint8)
+        self.store.append_nusc(up(pc, np.float64, torch.float64), up(pc_cam_idx, np.int64, torch.int64), imgs, sems,
+                               T_ego_world, self.semseg_filters)
+        return pose, semsegs
+
+    def obs2sem_vec_space(self, rgbs, pc, pc_cam_idx, T_ego_global, ego_pose_z: float = 0) -> tuple:
+        """Host-array form: ((M,10) rows, pose, semsegs).  Raises AssertionError like the reference if a
+        point assigned to a camera has pixel coordinates outside the open box (1, wh-1)."""
+        from pca_amd.device_store import DeviceStore
+        main, self._store = self._store, DeviceStore(capacity=max(len(pc), 1), max_frames=2, intensity_div255=True)
+        try:
+            pose, semsegs = self._append_frame(rgbs, pc, pc_cam_idx, T_ego_global, ego_pose_z)
+            self._store.check_status()
+            rows = self._store.rows(0)
+        finally:
+            self._store = main
+        return rows, pose, semsegs
+
+    # ---- trajectories of other agents (host) ---------------------------------------------------
+    def get_split_dyn_obj_trajs(self, split_idx: int, skip_ego_traj: bool = True):
+        return self._tracker.split_trajectories(split_idx)
+
+    def get_dyn_obj_trajs(self, ts_start: int = 0, ts_end: int = None, skip_ego_traj: bool = True):
+        out = self._tracker.trajectories(ts_start, ts_end)
+        if not skip_ego_traj:
+            out.append(self.poses)
+        return out
+
+    # ---- BEV -----------------------------------------------------------------------------------
+    def generate_bev(self, present_idx: int = None, bev_num: int = 1, gen_future: bool = False):
+        others = self.get_split_dyn_obj_trajs(present_idx)
+        lanes = self.gt_lane_poses if self.get_gt_lanes else None
+        pcs, trajs = self._window_inputs(present_idx, gen_future, others, lanes)
+        self.store.check_status()
+        return self._run_bev(pcs, trajs, bev_num)
+
+    @staticmethod
+    def get_tf_pose(inst_tf: np.array) -> np.array:
+        return inst_tf[:3, -1]
+
+    @staticmethod
+    def get_obj_inst_poses_ts(inst_obs: list) -> tuple:
+        poses, tss = zip(*inst_obs)
+        return poses, tss
+
+    @staticmethod
+    def cal_pose_change(pose_0: np.array, pose_1: np.array) -> float:
+        return np.linalg.norm(pose_1 - pose_0)

@@ -1,0 +1,138 @@
+"""ctypes binding of the gfx950 C-ABI library (include/pca.h).
+
+There is no CPU fallback: if ``libpca_hip.so`` is missing or no GPU is visible the product path raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpca_hip.so')
+
+STATUS_STORE_OVERFLOW = 1
+STATUS_UV_OUT_OF_IMAGE = 2
+
+EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error', 'pca_status',
+           'pca_kitti_tile_points', 'pca_kitti_tiles', 'pca_kitti_project_sample_filter',
+           'pca_nusc_sample_filter_transform', 'pca_nusc_project_cams', 'pca_retransform', 'pca_mark_dynamic',
+           'pca_bev_workspace_bytes', 'pca_bev_generate')
+
+
+class PcaStore(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('z', C.c_void_p), ('intensity', C.c_void_p),
+                ('rgbs', C.c_void_p), ('inst', C.c_void_p), ('dyn', C.c_void_p), ('capacity', C.c_int64)]
+
+
+class PcaKittiFrame(C.Structure):
+    _fields_ = [('pts', C.c_void_p), ('rgb', C.c_void_p), ('sem', C.c_void_p), ('sem_gt', C.c_void_p),
+                ('n', C.c_int32), ('tile0', C.c_int32)]
+
+
+class PcaBevParams(C.Structure):
+    _fields_ = [('origin', C.c_double * 3), ('R', C.c_double * 9), ('dx', C.c_double), ('dy', C.c_double),
+                ('view', C.c_double), ('height_filter', C.c_double), ('int_scaler', C.c_double),
+                ('int_sep_scaler', C.c_double), ('int_mid_threshold', C.c_double), ('rgb_fill', C.c_double),
+                ('px', C.c_int32), ('road_class', C.c_int32), ('dynobj_mask', C.c_uint64 * 4),
+                ('intensity_div255', C.c_int32), ('pad', C.c_int32)]
+
+
+def class_mask(classes):
+    """256-bit class set as 4 x uint64 (classes outside 0..255 can never match a u8 label)."""
+    m = [0, 0, 0, 0]
+    for c in classes or []:
+        c = int(c)
+        if 0 <= c < 256:
+            m[c >> 6] |= 1 << (c & 63)
+    return (C.c_uint64 * 4)(*m)
+
+
+def f64_array(a, n):
+    a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+    assert a.size == n, (a.size, n)
+    return (C.c_double * n)(*a.tolist())
+
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (once) and declares the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; '
+                           f'g.build()"` or `make -C pc-accumulation-lib_amd/csrc` (no CPU fallback exists)')
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    lib.pca_version.restype = C.c_int
+    lib.pca_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    lib.pca_ctx_destroy.argtypes = [vp]
+    lib.pca_ctx_destroy.restype = None
+    lib.pca_last_error.argtypes = [vp]
+    lib.pca_last_error.restype = C.c_char_p
+    lib.pca_status.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
+    lib.pca_kitti_tile_points.restype = C.c_int
+    lib.pca_kitti_tiles.argtypes = [C.c_int32]
+    lib.pca_kitti_project_sample_filter.argtypes = [
+        vp, C.POINTER(PcaKittiFrame), i32, C.POINTER(C.c_double), i32, i32, C.POINTER(C.c_uint64),
+        C.POINTER(PcaStore), vp, i32, vp
+    ]
+    lib.pca_nusc_sample_filter_transform.argtypes = [
+        vp, vp, vp, C.c_int32, vp, vp, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+        C.POINTER(PcaStore), vp, i32, vp
+    ]
+    lib.pca_nusc_project_cams.argtypes = [
+        vp, vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+        C.POINTER(C.c_double), C.POINTER(C.c_double), i32, vp, vp, vp, vp
+    ]
+    lib.pca_retransform.argtypes = [vp, C.POINTER(PcaStore), vp, i32, i32, C.POINTER(C.c_double), i32, vp]
+    lib.pca_mark_dynamic.argtypes = [vp, C.POINTER(PcaStore), vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32, vp]
+    lib.pca_bev_workspace_bytes.argtypes = [i64, i32]
+    lib.pca_bev_workspace_bytes.restype = i64
+    lib.pca_bev_generate.argtypes = [
+        vp, C.POINTER(PcaStore), vp, vp, i32, i32, i32, i64, C.POINTER(PcaBevParams), vp, i64, vp, vp, vp
+    ]
+    _lib = lib
+    return lib
+
+
+class Context:
+    """One pca_ctx per (process, GPU).  All calls are enqueued on torch's current stream."""
+
+    _by_device = {}
+
+    def __init__(self, device_index):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError('pca_amd needs an AMD GPU (torch.cuda.is_available() is False); '
+                               'there is no CPU fallback')
+        self.lib = load()
+        self.device_index = int(device_index)
+        h = C.c_void_p()
+        if self.lib.pca_ctx_create(self.device_index, C.byref(h)) != 0:
+            raise RuntimeError('pca_ctx_create failed')
+        self.h = h
+
+    @classmethod
+    def get(cls, device=None):
+        import torch
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+        if idx not in cls._by_device:
+            cls._by_device[idx] = Context(idx)
+        return cls._by_device[idx]
+
+    def stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream)
+
+    def check(self, rc):
+        if rc != 0:
+            raise RuntimeError('pca: ' + self.lib.pca_last_error(self.h).decode())
+
+    def status(self):
+        """Synchronises the stream and returns (and clears) the device status bits."""
+        st = C.c_uint32(0)
+        self.check(self.lib.pca_status(self.h, self.stream(), C.byref(st)))
+        return st.value

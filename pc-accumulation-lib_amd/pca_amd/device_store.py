@@ -1,0 +1,287 @@
+"""Device-resident point store: the HBM replacement of the reference's ``self.sem_pcs`` list.
+
+Layout (include/pca.h): structure-of-arrays, frames are contiguous segments, the segment boundaries
+``frame_off`` live on the device so that integrate() never reads a count back.  The host only tracks
+UPPER bounds of the append position (every input point kept) for capacity planning; exact counts are
+fetched lazily (``sizes()``) when somebody asks for rows.
+
+Slots: frame k of the live window occupies slot ``head + k``; eviction advances ``head``; when slots or
+capacity run out the live window is moved to the front (rare, amortised).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PcaBevParams, PcaKittiFrame, PcaStore
+
+
+class DeviceStore:
+
+    def __init__(self, capacity=1 << 24, max_frames=4096, device=None, intensity_div255=False):
+        self.ctx = _lib.Context.get(device)
+        self.device = torch.device('cuda', self.ctx.device_index)
+        self.intensity_div255 = bool(intensity_div255)
+        self.max_frames = int(max_frames)
+        self._alloc(int(capacity))
+        self.frame_off = torch.zeros(self.max_frames + 1, dtype=torch.int64, device=self.device)
+        self.head = 0            # first live slot
+        self.tail = 0            # one past the last live slot
+        self.ub_tail = 0         # upper bound of frame_off[tail]
+        self.lb_head = 0         # lower bound of frame_off[head] (exact after a sync)
+        self._ub = []            # per live frame: upper bound of its size (its input point count)
+        self._ws = None
+        self._planes16 = {}
+        self._planes64 = {}
+
+    # ---- memory ----------------------------------------------------------------------------
+    def _alloc(self, cap):
+        d = self.device
+        self.capacity = cap
+        self.x = torch.empty(cap, dtype=torch.float64, device=d)
+        self.y = torch.empty(cap, dtype=torch.float64, device=d)
+        self.z = torch.empty(cap, dtype=torch.float64, device=d)
+        self.intensity = torch.empty(cap, dtype=torch.float32, device=d)
+        self.rgbs = torch.empty(cap, dtype=torch.int32, device=d)     # bit pattern of the u32
+        self.inst = torch.empty(cap, dtype=torch.int32, device=d)
+        self.dyn = torch.empty(cap, dtype=torch.uint8, device=d)
+
+    def _arrays(self):
+        return (self.x, self.y, self.z, self.intensity, self.rgbs, self.inst, self.dyn)
+
+    def c_store(self):
+        return PcaStore(self.x.data_ptr(), self.y.data_ptr(), self.z.data_ptr(), self.intensity.data_ptr(),
+                        self.rgbs.data_ptr(), self.inst.data_ptr(), self.dyn.data_ptr(), self.capacity)
+
+    @property
+    def n_frames(self):
+        return self.tail - self.head
+
+    def offsets(self):
+        """Exact segment boundaries of the live frames (host numpy int64, length n_frames+1).  Synchronises."""
+        off = self.frame_off[self.head:self.tail + 1].cpu().numpy()
+        self.lb_head = int(off[0])
+        self.ub_tail = int(off[-1])
+        self._ub = [int(v) for v in np.diff(off)]
+        return off
+
+    def sizes(self):
+        return np.diff(self.offsets())
+
+    def check_status(self):
+        st = self.ctx.status()
+        if st & _lib.STATUS_UV_OUT_OF_IMAGE:
+            raise AssertionError('pts_uv must be all inside image')
+        if st & _lib.STATUS_STORE_OVERFLOW:
+            raise RuntimeError('pca: device point store overflow (points were dropped)')
+
+    def reserve(self, n_new, n_slots=1):
+        """Make room for n_slots more frames holding at most n_new points in total."""
+        if self.tail + n_slots <= self.max_frames and self.ub_tail + n_new <= self.capacity:
+            return
+        off = self.offsets()                       # synchronises: exact numbers
+        a, b = int(off[0]), int(off[-1])
+        live, nf = b - a, self.n_frames
+        new_cap = self.capacity
+        while live + n_new > new_cap:
+            new_cap *= 2
+        new_maxf = self.max_frames
+        while nf + n_slots > new_maxf:
+            new_maxf *= 2
+        old = self._arrays()
+        if new_cap != self.capacity:
+            self._alloc(new_cap)
+            for dst, src in zip(self._arrays(), old):
+                dst[:live] = src[a:b]
+        elif a > 0:                                # slide the live window to the front
+            for t in old:
+                t[:live] = t[a:b].clone()
+        self.max_frames = new_maxf
+        new_off = torch.zeros(new_maxf + 1, dtype=torch.int64, device=self.device)
+        new_off[:nf + 1] = torch.from_numpy(off - a).to(self.device)
+        self.frame_off = new_off
+        self.head, self.tail = 0, nf
+        self.lb_head, self.ub_tail = 0, live
+
+    def evict(self, k):
+        self.head += int(k)
+        del self._ub[:int(k)]
+
+    def max_window_points(self):
+        return max(int(sum(self._ub)), 1)
+
+    def clear(self):
+        self.head = self.tail = 0
+        self.ub_tail = self.lb_head = 0
+        self._ub = []
+        self.frame_off.zero_()
+
+    # ---- K1: KITTI ------------------------------------------------------------------------
+    def append_kitti(self, frames, P, H, W, filters):
+        """frames: list of dicts {pts (n,4) f32 cuda, rgb (H,W,3) u8 cuda | None, sem (H,W) u8 cuda | None,
+        sem_gt (n,) u8 cuda | None}.  One launch appends all of them (stable order) as new slots."""
+        lib, ctx = self.ctx.lib, self.ctx
+        n_in = sum(int(f['pts'].shape[0]) for f in frames)
+        self.reserve(n_in, len(frames))
+        descs = (PcaKittiFrame * len(frames))()
+        tile0 = 0
+        for k, f in enumerate(frames):
+            n = int(f['pts'].shape[0])
+            assert f['pts'].dtype == torch.float32 and f['pts'].is_contiguous()
+            descs[k].pts = f['pts'].data_ptr() if n else None
+            descs[k].rgb = f['rgb'].data_ptr() if f.get('rgb') is not None else None
+            descs[k].sem = f['sem'].data_ptr() if f.get('sem') is not None else None
+            descs[k].sem_gt = f['sem_gt'].data_ptr() if f.get('sem_gt') is not None else None
+            descs[k].n = n
+            descs[k].tile0 = tile0
+            tile0 += lib.pca_kitti_tiles(n)
+        st = self.c_store()
+        Pc = _lib.f64_array(P, 12)
+        ctx.check(lib.pca_kitti_project_sample_filter(ctx.h, descs, len(frames), Pc, int(H), int(W),
+                                                      _lib.class_mask(filters), C.byref(st),
+                                                      self.frame_off.data_ptr(), self.tail, ctx.stream()))
+        self.tail += len(frames)
+        self.ub_tail += n_in
+        self._ub += [int(f['pts'].shape[0]) for f in frames]
+
+    # ---- K1n: NuScenes --------------------------------------------------------------------
+    def append_nusc(self, pc, cam_idx, imgs, sems, T, filters):
+        lib, ctx = self.ctx.lib, self.ctx
+        n = int(pc.shape[0])
+        self.reserve(n)
+        ncam, H, W = sems.shape
+        st = self.c_store()
+        ctx.check(lib.pca_nusc_sample_filter_transform(ctx.h, pc.data_ptr(), cam_idx.data_ptr(), n, imgs.data_ptr(),
+                                                       sems.data_ptr(), int(ncam), int(H), int(W),
+                                                       _lib.f64_array(T, 16), _lib.class_mask(filters),
+                                                       C.byref(st), self.frame_off.data_ptr(), self.tail,
+                                                       ctx.stream()))
+        self.tail += 1
+        self.ub_tail += n
+        self._ub.append(n)
+
+    # ---- K2 / K3 --------------------------------------------------------------------------
+    def retransform(self, Ts):
+        """Applies the 4x4 transform(s) to every live point, in order (Ts: (4,4) or (k,4,4))."""
+        if self.n_frames == 0:
+            return
+        Ts = np.ascontiguousarray(Ts, dtype=np.float64).reshape(-1, 16)
+        st = self.c_store()
+        ctx = self.ctx
+        ctx.check(ctx.lib.pca_retransform(ctx.h, C.byref(st), self.frame_off.data_ptr(), self.head, self.tail,
+                                          _lib.f64_array(Ts, Ts.size), Ts.shape[0], ctx.stream()))
+
+    def mark_dynamic(self, pairs):
+        """pairs: iterable of (frame index in the live window, instance index)."""
+        pairs = list(pairs)
+        if not pairs:
+            return
+        slots = (C.c_int32 * len(pairs))(*[self.head + int(f) for f, _ in pairs])
+        insts = (C.c_int32 * len(pairs))(*[int(i) for _, i in pairs])
+        st = self.c_store()
+        ctx = self.ctx
+        ctx.check(ctx.lib.pca_mark_dynamic(ctx.h, C.byref(st), self.frame_off.data_ptr(), slots, insts, len(pairs),
+                                           ctx.stream()))
+
+    # ---- BEV ------------------------------------------------------------------------------
+    def bev(self, split_frame, prm, want_f64=False, intensity64=None, first_frame=0, last_frame=None):
+        """Rasterises live frames [first_frame, last_frame) with 'present' = frames before split_frame.
+        Returns (planes_f16 [21,px,px] cuda float16, planes_f64 or None)."""
+        ctx, lib = self.ctx, self.ctx.lib
+        last_frame = self.n_frames if last_frame is None else last_frame
+        px = int(prm.px)
+        max_points = self.max_window_points()
+        need = lib.pca_bev_workspace_bytes(max_points, px)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        p16 = torch.empty((21, px, px), dtype=torch.float16, device=self.device)
+        p64 = torch.empty((21, px, px), dtype=torch.float64, device=self.device) if want_f64 else None
+        st = self.c_store()
+        ctx.check(lib.pca_bev_generate(ctx.h, C.byref(st), None if intensity64 is None else intensity64.data_ptr(),
+                                       self.frame_off.data_ptr(), self.head + first_frame, self.head + split_frame,
+                                       self.head + last_frame, max_points, C.byref(prm), self._ws.data_ptr(),
+                                       self._ws.numel(), None if p64 is None else p64.data_ptr(), p16.data_ptr(),
+                                       ctx.stream()))
+        return p16, p64
+
+    # ---- host views (synchronise) -----------------------------------------------------------
+    def rows(self, frame=None):
+        """(M,10) f64 rows exactly as the reference keeps them in sem_pcs (one frame, or all live points)."""
+        off = self.offsets()
+        lo, hi = (int(off[0]), int(off[-1])) if frame is None else (int(off[frame]), int(off[frame + 1]))
+        out = np.empty((hi - lo, 10))
+        out[:, 0] = self.x[lo:hi].cpu().numpy()
+        out[:, 1] = self.y[lo:hi].cpu().numpy()
+        out[:, 2] = self.z[lo:hi].cpu().numpy()
+        i = self.intensity[lo:hi].cpu().numpy().astype(np.float64)
+        out[:, 3] = i / 255. if self.intensity_div255 else i
+        r = self.rgbs[lo:hi].cpu().numpy().view(np.uint32)
+        out[:, 4], out[:, 5], out[:, 6], out[:, 7] = r & 255, (r >> 8) & 255, (r >> 16) & 255, r >> 24
+        out[:, 8] = self.inst[lo:hi].cpu().numpy()
+        out[:, 9] = self.dyn[lo:hi].cpu().numpy()
+        return out
+
+    def frame_rows(self):
+        off = self.offsets()
+        allrows = self.rows()
+        base = int(off[0])
+        return [allrows[int(off[k]) - base:int(off[k + 1]) - base] for k in range(self.n_frames)]
+
+    def load_rows(self, rows_list, intensity64_out=None):
+        """Replaces the content by host (M,10) f64 arrays, one frame each.  Returns a cuda f64 intensity
+        tensor if column 3 is not representable in the store's f32(+/255) encoding, else None."""
+        self.clear()
+        total = int(sum(r.shape[0] for r in rows_list))
+        if total > self.capacity or len(rows_list) > self.max_frames:
+            self.max_frames = max(self.max_frames, len(rows_list))
+            self._alloc(max(total, 1))
+            self.frame_off = torch.zeros(self.max_frames + 1, dtype=torch.int64, device=self.device)
+        rows = np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, 10) for r in rows_list]) if rows_list \
+            else np.zeros((0, 10))
+        c = rows[:, 4:8]
+        if rows.size and not (np.all(c == np.floor(c)) and c.min() >= 0 and c.max() <= 255):
+            raise NotImplementedError('rgb / semantic columns must hold integers 0..255')
+        if rows.size and not np.all(rows[:, 8] == np.floor(rows[:, 8])):
+            raise NotImplementedError('instance column must hold integers')
+        d = self.device
+        self.x[:total] = torch.from_numpy(np.ascontiguousarray(rows[:, 0])).to(d)
+        self.y[:total] = torch.from_numpy(np.ascontiguousarray(rows[:, 1])).to(d)
+        self.z[:total] = torch.from_numpy(np.ascontiguousarray(rows[:, 2])).to(d)
+        inten = rows[:, 3]
+        raw = np.rint(inten * 255.) if self.intensity_div255 else inten
+        raw32 = raw.astype(np.float32)
+        back = raw32.astype(np.float64) / 255. if self.intensity_div255 else raw32.astype(np.float64)
+        i64 = None
+        if not np.array_equal(back, inten):
+            i64 = torch.from_numpy(np.ascontiguousarray(inten)).to(d)
+        self.intensity[:total] = torch.from_numpy(raw32).to(d)
+        cu = c.astype(np.uint32)
+        packed = (cu[:, 0] | (cu[:, 1] << 8) | (cu[:, 2] << 16) | (cu[:, 3] << 24)).astype(np.uint32)
+        self.rgbs[:total] = torch.from_numpy(packed.view(np.int32)).to(d)
+        self.inst[:total] = torch.from_numpy(rows[:, 8].astype(np.int32)).to(d)
+        self.dyn[:total] = torch.from_numpy((rows[:, 9] == 1).astype(np.uint8)).to(d)
+        off = np.concatenate([[0], np.cumsum([r.shape[0] for r in rows_list])]).astype(np.int64)
+        self.frame_off[:off.size] = torch.from_numpy(off).to(d)
+        self.head, self.tail = 0, len(rows_list)
+        self.lb_head, self.ub_tail = 0, total
+        self._ub = [int(r.shape[0]) for r in rows_list]
+        return i64
+
+
+def make_bev_params(origin, R, dx, dy, view, px, height_filter, int_scaler, int_sep_scaler, int_mid_threshold,
+                    road_class, dynobj_classes, intensity_div255, rgb_fill=0.):
+    prm = PcaBevParams()
+    prm.origin[:] = [float(v) for v in origin]
+    prm.R[:] = [float(v) for v in np.asarray(R, dtype=np.float64).ravel()]
+    prm.dx, prm.dy, prm.view = float(dx), float(dy), float(view)
+    prm.height_filter = float('nan') if height_filter is None else float(height_filter)
+    prm.int_scaler = float(int_scaler)
+    prm.int_sep_scaler = float(int_sep_scaler)
+    prm.int_mid_threshold = float(int_mid_threshold)
+    prm.rgb_fill = float(rgb_fill)
+    prm.px = int(px)
+    prm.road_class = int(road_class)
+    prm.dynobj_mask[:] = list(_lib.class_mask(dynobj_classes))
+    prm.intensity_div255 = int(bool(intensity_div255))
+    return prm

@@ -1,0 +1,254 @@
+"""Semantic point-cloud accumulator base class -- drop-in for the reference's
+``sem_pc_accum.SemanticPointCloudAccumulator`` (same constructor, attributes and method names).
+
+State that the reference keeps as Python lists of (M,10) f64 numpy arrays (``self.sem_pcs``) lives in a
+device-resident structure-of-arrays store (pca_amd.device_store.DeviceStore); ``sem_pcs`` is still
+readable (it materialises host copies on access).  Poses, segment distances, images stay host lists
+exactly like the reference.  There is no CPU fallback: constructing an accumulator without a visible
+MI355X raises.
+"""
+import gzip
+import os
+import pickle
+
+import numpy as np
+
+from bev_generator.bev_generator import DeviceWindow
+from bev_generator.rgb_bev import RGBBEVGenerator  # noqa: F401  (import surface of the reference module)
+from bev_generator.sem_bev import SemBEVGenerator
+from pca_amd import host_logic as hl
+
+
+class SemanticPointCloudAccumulator:
+
+    def __init__(self, horizon_dist: float, icp_threshold: float, semseg_onnx_path: str, semseg_filters: list,
+                 sem_idxs: dict, use_gt_sem: bool, bev_params: dict):
+        self.semseg_model = None
+        if use_gt_sem is False:
+            self.semseg_model = SemSegONNX(semseg_onnx_path)
+        self.semseg_filters = semseg_filters
+        self.sem_idxs = sem_idxs
+        self.use_gt_sem = use_gt_sem
+        self.icp_threshold = icp_threshold
+        self.icp_trans_init = np.eye(4)
+        self.T_prev_origin = np.eye(4)
+        self.pcd_prev = None
+        self.horizon_dist = horizon_dist
+
+        self._track = hl.PoseTrack()     # poses (N) and seg_dists (N-1)
+        self.rgbs = []
+        self.semsegs = []
+        self._store = None               # created on first use (needs the GPU)
+        self._store_args = {}
+
+        self.sem_bev_generator = None
+        if bev_params['type'] == 'sem':
+            self.sem_bev_generator = SemBEVGenerator(
+                self.sem_idxs, bev_params['view_size'], bev_params['pixel_size'], bev_params['max_trans_radius'],
+                bev_params['zoom_thresh'], bev_params['do_warp'], bev_params['int_scaler'],
+                bev_params['int_sep_scaler'], bev_params['int_mid_threshold'], bev_params['height_filter'])
+        elif bev_params['type'] == 'rgb':
+            raise NotImplementedError('Needs refactoring')
+
+    # ---- state views -------------------------------------------------------------------------
+    @property
+    def store(self):
+        if self._store is None:
+            from pca_amd.device_store import DeviceStore
+            self._store = DeviceStore(**self._store_args)
+        return self._store
+
+    @property
+    def poses(self):
+        return self._track.poses
+
+    @poses.setter
+    def poses(self, value):
+        self._track.poses = value
+
+    @property
+    def seg_dists(self):
+        return self._track.seg_dists
+
+    @seg_dists.setter
+    def seg_dists(self, value):
+        self._track.seg_dists = value
+
+    @property
+    def sem_pcs(self):
+        """Host copies of the stored frames: list of (M,10) f64 arrays [x,y,z,i,r,g,b,sem,inst,dyn]."""
+        if self._store is None:
+            return []
+        return self._store.frame_rows()
+
+    # ---- integrate (platform specific) ---------------------------------------------------------
+    def integrate(self, observations: list):
+        raise NotImplementedError()
+
+    def obs2sem_vec_space(self, rgb, pc, sem_gt=None) -> tuple:
+        raise NotImplementedError()
+
+    def update_poses(self, T_new_prev):
+        self._track.apply_transform(T_new_prev)
+
+    def update_sem_pcs(self, T_new_prev):
+        """Every stored point p <- T_new_prev p, in place on the device (K2)."""
+        self.store.retransform(np.asarray(T_new_prev, dtype=np.float64))
+
+    def remove_observations(self):
+        """Appends the newest path segment and evicts frames beyond the memory horizon."""
+        path_length = self._track.push_segment()
+        idx = self._track.evict_beyond(self.horizon_dist, path_length)
+        if idx:
+            self.store.evict(idx)
+            self.rgbs = self.rgbs[idx:]
+            self.semsegs = self.semsegs[idx:]
+        return idx, path_length
+
+    # ---- small host helpers --------------------------------------------------------------------
+    @staticmethod
+    def comp_incr_path_dist(seg_dists: list):
+        return hl.incremental_path_dists(seg_dists)
+
+    def get_segment_dists(self) -> list:
+        return self.seg_dists
+
+    def get_incremental_path_dists(self) -> np.array:
+        return hl.incremental_path_dists(np.array(self.seg_dists))
+
+    def get_pose(self, idx: int = None) -> np.array:
+        return np.array(self.poses) if idx is None else np.array(self.poses[idx])
+
+    def get_rgb(self, idx: int = None) -> list:
+        return self.rgbs if idx is None else [self.rgbs[idx]]
+
+    def get_semseg(self, idx: int = None) -> list:
+        return self.semsegs if idx is None else [self.semsegs[idx]]
+
+    @staticmethod
+    def dist(pose_0: np.array, pose_1: np.array):
+        return hl.pose_dist(pose_0, pose_1)
+
+    @staticmethod
+    def write_compressed_pickle(obj, filename, write_dir):
+        path = os.path.join(write_dir, f"{filename}.gz")
+        blob = pickle.dumps(obj)
+        try:
+            with gzip.open(path, "wb") as f:
+                f.write(blob)
+        except IOError as error:
+            print(error)
+
+    @staticmethod
+    def read_compressed_pickle(path):
+        try:
+            with gzip.open(path, "rb") as f:
+                return pickle.loads(f.read())
+        except IOError as error:
+            print(error)
+
+    @staticmethod
+    def pc2pcd(pc):
+        import open3d as o3d
+        pcd = o3d.geometry.PointCloud()
+        pcd.points = o3d.utility.Vector3dVector(pc[:, :3])
+        pcd.estimate_normals()
+        return pcd
+
+    # ---- projection helpers of the reference's public surface (device-backed) ---------------------
+    def _k1_rows(self, pc_velo, rgb, sem, P_velo_frame, filters):
+        import torch
+        from pca_amd.device_store import DeviceStore
+        H, W = sem.shape[:2]
+        tmp = DeviceStore(capacity=max(pc_velo.shape[0], 1), max_frames=2)
+        dev = tmp.device
+        frame = dict(pts=torch.from_numpy(np.ascontiguousarray(pc_velo, dtype=np.float32)).to(dev),
+                     rgb=torch.from_numpy(np.ascontiguousarray(rgb, dtype=np.uint8)).to(dev),
+                     sem=torch.from_numpy(np.ascontiguousarray(sem, dtype=np.uint8)).to(dev))
+        tmp.append_kitti([frame], P_velo_frame, H, W, filters)
+        return tmp.rows(0)
+
+    def filter_semseg_pc(self, pc):
+        keep = ~np.isin(pc[:, -1], list(self.semseg_filters))
+        return pc[keep]
+
+    def gen_semantic_pc(self, pc_velo, semantic_map, P_velo_frame):
+        """(M, 4+K) rows [x,y,z,i, map channels] of the points that project inside the map."""
+        semantic_map = np.asarray(semantic_map)
+        K = semantic_map.shape[2]
+        if K == 3:
+            rows = self._k1_rows(pc_velo, semantic_map, np.zeros(semantic_map.shape[:2], np.uint8), P_velo_frame, [])
+            return rows[:, :7]
+        if K == 1:
+            rgb0 = np.zeros(semantic_map.shape[:2] + (3, ), np.uint8)
+            rows = self._k1_rows(pc_velo, rgb0, semantic_map[..., 0], P_velo_frame, [])
+            return np.concatenate([rows[:, :4], rows[:, 7:8]], axis=1)
+        raise NotImplementedError('semantic_map must have 1 or 3 layers')
+
+    @staticmethod
+    def velo2frame(pc_velo, P_velo_frame):
+        """(N,3) velodyne -> (N,3) homogeneous image-frame coordinates (host helper, numpy)."""
+        homo = np.concatenate((pc_velo, np.ones((pc_velo.shape[0], 1))), axis=1)
+        return np.matmul(P_velo_frame, homo.T).T
+
+    # ---- BEV -------------------------------------------------------------------------------------
+    def viz_bev(self, bev, file_path, rgbs: list = [], semsegs: list = []):
+        self.sem_bev_generator.viz_bev(bev, file_path, rgbs, semsegs)
+
+    def generate_bev(self, present_idx: int = None, bev_num: int = 1, gen_future: bool = False):
+        raise NotImplementedError()
+
+    def _window_inputs(self, present_idx, gen_future, other_trajs=None, gt_lanes=None):
+        """The reference's (pcs, trajs) dicts for one BEV sample, with device window handles in place of
+        the concatenated host arrays (kitti360_sem_pc_accum.py:180-228 / nuscenes_oracle_...py:521-595)."""
+        origin = np.array(self.poses[-1] if present_idx is None else self.poses[present_idx])
+        split = self.store.n_frames if present_idx is None else \
+            (present_idx if present_idx >= 0 else self.store.n_frames + present_idx)
+        if split <= 0:
+            raise ValueError('need at least one array to concatenate')     # np.concatenate([]) in the reference
+        win = DeviceWindow(self.store, split, origin)
+        poses = np.concatenate([self.poses])
+        pcs = {'pc_present': win.part('present')}
+        trajs = {'ego_traj_present': poses[:present_idx] - origin}
+        others = other_trajs if other_trajs is not None else ([], [], [])
+        trajs['other_trajs_present'] = [np.concatenate([t]) - origin for t in others[0]]
+        if gt_lanes is not None:
+            trajs['gt_lanes'] = [lane - origin for lane in gt_lanes]
+        if gen_future:
+            if split >= self.store.n_frames:
+                raise ValueError('need at least one array to concatenate')
+            pcs['pc_future'] = win.part('future')
+            pcs['pc_full'] = win.part('full')
+            trajs['ego_traj_future'] = poses[present_idx:] - origin
+            trajs['ego_traj_full'] = poses - origin
+            trajs['other_trajs_future'] = [np.concatenate([t]) - origin for t in others[1]]
+            trajs['other_trajs_full'] = [np.concatenate([t]) - origin for t in others[2]]
+        else:
+            for k in ('pc_future', 'pc_full'):
+                pcs[k] = None
+            for k in ('ego_traj_future', 'other_trajs_future', 'ego_traj_full', 'other_trajs_full'):
+                trajs[k] = None
+        return pcs, trajs
+
+    def _run_bev(self, pcs, trajs, bev_num):
+        # the reference forks a multiprocessing.Pool for bev_num > 1 (pickling the window per worker);
+        # the rasteriser is ~100 us, so the copies are simply generated one after the other
+        return [self.sem_bev_generator.generate_multiproc((pcs, self._copy_trajs(trajs))) for _ in range(bev_num)]
+
+    @staticmethod
+    def _copy_trajs(trajs):
+        out = {}
+        for k, v in trajs.items():
+            if isinstance(v, list):
+                out[k] = [np.array(t) for t in v]
+            elif v is None:
+                out[k] = None
+            else:
+                out[k] = np.array(v)
+        return out
+
+
+def SemSegONNX(path):
+    """Late import so that GT-semantics runs never need onnxruntime."""
+    from utils.onnx_utils import SemSegONNX as _S
+    return _S(path)

@@ -1,0 +1,213 @@
+"""GPU parity, API level: the drop-in classes (same names / constructors / methods as the reference) run
+the golden sequences end to end on the device and must reproduce the reference's own outputs."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KITTI_FILTERS = [10, 11, 12, 16, 18, 255]
+NUSC_FILTERS = [10, 11, 12, 16, 18]
+SEM_IDXS = {'road': 0, 'car': 13, 'truck': 14, 'bus': 15, 'motorcycle': 17}
+BEV_KITTI = dict(type='sem', view_size=40, pixel_size=32, max_trans_radius=0., zoom_thresh=0., do_warp=False,
+                 int_scaler=20., int_sep_scaler=20., int_mid_threshold=0.5, height_filter=None)
+BEV_NUSC = dict(type='sem', view_size=30, pixel_size=32, max_trans_radius=0., zoom_thresh=0., do_warp=False,
+                int_scaler=1., int_sep_scaler=30., int_mid_threshold=0.12, height_filter=3.)
+
+
+class FakeSemSeg:
+    """Same stand-in for the ONNX model that generated the fixtures (tools/make_golden.py)."""
+
+    def pred(self, rgb):
+        a = np.asarray(rgb).astype(np.int64)
+        return ((a[..., 0] + 2 * a[..., 1] + 3 * a[..., 2]) % 19)[None, None]
+
+
+@pytest.fixture(autouse=True)
+def fake_model(monkeypatch):
+    import torch
+    assert torch.cuda.is_available()
+    import sem_pc_accum
+    monkeypatch.setattr(sem_pc_accum, 'SemSegONNX', lambda path: FakeSemSeg())
+
+
+def check_bev(bev, g, prefix='bev_'):
+    keys = [k[len(prefix):] for k in g.files if k.startswith(prefix)]
+    assert keys
+    for s in ('present', 'future', 'full'):
+        for key in ('road', 'dynamic', 'elevation', 'rgb'):
+            got, want = bev[f'{key}_{s}'], g[f'{prefix}{key}_{s}']
+            assert got.dtype == np.float16 and got.shape == want.shape
+            assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (key, s)
+        d = np.abs(bev[f'intensity_{s}'].view(np.uint16).astype(int) - g[f'{prefix}intensity_{s}'].view(np.uint16).astype(int))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-3
+        n = int(g[f'{prefix}trajs_{s}_n'])
+        assert len(bev[f'trajs_{s}']) == n
+        for k in range(n):
+            assert np.array_equal(bev[f'trajs_{s}'][k], g[f'{prefix}trajs_{s}_{k}']), (s, k)
+    assert set(bev.keys()) == {f'{a}_{s}' for a in ('road', 'trajs', 'intensity', 'rgb', 'dynamic', 'elevation')
+                               for s in ('present', 'future', 'full')} | ({'gt_lanes'} & set(bev.keys()))
+
+
+def test_kitti_accumulator_sequence(golden, capsys):
+    from PIL import Image
+
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    g = golden('kitti_accum')
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': g['P']}
+    acc = Kitti360SemanticPointCloudAccumulator(float(g['horizon']), calib, 1e3, 'fake.onnx', KITTI_FILTERS, SEM_IDXS,
+                                                False, dict(BEV_KITTI))
+    queue = list(g['Ts'])
+    acc.pose_provider = lambda pc: queue.pop(0)
+    removed = []
+    for k in range(int(g['F'])):
+        removed.append(acc.integrate([(Image.fromarray(g[f'img_{k}']), g[f'pc_{k}'], None)]))
+        if f'step{k}_sizes' in g.files:
+            sem_pcs = acc.sem_pcs
+            assert np.array_equal(np.array([a.shape[0] for a in sem_pcs]), g[f'step{k}_sizes'])
+            assert np.array_equal(np.concatenate(sem_pcs), g[f'step{k}_sem_pcs'])
+            assert np.array_equal(np.array(acc.poses), g[f'step{k}_poses'])
+            assert np.array_equal(np.array(acc.seg_dists), g[f'step{k}_seg_dists'])
+    assert np.array_equal(np.array(removed), g['removed'])
+    assert np.array_equal(acc.get_incremental_path_dists(), g['incr_path_dists'])
+    assert len(acc.get_rgb(2)) == 1 and acc.get_semseg(2)[0].shape == (64, 96)
+    bevs = acc.generate_bev(int(g['present_idx']), 1, gen_future=True)
+    assert len(bevs) == 1
+    check_bev(bevs[0], g)
+    acc.store.check_status()
+    assert '#pc' in capsys.readouterr().out
+
+
+def test_kitti_accumulator_gt_sem_and_io(golden, tmp_path):
+    from PIL import Image
+
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    g = golden('kitti_gtsem')
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': g['P']}
+    acc = Kitti360SemanticPointCloudAccumulator(50., calib, 1e3, None, KITTI_FILTERS, SEM_IDXS, True, dict(BEV_KITTI))
+    queue = list(g['Ts'])
+    acc.pose_provider = lambda pc: queue.pop(0)
+    dummy = Image.fromarray(np.zeros((64, 96, 3), np.uint8))
+    for k in range(4):
+        assert acc.integrate([(dummy, g[f'pc_{k}'], g[f'sem_gt_{k}'])]) == 0
+    assert np.array_equal(np.concatenate(acc.sem_pcs), g['sem_pcs'])
+    assert np.array_equal(np.array(acc.poses), g['poses'])
+    bev = acc.generate_bev(2, 1, gen_future=True)[0]
+    check_bev(bev, g)
+    # output writer: same container format as the reference (gzip + pickle of the dict)
+    acc.write_compressed_pickle(bev, 'bev_000.pkl', str(tmp_path))
+    back = acc.read_compressed_pickle(os.path.join(str(tmp_path), 'bev_000.pkl.gz'))
+    assert set(back.keys()) == set(bev.keys())
+    assert np.array_equal(back['rgb_full'].view(np.uint16), bev['rgb_full'].view(np.uint16))
+    acc.viz_bev(bev, os.path.join(str(tmp_path), 'viz.png'), acc.get_rgb(2), acc.get_semseg(2))
+    assert os.path.getsize(os.path.join(str(tmp_path), 'viz.png')) > 1000
+    # two augmentation-free copies are identical
+    b2 = acc.generate_bev(2, 2, gen_future=True)
+    assert len(b2) == 2 and np.array_equal(b2[0]['road_full'].view(np.uint16), b2[1]['road_full'].view(np.uint16))
+
+
+def test_nuscenes_oracle_accumulator_sequence(golden):
+    from PIL import Image
+
+    from nuscenes_oracle_sem_pc_accum import NuScenesOracleSemanticPointCloudAccumulator
+    g = golden('nusc_oracle')
+    acc = NuScenesOracleSemanticPointCloudAccumulator('fake.onnx', NUSC_FILTERS, SEM_IDXS, False, dict(BEV_NUSC),
+                                                      'boston', False, None)
+    for k in range(int(g['F'])):
+        T = g[f'T_{k}']
+        obs = dict(images=[Image.fromarray(im) for im in g[f'imgs_{k}']], pc=g[f'pc_{k}'],
+                   pc_cam_idx=g[f'cam_idx_{k}'], ego_at_lidar_ts=T, ego_global_x=T[0, 3], ego_global_y=T[1, 3],
+                   inst_tokens=str(g['inst_tokens'][k]).split(','), inst_cls=list(g[f'inst_cls_{k}']),
+                   inst_center=list(g[f'inst_center_{k}']))
+        assert acc.integrate([obs]) is None
+        if k == 0:
+            assert np.array_equal(acc.sem_pcs[0], g['frame0_after_integrate'])
+    assert np.array_equal(np.array([a.shape[0] for a in acc.sem_pcs]), g['sizes'])
+    assert np.array_equal(np.concatenate(acc.sem_pcs), g['sem_pcs'])          # incl. retroactive dyn flags
+    assert np.array_equal(np.array(acc.poses), g['poses'])
+    assert np.array_equal(np.array(acc.seg_dists), g['seg_dists'])
+    assert list(g['dyn_instances']) == acc.dyn_instances
+    assert np.array_equal(acc.get_incremental_path_dists(), g['incr_path_dists'])
+    assert acc.map == 'boston' and len(acc.ego_global_xs) == int(g['F'])
+    bev = acc.generate_bev(int(g['present_idx']), 1, gen_future=True)[0]
+    check_bev(bev, g)
+
+
+@pytest.mark.parametrize('case,ctor,args', [
+    ('bev_a', (20, 32, 0., 0., False, 20., 20., 0.5, None), None),
+    ('bev_b', (51.2, 64, 0., 0., False, 1., 30., 0.12, 3.), 'file'),
+    ('bev_c', (80, 256, 0., 0., False, 20., 20., 0.5, None), None),
+    ('bev_d', (20, 16, 0., 0., False, 20., 20., 0.5, None), None),
+    ('bev_e', (20, 32, 0., 0., True, 20., 20., 0.5, None), None),
+])
+def test_sem_bev_generator_host_arrays(golden, case, ctor, args):
+    """SemBEVGenerator.generate on host (N,10) arrays -- the reference's own calling convention."""
+    from bev_generator.sem_bev import SemBEVGenerator
+    g = golden(case)
+    gen = SemBEVGenerator(SEM_IDXS, *ctor)
+    if case == 'bev_e':
+        w = tuple(g['warp'])
+        gen.get_random_warp_params = lambda *a: w
+    present, future = g['pc_present'], g['pc_future']
+    pcs = dict(pc_present=present.copy(), pc_future=future.copy(), pc_full=np.concatenate([present, future]))
+    trajs = {}
+    for k in ('ego_traj_present', 'ego_traj_future', 'ego_traj_full'):
+        trajs[k] = g['in_' + k].copy()
+    for k in ('other_trajs_present', 'other_trajs_future', 'other_trajs_full'):
+        trajs[k] = [g[f'in_{k}_{i}'].copy() for i in range(int(g[f'in_{k}_n']))]
+    keep = present.copy()
+    if args == 'file':
+        a = g['args']
+        bev = gen.generate(pcs, trajs, a[0], a[1], a[2], a[3], True)
+    else:
+        bev = gen.generate(pcs, trajs)
+    check_bev(bev, g)
+    assert np.array_equal(pcs['pc_present'], keep)          # inputs are not mutated (documented difference)
+
+
+def test_generate_without_future_raises_like_reference(golden):
+    from bev_generator.sem_bev import SemBEVGenerator
+    g = golden('bev_d')
+    gen = SemBEVGenerator(SEM_IDXS, 20, 16)
+    pcs = dict(pc_present=g['pc_present'], pc_future=None, pc_full=None)
+    trajs = dict(ego_traj_present=g['in_ego_traj_present'], ego_traj_future=None, ego_traj_full=None,
+                 other_trajs_present=[], other_trajs_future=None, other_trajs_full=None)
+    with pytest.raises(UnboundLocalError):
+        gen.generate(pcs, trajs)
+
+
+def test_rgb_bev_generator_medians(golden):
+    from bev_generator.rgb_bev import RGBBEVGenerator
+    from bev_generator.sem_bev import SemBEVGenerator
+    g = golden('utils')
+    rgen = RGBBEVGenerator(20, 16, 7)
+    r, gr, b = rgen.get_rgb_maps(g['rg_pc'])
+    assert np.array_equal(np.stack([r, gr, b]), g['rg_out'])
+    sgen = SemBEVGenerator(SEM_IDXS, 20, 16, rgb_fill=7)
+    r2, g2, b2 = sgen.get_rgb_maps(g['rg_pc'])
+    assert np.array_equal(np.stack([r2, g2, b2]), g['rg_out'])
+    elev, mask = sgen.get_elevation_map(g['rg_pc'])
+    ij = g['rg_pc'][:, :2].astype(int)
+    want = np.zeros((16, 16))
+    seen = np.zeros((16, 16), bool)
+    for (i, j), z in zip(ij, g['rg_pc'][:, 2]):
+        if not seen[15 - j, i] or z < want[15 - j, i]:
+            want[15 - j, i] = z
+            seen[15 - j, i] = True
+    assert np.array_equal(elev, want) and np.array_equal(mask, seen)
+
+
+def test_helper_methods_match_reference(golden):
+    """velo2img-level helpers of the accumulator's public surface."""
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    g = golden('k1')
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': g['P']}
+    acc = Kitti360SemanticPointCloudAccumulator(8., calib, 1e3, None, KITTI_FILTERS, SEM_IDXS, True, dict(BEV_KITTI))
+    rgb_rows = acc.gen_semantic_pc(g['pc'], g['img'], g['P'])
+    sem_rows = acc.gen_semantic_pc(g['pc'], g['sem'][..., None], g['P'])
+    assert np.array_equal(rgb_rows, g['sem_rgb'])
+    assert np.array_equal(sem_rows, g['sem_sem'])
+    both = np.concatenate((rgb_rows, sem_rows[:, -1:]), axis=1)
+    assert np.array_equal(acc.filter_semseg_pc(both), g['filtered'])

@@ -1,0 +1,312 @@
+"""GPU parity, kernel level: every HIP kernel (through the C ABI) against the CPU oracle on the same seeded
+inputs and against the committed golden vectors.  Integers / masks / coordinates: bit-exact.
+Floating-point planes: 1e-12 absolute against the oracle (contract: 1e-5 against the reference)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KITTI_FILTERS = [10, 11, 12, 16, 18, 255]
+NUSC_FILTERS = [10, 11, 12, 16, 18]
+SEM_IDXS = {'road': 0, 'car': 13, 'truck': 14, 'bus': 15, 'motorcycle': 17}
+DYNOBJ = [13, 14, 15, 17]
+
+CAM_TO_VELO = np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418],
+                        [-0.999004371, 0.007784614041, 0.04392796942, 0.2993489574],
+                        [-0.01162548558, -0.9960641394, -0.08786966659, -0.1770225824], [0, 0, 0, 1]])
+P_RECT = np.array([[552.554261, 0, 682.049453, 0], [0, 552.554261, 238.769549, 0], [0, 0, 1, 0]])
+P_KITTI = P_RECT @ np.linalg.inv(CAM_TO_VELO)
+
+
+@pytest.fixture(scope='module')
+def T():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need the MI355X'
+    return torch
+
+
+@pytest.fixture(scope='module')
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def dev_store(**kw):
+    from pca_amd.device_store import DeviceStore
+    return DeviceStore(**kw)
+
+
+def cu(T, a, dtype=None):
+    t = T.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def kitti_frame(rng, n, H, W, lim=60.0):
+    pc = np.stack([rng.uniform(-lim, lim, n), rng.uniform(-lim, lim, n), rng.uniform(-2, 3, n),
+                   rng.uniform(0, 1, n)], 1).astype(np.float32)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    sem = rng.integers(0, 19, (H, W)).astype(np.uint8)
+    sem[rng.random((H, W)) < 0.01] = 255
+    return pc, img, sem
+
+
+# ------------------------------------------------------------------------------------------- K1
+@pytest.mark.parametrize('suffix,Pkey', [('', 'P'), ('2', 'P2')])
+@pytest.mark.parametrize('filters', [[], KITTI_FILTERS])
+def test_k1_golden(T, orc, golden, suffix, Pkey, filters):
+    g = golden('k1')
+    pc, img, sem = g['pc' + suffix], g['img'], g['sem'].astype(np.uint8)
+    H, W = int(g['H']), int(g['W'])
+    st = dev_store(capacity=8192, max_frames=4)
+    st.append_kitti([dict(pts=cu(T, pc), rgb=cu(T, img), sem=cu(T, sem))], g[Pkey], H, W, filters)
+    rows = st.rows(0)
+    ost = orc.Store(pc.shape[0])
+    orc.kitti_project_sample_filter(ost, pc, g[Pkey], img, sem, None, H, W, filters)
+    assert np.array_equal(rows, ost.rows())
+    if not filters:
+        assert np.array_equal(rows[:, :7], g['sem_rgb' + suffix])
+        assert np.array_equal(rows[:, 7], g['sem_sem' + suffix][:, -1])
+    elif suffix == '':
+        assert np.array_equal(rows[:, :8], g['filtered'])
+    st.check_status()
+
+
+def test_k1_full_size_batch_and_ragged(T, orc):
+    """KITTI-shape frames (120k points, 376x1408 images), several per launch incl. an empty and a
+    one-point frame and sizes around the tile size; stable order, segment offsets, bit-exact rows."""
+    rng = np.random.default_rng(7)
+    H, W = 376, 1408
+    sizes = [120000, 0, 1, 1023, 1024, 1025, 120000, 4097]
+    frames, host = [], []
+    for n in sizes:
+        pc, img, sem = kitti_frame(rng, n, H, W)
+        host.append((pc, img, sem))
+        frames.append(dict(pts=cu(T, pc), rgb=cu(T, img), sem=cu(T, sem)))
+    st = dev_store(capacity=400000, max_frames=16)
+    st.append_kitti(frames[:3], P_KITTI, H, W, KITTI_FILTERS)
+    st.append_kitti(frames[3:], P_KITTI, H, W, KITTI_FILTERS)
+    got = st.frame_rows()
+    st.check_status()
+    assert len(got) == len(sizes)
+    kept = 0
+    for (pc, img, sem), rows in zip(host, got):
+        ost = orc.Store(max(pc.shape[0], 1))
+        orc.kitti_project_sample_filter(ost, pc, P_KITTI, img, sem, None, H, W, KITTI_FILTERS)
+        assert np.array_equal(rows, ost.rows())
+        kept += ost.n
+    assert 0.15 < kept / sum(sizes) < 0.30          # ~0.22 of the input survives
+
+
+def test_k1_use_gt_sem(T, orc, golden):
+    g = golden('kitti_gtsem')
+    pc = g['pc_0']
+    sem_gt = g['sem_gt_0'][:, -1].astype(np.uint8)
+    st = dev_store(capacity=4096, max_frames=4)
+    st.append_kitti([dict(pts=cu(T, pc), sem_gt=cu(T, sem_gt))], g['P'], 1, 1, KITTI_FILTERS)
+    ost = orc.Store(pc.shape[0])
+    orc.kitti_project_sample_filter(ost, pc, g['P'], None, None, sem_gt, 1, 1, KITTI_FILTERS)
+    assert np.array_equal(st.rows(0), ost.rows())
+    assert st.rows(0).shape[0] == int(g['sizes'][0])
+
+
+def test_k1_capacity_overflow_is_reported(T):
+    rng = np.random.default_rng(3)
+    pc, img, sem = kitti_frame(rng, 5000, 64, 96, 10.0)
+    pc[:, 2] = 0.0
+    st = dev_store(capacity=16, max_frames=4)
+    st.ub_tail = -10**9           # defeat the host-side planner on purpose
+    sem_gt = np.zeros(5000, np.uint8)
+    st.append_kitti([dict(pts=cu(T, pc), sem_gt=cu(T, sem_gt))], P_KITTI, 1, 1, [])
+    with pytest.raises(RuntimeError, match='overflow'):
+        st.check_status()
+
+
+# ------------------------------------------------------------------------------------------- K2
+@pytest.mark.parametrize('n_T', [1, 3, 16, 21])
+def test_k2_retransform_chain(T, orc, n_T):
+    rng = np.random.default_rng(11)
+    rows = np.zeros((100003, 10))
+    rows[:, :3] = rng.uniform(-100, 100, (100003, 3))
+    parts = [rows[:1], rows[1:2], rows[2:50001], rows[50001:]]
+    st = dev_store(capacity=200000, max_frames=8)
+    st.load_rows(parts)
+    st.evict(1)                                     # odd start offset: scalar head path
+    Ts = []
+    for k in range(n_T):
+        a = rng.uniform(-0.05, 0.05)
+        c, s = np.cos(a), np.sin(a)
+        Tm = np.eye(4)
+        Tm[:3, :3] = np.array([[c, -s, 0.001], [s, c, -0.002], [0.0005, 0.001, 1.0]])
+        Tm[:3, 3] = rng.uniform(-2, 2, 3)
+        Ts.append(Tm)
+    st.retransform(np.stack(Ts))
+    ost = orc.Store.from_rows(rows[1:])
+    for Tm in Ts:
+        orc.retransform(ost, Tm)
+    assert np.array_equal(st.rows()[:, :3], ost.rows()[:, :3])
+
+
+# ------------------------------------------------------------------------------------------ K1n / K3
+def fake_semseg(img):
+    a = img.astype(np.int64)
+    return ((a[..., 0] + 2 * a[..., 1] + 3 * a[..., 2]) % 19).astype(np.uint8)
+
+
+def test_k1n_and_k3_golden(T, orc, golden):
+    g = golden('nusc_oracle')
+    st = dev_store(capacity=1 << 15, max_frames=16, intensity_div255=True)
+    ost = orc.Store(1 << 15, intensity_div255=True)
+    T0 = np.linalg.inv(g['T_0'])
+    offs = [0]
+    for k in range(int(g['F'])):
+        Tw = T0 @ g[f'T_{k}']
+        imgs = g[f'imgs_{k}']
+        sems = np.stack([fake_semseg(im) for im in imgs])
+        st.append_nusc(cu(T, g[f'pc_{k}']), cu(T, g[f'cam_idx_{k}']), cu(T, imgs), cu(T, sems), Tw, NUSC_FILTERS)
+        offs.append(offs[-1] + orc.nusc_sample_filter_transform(ost, g[f'pc_{k}'], g[f'cam_idx_{k}'], imgs, sems, Tw,
+                                                                NUSC_FILTERS))
+    assert np.array_equal(st.offsets(), np.array(offs))
+    assert np.array_equal(st.rows(), ost.rows())
+    pairs = [(0, 0), (2, 0), (3, 3), (6, 2), (6, -1)]
+    st.mark_dynamic(pairs)
+    for f, i in pairs:
+        orc.mark_dynamic(ost, offs[f], offs[f + 1], i)
+    assert np.array_equal(st.rows(), ost.rows())
+    assert st.rows()[:, 9].sum() > 0
+    st.check_status()
+
+
+def test_k1n_uv_outside_image_raises(T, golden):
+    g = golden('nusc_oracle')
+    pc = g['pc_0'].copy()
+    pc[5, 4] = 0.5                                   # u <= 1 for a point assigned to a camera
+    cam = g['cam_idx_0'].copy()
+    cam[5] = 2
+    imgs = g['imgs_0']
+    sems = np.stack([fake_semseg(im) for im in imgs])
+    st = dev_store(capacity=4096, max_frames=4, intensity_div255=True)
+    st.append_nusc(cu(T, pc), cu(T, cam), cu(T, imgs), cu(T, sems), np.eye(4), NUSC_FILTERS)
+    with pytest.raises(AssertionError):
+        st.check_status()
+
+
+def test_k0n_project_cams_golden(T, orc, golden):
+    from datasets.nuscenes_utils import project_to_cameras
+    g = golden('utils')
+    K = [g['pp_K']] * 6
+    wh = [g['pp_wh']] * 6
+    ego, uv, cam = project_to_cameras(g['c6_pc'], g['c6_ego_from_lidar'], g['c6_glob_from_ego'],
+                                      list(g['c6_glob_from_cam']), K, wh)
+    assert np.array_equal(ego, g['c6_pc_in_ego'])
+    assert np.array_equal(cam, g['c6_cam_idx'])
+    assert np.array_equal(uv, g['c6_uv'])
+
+
+# ------------------------------------------------------------------------------------------- BEV
+def run_dev_bev(T, rows_p, rows_f, view, px, hf, ints, div255, rot, dx=0., dy=0., origin=(0., 0., 0.)):
+    from pca_amd import host_logic as hl
+    from pca_amd.device_store import make_bev_params
+    st = dev_store(capacity=max(rows_p.shape[0] + rows_f.shape[0], 1), max_frames=4, intensity_div255=div255)
+    i64 = st.load_rows([rows_p, rows_f])
+    prm = make_bev_params(origin, hl.rotation_matrix_3d(rot), dx, dy, view, px, hf, *ints, 0, DYNOBJ, div255)
+    p16, p64 = st.bev(1, prm, want_f64=True, intensity64=i64)
+    st.check_status()
+    return p16.cpu().numpy(), p64.cpu().numpy(), i64 is not None
+
+
+def run_orc_bev(orc, rows_p, rows_f, view, px, hf, ints, div255, rot, dx=0., dy=0., origin=(0., 0., 0.)):
+    from pca_amd import host_logic as hl
+    rows = np.concatenate([rows_p, rows_f])
+    ost = orc.Store.from_rows(rows, intensity_div255=div255)
+    prm = orc.make_bev_params(origin, hl.rotation_matrix_3d(rot), dx, dy, view, px, hf, *ints, 0, DYNOBJ, div255)
+    return orc.bev(ost, rows_p.shape[0], prm)
+
+
+def assert_planes_match(p16, p64, ref, name=''):
+    P, F = ref['planes'], ref['f16']
+    for s in range(3):
+        for k, key in enumerate(('road', 'intensity', 'r', 'g', 'b', 'dynamic', 'elevation')):
+            a, b = p64[7 * s + k], P[7 * s + k]
+            if key == 'intensity':
+                np.testing.assert_allclose(a, b, rtol=0, atol=1e-12, err_msg=f'{name} {key} set {s}')
+                d = np.abs(p16[7 * s + k].view(np.uint16).astype(int) - F[7 * s + k].view(np.uint16).astype(int))
+                assert d.max() <= 1 and (d != 0).mean() < 1e-3
+            else:
+                assert np.array_equal(a, b), f'{name} {key} set {s}'
+                assert np.array_equal(p16[7 * s + k].view(np.uint16), F[7 * s + k].view(np.uint16))
+
+
+BEV_CASES = {
+    'bev_a': (20, 32, None, (20., 20., 0.5), False),
+    'bev_b': (51.2, 64, 3., (1., 30., 0.12), True),
+    'bev_c': (80, 256, None, (20., 20., 0.5), False),
+    'bev_d': (20, 16, None, (20., 20., 0.5), False),
+}
+
+
+@pytest.mark.parametrize('case', sorted(BEV_CASES))
+def test_bev_golden_and_oracle(T, orc, golden, case):
+    from pca_amd import host_logic as hl
+    g = golden(case)
+    view, px, hf, ints, div255 = BEV_CASES[case]
+    if case == 'bev_b':
+        rot, dx, dy, zoom = g['args']
+    else:
+        rot, dx, dy, zoom = hl.heading_rot_ang(g['in_ego_traj_present']), 0., 0., 1.
+    p16, p64, used_i64 = run_dev_bev(T, g['pc_present'], g['pc_future'], zoom * view, px, hf, ints, div255, rot, dx, dy)
+    assert not used_i64                              # fixture intensities are representable
+    ref = run_orc_bev(orc, g['pc_present'], g['pc_future'], zoom * view, px, hf, ints, div255, rot, dx, dy)
+    assert_planes_match(p16, p64, ref, case)
+    # and straight against the reference's own fp16 outputs
+    for s, name in enumerate(('present', 'future', 'full')):
+        for k, key in ((0, 'road'), (5, 'dynamic'), (6, 'elevation')):
+            assert np.array_equal(p16[7 * s + k].view(np.uint16), g[f'bev_{key}_{name}'].view(np.uint16))
+        assert np.array_equal(p16[7 * s + 2:7 * s + 5].view(np.uint16), g[f'bev_rgb_{name}'].view(np.uint16))
+        d = np.abs(p16[7 * s + 1].view(np.uint16).astype(int) - g[f'bev_intensity_{name}'].view(np.uint16).astype(int))
+        assert d.max() <= 1
+        if f'pre_road_{name}' in g:                  # pre-cast f64 planes: the 1e-5 contract
+            for k, key in ((0, 'road'), (1, 'intensity'), (5, 'dynamic'), (6, 'elevation')):
+                np.testing.assert_allclose(p64[7 * s + k], g[f'pre_{key}_{name}'], rtol=0, atol=1e-5)
+            np.testing.assert_allclose(p64[7 * s + 2:7 * s + 5], g[f'pre_rgb_{name}'], rtol=0, atol=1e-5)
+
+
+def test_bev_f64_intensity_override(T, orc):
+    """Column 3 not f32-representable -> the f64 side channel is used and matches the oracle."""
+    rng = np.random.default_rng(5)
+    rows = np.zeros((5000, 10))
+    rows[:, :2] = rng.uniform(-9, 9, (5000, 2))
+    rows[:, 2] = rng.uniform(-1, 2, 5000)
+    rows[:, 3] = rng.uniform(0, 1, 5000)            # genuine f64
+    rows[:, 4:7] = rng.integers(0, 256, (5000, 3))
+    p16, p64, used = run_dev_bev(T, rows[:3000], rows[3000:], 20, 32, None, (20., 20., 0.5), False, 0.3)
+    assert used
+    ost = orc.Store.from_rows(rows)
+    from pca_amd import host_logic as hl
+    prm = orc.make_bev_params([0, 0, 0], hl.rotation_matrix_3d(0.3), 0, 0, 20, 32, None, 20., 20., 0.5, 0, DYNOBJ, False)
+    ref = orc.bev(ost, 3000, prm, intensity64=rows[:, 3])
+    assert_planes_match(p16, p64, ref)
+
+
+def test_bev_full_size_window(T, orc):
+    """Config-2-sized window (5.3 M stored points, 256x256, view 80): oracle parity + conservation."""
+    rng = np.random.default_rng(9)
+    n = 5_300_000
+    rows = np.zeros((n, 10))
+    rows[:, 0] = rng.uniform(-160, 60, n)           # frames strung along a 200 m path
+    rows[:, 1] = rng.uniform(-60, 60, n)
+    rows[:, 2] = rng.uniform(-2, 3, n)
+    rows[:, 3] = rng.uniform(0, 1, n).astype(np.float32)
+    rows[:, 4:7] = rng.integers(0, 256, (n, 3))
+    rows[:, 7] = rng.choice([0, 0, 1, 2, 8, 9, 13, 14, 15, 17], n)
+    rows[:, 9] = rng.random(n) < 0.02
+    # hot cells: 60k points inside one cell, 20k with identical colour
+    rows[:60000, 0:2] = rng.uniform(0.01, 0.30, (60000, 2))
+    rows[:20000, 4:7] = 77
+    split = 2_600_000
+    origin = (-50., 1.5, 0.25)
+    p16, p64, _ = run_dev_bev(T, rows[:split], rows[split:], 80, 256, None, (20., 20., 0.5), False, 1.234, 0., 0., origin)
+    ref = run_orc_bev(orc, rows[:split], rows[split:], 80, 256, None, (20., 20., 0.5), False, 1.234, 0., 0., origin)
+    assert_planes_match(p16, p64, ref, 'full-size')
+    assert (p64[6] != 0).sum() > 30000               # most of the grid is observed
