@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpoints/s projected+accumulated and BEV frames/s @256x256 (BASELINE.json).
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): KITTI-360-shaped synthetic frames
+(120 000 points f32, 376x1408 RGB + semseg), 200 m accumulation horizon at 1 m / frame (~200 live
+frames, ~5 M stored points), one 256x256 x 21-plane BEV per integrated frame.
+
+One STEP = integrate one frame  (K2 re-transform of every stored point + K1 fused project / sample /
+filter / append + horizon eviction)  +  generate one BEV sample (bin, scan, scatter, per-cell reduce).
+Inputs (point clouds, images, semseg maps) are resident in HBM before the timed region; BEV tensors
+stay in HBM (multi-GPU: gathered to rank 0 over RCCL inside the timed region).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'pc-accumulation-lib_amd')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, PKG)
+
+import numpy as np  # noqa: E402
+
+N_PTS, IMG_H, IMG_W = 120_000, 376, 1408
+HORIZON_M, BEV_HORIZON_M, VIEW_M, PX = 200.0, 80, 80, 256
+FILTERS = [10, 11, 12, 16, 18, 255]
+SEM_IDXS = {'road': 0, 'car': 13, 'truck': 14, 'bus': 15, 'motorcycle': 17}
+POOL = 8                                  # distinct synthetic frames cycled through
+HBM_PEAK_GBS = 8000.0                     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+CAM_TO_VELO = np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418],
+                        [-0.999004371, 0.007784614041, 0.04392796942, 0.2993489574],
+                        [-0.01162548558, -0.9960641394, -0.08786966659, -0.1770225824], [0, 0, 0, 1]])
+P_RECT = np.array([[552.554261, 0, 682.049453, 0], [0, 552.554261, 238.769549, 0], [0, 0, 1, 0]])
+P_VELO_FRAME = P_RECT @ np.linalg.inv(CAM_TO_VELO)
+
+
+def t_new_prev():
+    """1 m / frame on a gentle curve: Rz(-0.002) . trans(-1, 0, 0)   (SURVEY.md 8d)."""
+    c, s = np.cos(-0.002), np.sin(-0.002)
+    R = np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.]])
+    Tt = np.eye(4)
+    Tt[0, 3] = -1.0
+    return R @ Tt
+
+
+def synth_frame(seq, frame):
+    """K-shape frame, seed = 1000*sequence + frame."""
+    rng = np.random.default_rng(1000 * seq + frame)
+    pc = np.stack([rng.uniform(-60, 60, N_PTS), rng.uniform(-60, 60, N_PTS), rng.uniform(-2, 3, N_PTS),
+                   rng.uniform(0, 1, N_PTS)], 1).astype(np.float32)
+    img = rng.integers(0, 256, (IMG_H, IMG_W, 3), dtype=np.uint8)
+    sem = rng.integers(0, 19, (IMG_H, IMG_W)).astype(np.uint8)
+    sem[rng.random((IMG_H, IMG_W)) < 0.01] = 255
+    return pc, img, sem
+
+
+class ResidentSemSeg:
+    """Stand-in for the external ONNX CNN (not part of the hot path): hands back the semseg map that is
+    already resident in HBM for the image it is asked about."""
+
+    def __init__(self):
+        self.by_ptr = {}
+
+    def pred(self, rgb):
+        return self.by_ptr[rgb.data_ptr()][None, None]
+
+
+def present_index(acc):
+    """Sample trigger of run_kitti360_bev_gen.py:218-230: first pose more than 80 m of path behind the newest."""
+    if len(acc.poses) < 2:
+        return None
+    d = acc.get_incremental_path_dists()
+    if d[-1] < BEV_HORIZON_M:
+        return None
+    idx = int(((d - BEV_HORIZON_M) > 0).argmax())
+    if d[-1] - d[idx] < BEV_HORIZON_M:
+        return None
+    return idx
+
+
+def cpu_baseline(steps=20):
+    """Oracle (scalar C port of the reference algorithm, 1 core) on a bounded sample of the same workload:
+    fill the 200-frame window, then time `steps` full steps (re-transform + integrate + BEV)."""
+    from oracle import oracle as orc
+    from pca_amd import host_logic as hl
+    T = t_new_prev()
+    frames = [synth_frame(0, k) for k in range(2)]
+    st = orc.Store(220 * 40000)
+    track = hl.PoseTrack()
+    sizes = []
+    lo = 0
+
+    def step(k, do_bev):
+        nonlocal lo, sizes
+        pc, img, sem = frames[k % 2]
+        if track.poses:
+            track.apply_transform(T)
+            orc.retransform(st, T, lo, st.n)
+        sizes.append(orc.kitti_project_sample_filter(st, pc, P_VELO_FRAME, img, sem, None, IMG_H, IMG_W, FILTERS))
+        track.append([0., 0., 0.])
+        if len(track.poses) > 1:
+            ev = track.evict_beyond(HORIZON_M, track.push_segment())
+            lo += int(np.sum(sizes[:ev]))
+            sizes = sizes[ev:]
+        if do_bev:
+            d = hl.incremental_path_dists(track.seg_dists)
+            idx = int(((d - BEV_HORIZON_M) > 0).argmax())
+            origin = np.array(track.poses[idx])
+            ego = np.array(track.poses[:idx]) - origin
+            R = hl.rotation_matrix_3d(hl.heading_rot_ang(ego))
+            prm = orc.make_bev_params(origin, R, 0., 0., VIEW_M, PX, None, 20., 20., 0.5, 0, [13, 14, 15, 17], False)
+            sub = orc.Store(1)
+            for name in ('x', 'y', 'z', 'intensity', 'rgbs', 'inst', 'dyn'):
+                setattr(sub, name, getattr(st, name)[lo:st.n])
+            sub.n = sub.cap = st.n - lo
+            orc.bev(sub, int(np.sum(sizes[:idx])), prm)
+
+    for k in range(205):
+        step(k, False)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(205 + k, True)
+    dt = time.perf_counter() - t0
+    return {'value': N_PTS * steps / dt / 1e6, 'unit': 'Mpoints/s', 'bev_frames_per_s': steps / dt, 'cores': 1,
+            'kind': 'port',
+            'sample': f'oracle/pca_oracle.c (scalar C port), 205-frame window fill untimed, then {steps} full steps '
+                      f'(retransform ~{st.n - lo} stored pts + integrate 120k pts + one 256x256 BEV) in {dt:.1f} s',
+            'host_cpus': os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL on ROCm
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    import sem_pc_accum
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    from pca_amd import _lib
+
+    model = ResidentSemSeg()
+    sem_pc_accum.SemSegONNX = lambda path: model
+    bev_params = dict(type='sem', view_size=VIEW_M, pixel_size=PX, max_trans_radius=0., zoom_thresh=0., do_warp=False,
+                      int_scaler=20., int_sep_scaler=20., int_mid_threshold=0.5, height_filter=None)
+    calib = {'h_velo_cam': np.linalg.inv(CAM_TO_VELO), 'p_cam_frame': P_RECT, 'p_velo_frame': P_VELO_FRAME}
+    acc = Kitti360SemanticPointCloudAccumulator(HORIZON_M, calib, 1e3, 'resident', FILTERS, SEM_IDXS, False, bev_params)
+    acc._store_args = dict(capacity=1 << 26, max_frames=1 << 14)
+    T = t_new_prev()
+    acc.pose_provider = lambda pc: T
+
+    # ---- inputs resident in HBM: every rank works on its own sequence (scene shard) ----
+    pool = []
+    for k in range(POOL):
+        pc, img, sem = synth_frame(rank, k)
+        f = (torch.from_numpy(img).cuda(), torch.from_numpy(pc).cuda(), torch.from_numpy(sem).cuda())
+        model.by_ptr[f[0].data_ptr()] = f[2]
+        pool.append(f)
+
+    import builtins
+    real_print = builtins.print
+    builtins.print = lambda *a, **k: None           # the accumulator prints one line per frame, as the reference
+
+    frame_no = [0]
+
+    def step(bev_out=None, slot=0):
+        rgb, pc, _ = pool[frame_no[0] % POOL]
+        frame_no[0] += 1
+        acc.integrate([(rgb, pc, None)])
+        idx = present_index(acc)
+        if idx is None:
+            return None
+        pcs, trajs = acc._window_inputs(idx, True)
+        gen = acc.sem_bev_generator
+        bev = gen.generate(pcs, trajs, device_only=True)
+        if bev_out is not None:
+            bev_out[slot].copy_(bev['planes_f16'])
+        return bev
+
+    # ---- untimed: fill the accumulation window, then W warm-up steps ----
+    while present_index(acc) is None or len(acc.poses) < 195:
+        rgb, pc, _ = pool[frame_no[0] % POOL]
+        frame_no[0] += 1
+        acc.integrate([(rgb, pc, None)])
+    for _ in range(args.warmup):
+        step()
+    acc.store.check_status()
+    bev_buf = torch.empty((args.steps, 21, PX, PX), dtype=torch.float16, device='cuda')
+    gathered = None
+    if world > 1:
+        gathered = [torch.empty_like(bev_buf) for _ in range(world)] if rank == 0 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps ----
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(bev_buf, k)
+    if world > 1:                                     # finished BEV tensors -> rank 0 over RCCL / xGMI
+        dist.gather(bev_buf, gathered, dst=0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    acc.store.check_status()
+    stored = int(acc.store.offsets()[-1] - acc.store.offsets()[0])
+    n_live = acc.store.n_frames
+
+    # ---- second identical pass with per-kernel HIP events (on the launch stream, inside the library) ----
+    ctx = _lib.Context.get()
+    ctx.profile(True)
+    for k in range(args.steps):
+        step(bev_buf, k)
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    builtins.print = real_print
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    kern = {k: {'ms_total': v[0], 'launches': v[1], 'avg_us': 1e3 * v[0] / v[1]} for k, v in prof.items() if v[1]}
+    # algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md):
+    #   K2 retransform: 48 B per stored point;  K1: 16 N + 4 M_proj + 40 M_kept;
+    #   BEV (bin+scan+scatter+cells as one unit): 40 B per window point + 21 px^2 4 B
+    sizes = acc.store.sizes()
+    m_kept = float(np.mean(sizes))
+    m_proj = m_kept * 19.0 / 14.0 / 0.99               # 14 of 19 uniform classes survive, 1 % 'ignore'
+    alg = {
+        'retransform': 48.0 * stored,
+        'kitti_project_sample_filter': 16.0 * N_PTS + 4.0 * m_proj + 40.0 * m_kept,
+        'bev': 40.0 * stored + 21.0 * PX * PX * 4.0,
+    }
+    bev_us = sum(kern[k]['avg_us'] for k in ('bev_bin', 'bev_scan', 'bev_scatter', 'bev_cells') if k in kern)
+    units = {'retransform': kern['retransform']['avg_us'], 'kitti_project_sample_filter':
+             kern['kitti_project_sample_filter']['avg_us'], 'bev': bev_us}
+    dominant = max(units, key=lambda k: units[k])
+    achieved = alg[dominant] / (units[dominant] * 1e-6) / 1e9
+    roofline = {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'algorithmic_bytes_per_launch': alg[dominant], 'avg_launch_us': units[dominant],
+                'all': {k: {'avg_us': units[k], 'alg_bytes': alg[k],
+                            'GBps': alg[k] / (units[k] * 1e-6) / 1e9,
+                            'frac': alg[k] / (units[k] * 1e-6) / 1e9 / HBM_PEAK_GBS} for k in units},
+                'kernels': kern}
+
+    out = {
+        'metric': 'Mpoints/s projected+accumulated and BEV frames/s @256x256; 1/2/4/8 GPU',
+        'value': world * N_PTS * args.steps / elapsed / 1e6,
+        'unit': 'Mpoints/s',
+        'bev_frames_per_s': world * args.steps / elapsed,
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': 'KITTI-360 single forward cam, 120k pts/frame, 200 m horizon (~%d live frames, '
+                               '%d stored pts), one 256x256x21 BEV per integrated frame' % (n_live, stored),
+                   'points_per_frame': N_PTS, 'image': [IMG_H, IMG_W], 'bev_px': PX, 'view_m': VIEW_M,
+                   'sharding': 'one independent sequence per GPU; BEV tensors gathered to rank 0 (RCCL)'},
+        'roofline': roofline,
+    }
+    if not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

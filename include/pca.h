@@ -162,6 +162,18 @@ int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensi
                      int64_t max_points, const pca_bev_params *prm, void *workspace /*dev*/,
                      int64_t workspace_bytes, double *planes /*dev*/, uint16_t *planes_f16 /*dev*/, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Optional per-kernel timing: while enabled every kernel launch is bracketed by HIP events recorded on
+ * the call's stream.  pca_profile_read synchronises, returns the accumulated time / launch count of one
+ * kernel id since the last pca_profile_enable(ctx, 1) and keeps recording.  (No reference counterpart.)
+ * ------------------------------------------------------------------------------------------------ */
+enum {
+    PCA_K_KITTI = 0, PCA_K_NUSC, PCA_K_PROJECT_CAMS, PCA_K_RETRANSFORM, PCA_K_MARK_DYNAMIC,
+    PCA_K_BEV_BIN, PCA_K_BEV_SCAN, PCA_K_BEV_SCATTER, PCA_K_BEV_CELLS, PCA_K_COUNT
+};
+int pca_profile_enable(pca_ctx *ctx, int on);
+int pca_profile_read(pca_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

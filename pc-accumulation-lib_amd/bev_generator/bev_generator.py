@@ -78,6 +78,8 @@ class BEVGenerator(ABC):
         if self.height_filter is not None:
             print("NOTE: Removes points above ego-vehicle height!")
         self._tmp = {}                      # scratch device stores of the host-array path
+        self._frame = None
+        self._device_only = False
 
     def __getstate__(self):                 # device handles never travel through pickle
         d = dict(self.__dict__)
@@ -135,7 +137,11 @@ class BEVGenerator(ABC):
                  trans_dx: float = 0.,
                  trans_dy: float = 0.,
                  zoom_scalar: float = 1.,
-                 do_warping: bool = False):
+                 do_warping: bool = False,
+                 device_only: bool = False):
+        """device_only=True (extension): the 21 planes stay in HBM -- the returned dict holds one cuda
+        float16 tensor 'planes_f16' [21,px,px] instead of 15 host arrays (used by the sharded runner and
+        the benchmark, where BEVs are gathered with RCCL)."""
         pc_present, pc_future, pc_full = self.extract_pc_dict(pcs)
         ego_present, ego_future, ego_full = self.extract_ego_traj_dict(trajs)
         oth_present, oth_future, oth_full = self.extract_other_traj_dicts(trajs)
@@ -160,6 +166,7 @@ class BEVGenerator(ABC):
         trajs_full = to_grid([ego_full] + oth_full)
 
         self._frame = (rot_mat, trans_dx, trans_dy, aug_view_size)
+        self._device_only = device_only
         return self.generate_bev(pc_present, pc_future, pc_full, trajs_present, trajs_future, trajs_full, lanes)
 
     def preprocess_pc_and_trajs(self, pc, trajs, rot_ang, trans_dx, trans_dy, aug_view_size):

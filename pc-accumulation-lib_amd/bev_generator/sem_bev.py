@@ -47,8 +47,16 @@ class SemBEVGenerator(BEVGenerator):
         if not isinstance(pc_present, WindowPart) and self._frame is None:
             # called directly with the reference's pre-gridded rows: put every point at its cell centre
             pc_present, pc_future, pc_full = (self._grid_rows_to_metres(p) for p in (pc_present, pc_future, pc_full))
-        p16, p64 = self.generate_bev_device(pc_present, pc_future, pc_full, want_f64=self.do_warp)
+        device_only, self._device_only = self._device_only, False
+        p16, p64 = self.generate_bev_device(pc_present, pc_future, pc_full,
+                                            want_f64=self.do_warp and not device_only)
         self._frame = None
+        if device_only:
+            out = {'planes_f16': p16, 'trajs_present': trajs_present, 'trajs_future': trajs_future,
+                   'trajs_full': trajs_full}
+            if gt_lane_trajs is not None:
+                out['gt_lanes'] = gt_lane_trajs
+            return out
         if self.do_warp:
             px = self.pixel_size
             i_mid = j_mid = int(px / 2)

@@ -392,7 +392,7 @@ int pca_kitti_project_sample_filter(pca_ctx *ctx, const pca_kitti_frame *frames,
     a.state = ctx->tile_state;
     a.ticket = ctx->ticket;
     a.epoch = pca_ctx_next_epoch(ctx, s);
-    hipLaunchKernelGGL(k1_kitti, dim3(total), dim3(BLK), 0, s, a);
+    PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti, dim3(total), dim3(BLK), s, a);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }
@@ -416,7 +416,7 @@ int pca_nusc_sample_filter_transform(pca_ctx *ctx, const double *pc, const int64
     a.st = *store; a.frame_off = frame_off; a.slot = slot;
     a.state = ctx->tile_state; a.ticket = ctx->ticket;
     a.epoch = pca_ctx_next_epoch(ctx, s);
-    hipLaunchKernelGGL(k1n_nusc, dim3(total), dim3(BLK), 0, s, a);
+    PCA_LAUNCH(ctx, PCA_K_NUSC, k1n_nusc, dim3(total), dim3(BLK), s, a);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }
@@ -440,7 +440,7 @@ int pca_nusc_project_cams(pca_ctx *ctx, const double *pc_lidar, int32_t n, const
     }
     a.pc_in_ego = pc_in_ego; a.uv = uv; a.cam_idx = cam_idx;
     const int grid = (n + BLK - 1) / BLK < 2048 ? (n + BLK - 1) / BLK : 2048;
-    hipLaunchKernelGGL(k0n_project, dim3(grid), dim3(BLK), 0, s, a);
+    PCA_LAUNCH(ctx, PCA_K_PROJECT_CAMS, k0n_project, dim3(grid), dim3(BLK), s, a);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }
@@ -460,7 +460,7 @@ int pca_retransform(pca_ctx *ctx, const pca_store *store, const int64_t *frame_o
         a.n_T = (n_T - t0) < MAX_CHAIN ? (n_T - t0) : MAX_CHAIN;
         for (int t = 0; t < a.n_T; ++t)
             for (int i = 0; i < 12; ++i) a.T[t].m[i] = Ts[(int64_t)(t0 + t) * 16 + i];
-        hipLaunchKernelGGL(k2_retransform, dim3(2048), dim3(BLK), 0, s, a);
+        PCA_LAUNCH(ctx, PCA_K_RETRANSFORM, k2_retransform, dim3(2048), dim3(BLK), s, a);
         PCA_CHECK(ctx, hipGetLastError());
     }
     return 0;
@@ -478,7 +478,7 @@ int pca_mark_dynamic(pca_ctx *ctx, const pca_store *store, const int64_t *frame_
         a.inst = store->inst; a.dyn = store->dyn; a.frame_off = frame_off;
         a.n_pairs = (n_pairs - p0) < MAX_PAIRS ? (n_pairs - p0) : MAX_PAIRS;
         for (int i = 0; i < a.n_pairs; ++i) { a.slot[i] = slots[p0 + i]; a.inst_idx[i] = inst_idx[p0 + i]; }
-        hipLaunchKernelGGL(k3_mark_dynamic, dim3(64, a.n_pairs), dim3(BLK), 0, s, a);
+        PCA_LAUNCH(ctx, PCA_K_MARK_DYNAMIC, k3_mark_dynamic, dim3(64, a.n_pairs), dim3(BLK), s, a);
         PCA_CHECK(ctx, hipGetLastError());
     }
     return 0;

@@ -26,7 +26,48 @@ uint32_t pca_ctx_next_epoch(pca_ctx *ctx, hipStream_t s)
     return ctx->epoch;
 }
 
+void pca_prof_begin(pca_ctx *ctx, int kid, hipStream_t s)
+{
+    pca_ctx::Ev e;
+    if (!ctx->free_evs.empty()) { e = ctx->free_evs.back(); ctx->free_evs.pop_back(); }
+    else { (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); }
+    e.kid = kid;
+    (void)hipEventRecord(e.a, s);
+    ctx->evs.push_back(e);
+}
+
+void pca_prof_end(pca_ctx *ctx, hipStream_t s) { (void)hipEventRecord(ctx->evs.back().b, s); }
+
+static void prof_fold(pca_ctx *ctx)
+{
+    for (auto &e : ctx->evs) {
+        (void)hipEventSynchronize(e.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { ctx->prof_ms[e.kid] += ms; ctx->prof_n[e.kid]++; }
+        ctx->free_evs.push_back(e);
+    }
+    ctx->evs.clear();
+}
+
 extern "C" {
+
+int pca_profile_enable(pca_ctx *ctx, int on)
+{
+    if (!ctx) return -1;
+    prof_fold(ctx);
+    ctx->profiling = on != 0;
+    if (on) for (int k = 0; k < PCA_K_COUNT; ++k) { ctx->prof_ms[k] = 0; ctx->prof_n[k] = 0; }
+    return 0;
+}
+
+int pca_profile_read(pca_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches)
+{
+    if (!ctx || kernel_id < 0 || kernel_id >= PCA_K_COUNT) return -1;
+    prof_fold(ctx);
+    if (total_ms) *total_ms = ctx->prof_ms[kernel_id];
+    if (launches) *launches = ctx->prof_n[kernel_id];
+    return 0;
+}
 
 int pca_version(void) { return PCA_VERSION; }
 
@@ -54,6 +95,8 @@ void pca_ctx_destroy(pca_ctx *ctx)
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     if (ctx->frames_dev) (void)hipFree(ctx->frames_dev);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
+    prof_fold(ctx);
+    for (auto &e : ctx->free_evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete ctx;
 }
 

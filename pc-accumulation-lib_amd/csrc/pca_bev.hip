@@ -13,8 +13,13 @@
 #define BLK 256
 #define KEY_INVALID 0xffffffffu
 #define CELLS_PER_BLOCK 64
-#define FX_SCALE 1099511627776.0            /* 2^40: fixed-point intensity accumulation */
-#define FX_INV (1.0 / 1099511627776.0)
+// Intensity sums are accumulated as exact integers so that the result does not depend on the order in
+// which points arrive: value = hi * 2^-20 + lo * 2^-60 with hi = floor(v * 2^20), lo = rint(frac * 2^40).
+// Resolution 2^-60 (8.7e-19) per point; both partial sums fit an int64 for any realistic cell.
+#define FX_HI 1048576.0                     /* 2^20 */
+#define FX_LO 1099511627776.0               /* 2^40 */
+#define FX_HI_INV (1.0 / 1048576.0)
+#define FX_LO_INV (1.0 / 1152921504606846976.0)   /* 2^-60 */
 
 struct Rec16 { double z; float inten; uint32_t rgbs; };
 struct Rec24 { double z; double inten; uint32_t rgbs; uint32_t pad; };
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(BLK) void bev_cells(const BevArgs a)
         const uint32_t o_p = a.offs[2 * cell], o_f = a.offs[2 * cell + 1], o_e = a.offs[2 * cell + 2];
         const uint32_t n_set[2] = {o_f - o_p, o_e - o_f};
         uint32_t c_road[2] = {0, 0}, c_dyn[2] = {0, 0};
-        long long isum[2] = {0, 0};
+        long long ihi[2] = {0, 0}, ilo[2] = {0, 0};
         double zmin[2] = {__builtin_huge_val(), __builtin_huge_val()};
 
         for (uint32_t r0 = o_p; r0 < o_e; r0 += 64) {
@@ -250,7 +255,12 @@ __global__ __launch_bounds__(BLK) void bev_cells(const BevArgs a)
             const bool road = act && ((int)sem == q.road_class);
             const bool dynobj = act && ((q.dynobj_mask[sem >> 6] >> (sem & 63)) & 1ull);
             if (act) {
-                if (road) { c_road[set]++; isum[set] += (long long)rint(iv * FX_SCALE); }
+                if (road) {
+                    c_road[set]++;
+                    const double sc = iv * FX_HI, fl = floor(sc);
+                    ihi[set] += (long long)fl;
+                    ilo[set] += (long long)rint((sc - fl) * FX_LO);
+                }
                 if (dynobj) c_dyn[set]++;
                 zmin[set] = z < zmin[set] ? z : zmin[set];
             }
@@ -271,17 +281,19 @@ __global__ __launch_bounds__(BLK) void bev_cells(const BevArgs a)
         }
         // wave reductions of the per-lane partials
         uint32_t nr[3], nd[3], na[3];
-        long long is[3];
+        long long ish[3], isl[3];
         double zm[3];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             nr[s] = wave_sum_u32(c_road[s]);
             nd[s] = wave_sum_u32(c_dyn[s]);
-            is[s] = wave_sum_i64(isum[s]);
+            ish[s] = wave_sum_i64(ihi[s]);
+            isl[s] = wave_sum_i64(ilo[s]);
             zm[s] = wave_min_f64(zmin[s]);
             na[s] = n_set[s];
         }
-        nr[2] = nr[0] + nr[1]; nd[2] = nd[0] + nd[1]; is[2] = is[0] + is[1]; na[2] = na[0] + na[1];
+        nr[2] = nr[0] + nr[1]; nd[2] = nd[0] + nd[1]; na[2] = na[0] + na[1];
+        ish[2] = ish[0] + ish[1]; isl[2] = isl[0] + isl[1];
         zm[2] = zm[0] < zm[1] ? zm[0] : zm[1];
 
         // medians (every lane participates), then lane 0 finishes the closed-form maps
@@ -315,7 +327,8 @@ __global__ __launch_bounds__(BLK) void bev_cells(const BevArgs a)
                 const double a_all = (double)na[s], a_r = (double)nr[s], a_d = (double)nd[s];
                 const double road = (a_r + 1.0) / ((a_r + 1.0) + ((a_all - a_r) + 1.0));
                 const double dynp = (a_d + 1.0) / ((a_d + 1.0) + ((a_all - a_d) + 1.0));
-                const double iraw = ((double)is[s] * FX_INV) / (a_r + 1.0);
+                const double isum = (double)ish[s] * FX_HI_INV + (double)isl[s] * FX_LO_INV;
+                const double iraw = isum / (a_r + 1.0);
                 const double zarg = q.int_sep_scaler * (iraw - q.int_mid_threshold);
                 double inten = q.int_scaler * (1.0 / (1.0 + exp(-zarg)));
                 if (inten > 1.0) inten = 1.0;
@@ -392,15 +405,15 @@ int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensi
     PCA_CHECK(ctx, hipMemsetAsync(a.cnt, 0, n * 4, s));
     const int64_t want = (max_points + BLK - 1) / BLK;
     const int grid = (int)(want < 2048 ? want : 2048);
-    hipLaunchKernelGGL(bev_bin, dim3(grid), dim3(BLK), 0, s, a);
-    hipLaunchKernelGGL(bev_scan, dim3(a.scan_tiles), dim3(BLK), 0, s, a);
+    PCA_LAUNCH(ctx, PCA_K_BEV_BIN, bev_bin, dim3(grid), dim3(BLK), s, a);
+    PCA_LAUNCH(ctx, PCA_K_BEV_SCAN, bev_scan, dim3(a.scan_tiles), dim3(BLK), s, a);
     const int cgrid = (prm->px * prm->px + CELLS_PER_BLOCK - 1) / CELLS_PER_BLOCK;
     if (intensity64) {
-        hipLaunchKernelGGL(bev_scatter<true>, dim3(grid), dim3(BLK), 0, s, a);
-        hipLaunchKernelGGL(bev_cells<true>, dim3(cgrid), dim3(BLK), 0, s, a);
+        PCA_LAUNCH(ctx, PCA_K_BEV_SCATTER, bev_scatter<true>, dim3(grid), dim3(BLK), s, a);
+        PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_cells<true>, dim3(cgrid), dim3(BLK), s, a);
     } else {
-        hipLaunchKernelGGL(bev_scatter<false>, dim3(grid), dim3(BLK), 0, s, a);
-        hipLaunchKernelGGL(bev_cells<false>, dim3(cgrid), dim3(BLK), 0, s, a);
+        PCA_LAUNCH(ctx, PCA_K_BEV_SCATTER, bev_scatter<false>, dim3(grid), dim3(BLK), s, a);
+        PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_cells<false>, dim3(cgrid), dim3(BLK), s, a);
     }
     PCA_CHECK(ctx, hipGetLastError());
     return 0;

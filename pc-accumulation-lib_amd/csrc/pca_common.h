@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/pca.h"
 
@@ -22,7 +23,24 @@ struct pca_ctx {
     pca_kitti_frame *frames_dev = nullptr;
     int frames_cap = 0;
     uint32_t *status_host = nullptr;  // pinned
+    // optional per-kernel event timing
+    struct Ev { hipEvent_t a, b; int kid; };
+    bool profiling = false;
+    std::vector<Ev> evs;              // recorded pairs not yet folded into the totals
+    std::vector<Ev> free_evs;         // recycled events
+    double prof_ms[PCA_K_COUNT] = {0};
+    int64_t prof_n[PCA_K_COUNT] = {0};
 };
+
+// Launch wrapper: plain launch, or bracketed by events while profiling is on.
+void pca_prof_begin(pca_ctx *ctx, int kid, hipStream_t s);
+void pca_prof_end(pca_ctx *ctx, hipStream_t s);
+#define PCA_LAUNCH(ctx, kid, kernel, grid, block, stream, ...)                  \
+    do {                                                                        \
+        if ((ctx)->profiling) pca_prof_begin((ctx), (kid), (stream));           \
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);        \
+        if ((ctx)->profiling) pca_prof_end((ctx), (stream));                    \
+    } while (0)
 
 #define PCA_CHECK(ctx, expr)                                                                   \
     do {                                                                                       \

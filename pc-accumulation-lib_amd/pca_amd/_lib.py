@@ -16,7 +16,10 @@ STATUS_UV_OUT_OF_IMAGE = 2
 EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error', 'pca_status',
            'pca_kitti_tile_points', 'pca_kitti_tiles', 'pca_kitti_project_sample_filter',
            'pca_nusc_sample_filter_transform', 'pca_nusc_project_cams', 'pca_retransform', 'pca_mark_dynamic',
-           'pca_bev_workspace_bytes', 'pca_bev_generate')
+           'pca_bev_workspace_bytes', 'pca_bev_generate', 'pca_profile_enable', 'pca_profile_read')
+
+KERNEL_IDS = ('kitti_project_sample_filter', 'nusc_sample_filter_transform', 'nusc_project_cams', 'retransform',
+              'mark_dynamic', 'bev_bin', 'bev_scan', 'bev_scatter', 'bev_cells')
 
 
 class PcaStore(C.Structure):
@@ -94,6 +97,8 @@ def load():
     lib.pca_bev_generate.argtypes = [
         vp, C.POINTER(PcaStore), vp, vp, i32, i32, i32, i64, C.POINTER(PcaBevParams), vp, i64, vp, vp, vp
     ]
+    lib.pca_profile_enable.argtypes = [vp, i32]
+    lib.pca_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = lib
     return lib
 
@@ -130,6 +135,18 @@ class Context:
     def check(self, rc):
         if rc != 0:
             raise RuntimeError('pca: ' + self.lib.pca_last_error(self.h).decode())
+
+    def profile(self, on):
+        self.check(self.lib.pca_profile_enable(self.h, int(bool(on))))
+
+    def profile_read(self):
+        """{kernel name: (total_ms, launches)} since profiling was enabled (synchronises)."""
+        out = {}
+        for k, name in enumerate(KERNEL_IDS):
+            ms, n = C.c_double(0), C.c_int64(0)
+            self.check(self.lib.pca_profile_read(self.h, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
 
     def status(self):
         """Synchronises the stream and returns (and clears) the device status bits."""
