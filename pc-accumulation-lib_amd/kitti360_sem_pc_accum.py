@@ -76,16 +76,16 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         self.T_prev_origin = np.matmul(self.T_prev_origin, T_new_prev)
         frame, semseg, H, W = self._frame_tensors(rgb, pc, sem_gt)
 
-        if len(self.poses) > 0:          # move everything stored so far into the new ego frame
+        if len(self._track) > 0:          # move everything stored so far into the new ego frame
             self.update_poses(T_new_prev)
             self.update_sem_pcs(T_new_prev)
         self.store.append_kitti([frame], self.P_velo_frame, H, W, self.semseg_filters)
-        self.poses.append([0., 0., 0.])
+        self._track.append([0., 0., 0.])
         self.rgbs.append(rgb)
         self.semsegs.append(semseg)
 
         idx = 0
-        if len(self.poses) > 1:
+        if len(self._track) > 1:
             idx, path_length = self.remove_observations()
             print(f'    #pc {self.store.n_frames} |', f'path length {path_length:.2f}')
         return idx

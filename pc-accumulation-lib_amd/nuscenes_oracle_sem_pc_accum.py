@@ -72,7 +72,7 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
 
         pose, semsegs = self._append_frame(obs['images'], obs['pc'], obs['pc_cam_idx'], T_ego_global,
                                            self.ego_pose_z)
-        self.poses.append(pose)
+        self._track.append(pose)
         self.rgbs.append(obs['images'])
         self.semsegs.append(semsegs)
         self.ego_global_xs.append(obs['ego_global_x'])
@@ -83,7 +83,7 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
         marks = self._tracker.observe(self.ts, obs['inst_tokens'], obs['inst_cls'], centers)
         self.store.mark_dynamic(marks)
 
-        if len(self.poses) > 1:
+        if len(self._track) > 1:
             path_length = self._track.push_segment()
         else:
             path_length = 0

@@ -37,26 +37,46 @@ def incremental_path_dists(seg_dists):
 
 
 class PoseTrack:
-    """Ego poses of the live frames (python lists of 3 floats) and the segment distances between them."""
+    """Ego poses of the live frames and the segment distances between them.
+
+    Stored as one (F,3) f64 array; ``poses`` hands out the reference's list-of-lists form.  The pose
+    update keeps the reference's arithmetic -- one (4,4)@(4,1) product PER POSE (numpy routes those to
+    gemv, whose rounding differs from a (4,4)@(4,F) gemm) -- but issues them as one stacked matmul."""
 
     def __init__(self):
-        self.poses = []
+        self._P = np.zeros((0, 3))
         self.seg_dists = []
 
+    @property
+    def poses(self):
+        return self._P.tolist()
+
+    @poses.setter
+    def poses(self, value):
+        self._P = np.array(value, dtype=np.float64).reshape(-1, 3)
+
+    def __len__(self):
+        return self._P.shape[0]
+
+    def pose(self, idx):
+        return self._P[idx].copy()
+
+    def as_array(self):
+        return self._P.copy()
+
     def apply_transform(self, T):
-        """Every stored pose p <- (T @ [p,1])[:3]; (4,4)@(4,1) products, one per pose."""
-        moved = []
-        for p in self.poses:
-            col = np.matmul(T, np.array([p + [1]]).T)
-            moved.append(list(col[:, 0][:-1]))
-        self.poses = moved
+        """Every stored pose p <- (T @ [p,1])[:3]."""
+        if self._P.shape[0] == 0:
+            return
+        homo = np.concatenate([self._P, np.ones((self._P.shape[0], 1))], axis=1)[:, :, None]   # (F,4,1)
+        self._P = np.ascontiguousarray(np.matmul(T, homo)[:, :3, 0])
 
     def append(self, pose):
-        self.poses.append(pose)
+        self._P = np.concatenate([self._P, np.asarray(pose, dtype=np.float64).reshape(1, 3)])
 
     def push_segment(self):
         """Appends the distance between the two newest poses; returns the total path length."""
-        self.seg_dists.append(pose_dist(np.array(self.poses[-1]), np.array(self.poses[-2])))
+        self.seg_dists.append(pose_dist(self._P[-1], self._P[-2]))
         return np.sum(self.seg_dists)
 
     def evict_beyond(self, horizon_dist, path_length):
@@ -66,7 +86,7 @@ class PoseTrack:
         incr = incremental_path_dists(self.seg_dists)
         incr -= path_length - horizon_dist
         k = int((incr > 0.).argmax())
-        self.poses = self.poses[k:]
+        self._P = self._P[k:]
         self.seg_dists = self.seg_dists[k:]
         return k
 
@@ -123,28 +143,32 @@ def bisect_box_crossing(x0, y0, x1, y1, bbox, thresh=1e-4):
 
 
 def crop_trajectory(traj, view, thresh=1e-4):
-    """Clips a polyline to the open view box.  Walks EDGES, so the final vertex is never emitted on its
-    own (reference behaviour) and every emitted point carries the z of the edge's first vertex."""
-    h = 0.5 * view
-    bbox = [-h, -h, h, h]
-    kept = []
-    for k in range(traj.shape[0] - 1):
-        ax, ay = list(traj[k][:2])
-        bx, by = list(traj[k + 1][:2])
-        az = traj[k][2]
-        a_in = _inside(ax, ay, *bbox)
-        b_in = _inside(bx, by, *bbox)
-        if a_in:
-            kept.append([ax, ay, az])
-            if not b_in:
-                ix, iy, _ = bisect_box_crossing(ax, ay, bx, by, bbox)
-                kept.append([ix, iy, az])
-        elif b_in:
-            ix, iy, _ = bisect_box_crossing(ax, ay, bx, by, bbox, thresh)
-            kept.append([ix, iy, az])
-    if not kept:
+    """Clips a polyline to the open view box.  Walks EDGES (a -> b): an inside `a` is emitted, an edge that
+    crosses the border additionally emits the bisected crossing point.  Consequences kept from the
+    reference: the final vertex is never emitted on its own and every emitted point carries
+    the z of its edge's first vertex.  Vertex classification is vectorised; only crossing edges loop."""
+    n = traj.shape[0]
+    if n < 2:
         return np.zeros((0, 3))
-    return np.array(kept)
+    h = 0.5 * view
+    lo = -h
+    x, y = traj[:, 0], traj[:, 1]
+    inside = (lo < x) & (x < h) & (lo < y) & (y < h)
+    a_in, b_in = inside[:-1], inside[1:]
+    crossing = a_in != b_in
+    per_edge = a_in.astype(np.int64) + crossing.astype(np.int64)
+    total = int(per_edge.sum())
+    if total == 0:
+        return np.zeros((0, 3))
+    start = np.cumsum(per_edge) - per_edge
+    out = np.empty((total, 3))
+    ka = np.nonzero(a_in)[0]
+    out[start[ka]] = traj[ka, :3]
+    bbox = [lo, lo, h, h]
+    for k in np.nonzero(crossing)[0]:
+        ix, iy, _ = bisect_box_crossing(traj[k, 0], traj[k, 1], traj[k + 1, 0], traj[k + 1, 1], bbox, thresh)
+        out[start[k] + (1 if a_in[k] else 0)] = (ix, iy, traj[k, 2])
+    return out
 
 
 def transform_traj(traj, rot_mat, dx, dy, view, px):

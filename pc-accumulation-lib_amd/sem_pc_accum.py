@@ -60,6 +60,7 @@ class SemanticPointCloudAccumulator:
 
     @property
     def poses(self):
+        """List of [x,y,z] of the live frames (a copy: mutate through the accumulator, not this list)."""
         return self._track.poses
 
     @poses.setter
@@ -117,7 +118,7 @@ class SemanticPointCloudAccumulator:
         return hl.incremental_path_dists(np.array(self.seg_dists))
 
     def get_pose(self, idx: int = None) -> np.array:
-        return np.array(self.poses) if idx is None else np.array(self.poses[idx])
+        return self._track.as_array() if idx is None else self._track.pose(idx)
 
     def get_rgb(self, idx: int = None) -> list:
         return self.rgbs if idx is None else [self.rgbs[idx]]
@@ -201,13 +202,13 @@ class SemanticPointCloudAccumulator:
     def _window_inputs(self, present_idx, gen_future, other_trajs=None, gt_lanes=None):
         """The reference's (pcs, trajs) dicts for one BEV sample, with device window handles in place of
         the concatenated host arrays (kitti360_sem_pc_accum.py:180-228 / nuscenes_oracle_...py:521-595)."""
-        origin = np.array(self.poses[-1] if present_idx is None else self.poses[present_idx])
+        poses = self._track.as_array()
+        origin = poses[-1].copy() if present_idx is None else poses[present_idx].copy()
         split = self.store.n_frames if present_idx is None else \
             (present_idx if present_idx >= 0 else self.store.n_frames + present_idx)
         if split <= 0:
             raise ValueError('need at least one array to concatenate')     # np.concatenate([]) in the reference
         win = DeviceWindow(self.store, split, origin)
-        poses = np.concatenate([self.poses])
         pcs = {'pc_present': win.part('present')}
         trajs = {'ego_traj_present': poses[:present_idx] - origin}
         others = other_trajs if other_trajs is not None else ([], [], [])
