@@ -224,19 +224,49 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
 }
 
-// ascending bitonic sort of two independent u16 keys per lane across the 64 lanes of the wave
+// Value of lane (l ^ J), VALU only (no LDS traffic, no bpermute latency):
+//   J = 1, 2  DPP quad_perm;  J = 8  DPP row_ror:8 (rotation by half a 16-lane row);
+//   J = 4     DPP row_shl:4 / row_shr:4 selected by lane bit 2;
+//   J = 16,32 gfx950 v_permlane16_swap / v_permlane32_swap of the value with itself.
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane)
+{
+    if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+    else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+    else if constexpr (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);
+    else if constexpr (J == 4) {
+        const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0xF, true);   // from l+4
+        const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // from l-4
+        return (lane & 4) ? dn : up;
+    } else if constexpr (J == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (lane & 32) ? r[0] : r[1];
+    }
+}
+
+template <int K, int J>
+__device__ __forceinline__ void sort_stage(uint32_t &key, int lane)
+{
+    const uint32_t o = lane_xor<J>(key, lane);
+    const bool up = (lane & K) == 0, lower = (lane & J) == 0;
+    key = (up == lower) ? pk_min(key, o) : pk_max(key, o);
+}
+
+// ascending bitonic sort of two independent u16 keys per lane across the 64 lanes of the wave (21 stages)
 __device__ __forceinline__ uint32_t wave_sort_pk16(uint32_t key)
 {
     const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t o = __shfl_xor(key, j, 64);
-            const bool up = (lane & k) == 0, lower = (lane & j) == 0;
-            key = (up == lower) ? pk_min(key, o) : pk_max(key, o);
-        }
-    }
+    sort_stage<2, 1>(key, lane);
+    sort_stage<4, 2>(key, lane); sort_stage<4, 1>(key, lane);
+    sort_stage<8, 4>(key, lane); sort_stage<8, 2>(key, lane); sort_stage<8, 1>(key, lane);
+    sort_stage<16, 8>(key, lane); sort_stage<16, 4>(key, lane); sort_stage<16, 2>(key, lane); sort_stage<16, 1>(key, lane);
+    sort_stage<32, 16>(key, lane); sort_stage<32, 8>(key, lane); sort_stage<32, 4>(key, lane); sort_stage<32, 2>(key, lane);
+    sort_stage<32, 1>(key, lane);
+    sort_stage<64, 32>(key, lane); sort_stage<64, 16>(key, lane); sort_stage<64, 8>(key, lane); sort_stage<64, 4>(key, lane);
+    sort_stage<64, 2>(key, lane); sort_stage<64, 1>(key, lane);
     return key;
 }
 
