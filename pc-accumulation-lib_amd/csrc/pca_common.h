@@ -35,12 +35,14 @@ struct pca_ctx {
 // Launch wrapper: plain launch, or bracketed by events while profiling is on.
 void pca_prof_begin(pca_ctx *ctx, int kid, hipStream_t s);
 void pca_prof_end(pca_ctx *ctx, hipStream_t s);
-#define PCA_LAUNCH(ctx, kid, kernel, grid, block, stream, ...)                  \
+#define PCA_LAUNCH_SHM(ctx, kid, kernel, grid, block, shm, stream, ...)        \
     do {                                                                        \
         if ((ctx)->profiling) pca_prof_begin((ctx), (kid), (stream));           \
-        hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);        \
+        hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);      \
         if ((ctx)->profiling) pca_prof_end((ctx), (stream));                    \
     } while (0)
+#define PCA_LAUNCH(ctx, kid, kernel, grid, block, stream, ...) \
+    PCA_LAUNCH_SHM(ctx, kid, kernel, grid, block, 0, stream, __VA_ARGS__)
 
 #define PCA_CHECK(ctx, expr)                                                                   \
     do {                                                                                       \
