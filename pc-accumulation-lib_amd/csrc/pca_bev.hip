@@ -26,6 +26,10 @@
 #define FLAG_ROAD (1u << 24)
 #define FLAG_DYNOBJ (1u << 25)
 
+// tile-ordered records: one packed stream (5 or 6 dwords) so that a (workgroup, tile) run is one contiguous write
+struct __attribute__((packed, aligned(4))) RecF { double z; float inten; uint32_t c; uint32_t fk; };   // 20 B
+struct RecD { double z; double inten; uint32_t c; uint32_t fk; };                                      // 24 B
+
 struct BevArgs {
     pca_store st;
     const double *intensity64;
@@ -38,10 +42,7 @@ struct BevArgs {
     uint32_t *bh;         // [G*T]
     uint32_t *boff;       // [G*T]
     uint32_t *tile_off;   // [T+1]
-    double *rz;           // tile-ordered record streams [max_points]
-    void *ri;             // float (or double with intensity64)
-    uint32_t *rc;         // r | g<<8 | b<<16 | FLAG_*
-    uint8_t *rk;          // fine key
+    void *recs;           // RecF / RecD [max_points], tile-ordered; c = r | g<<8 | b<<16 | FLAG_*
     double *planes;
     uint16_t *planes_f16;
     uint64_t *state;
@@ -79,31 +80,48 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_hist(const BevArgs a)
     const pca_bev_params &q = a.prm;
     const double v = q.view, vlo = -0.5 * v, vhi = 0.5 * v, pxd = (double)q.px, half_px = 0.5 * pxd;
     const bool use_h = !(q.height_filter != q.height_filter);
-    for (int64_t p = w.c_lo + threadIdx.x; p < w.c_hi; p += AB_THREADS) {
-        const double x = a.st.x[p] - q.origin[0];
-        const double y = a.st.y[p] - q.origin[1];
-        const double z = a.st.z[p] - q.origin[2];
-        double ax = q.R[0] * x; ax = fma(q.R[1], y, ax); ax = fma(q.R[2], z, ax);
-        double ay = q.R[3] * x; ay = fma(q.R[4], y, ay); ay = fma(q.R[5], z, ay);
-        double az = q.R[6] * x; az = fma(q.R[7], y, az); az = fma(q.R[8], z, az);
-        ax += q.dx;
-        ay += q.dy;
-        bool keep = (ax > vlo) && (ax < vhi) && (ay > vlo) && (ay < vhi);
-        if (use_h) keep = keep && (az < q.height_filter);
-        keep = keep && (a.st.dyn[p] != 1);
-        uint32_t key = KEY_INVALID;
-        if (keep) {
-            int i = (int)floor(ax / v * pxd + half_px);
-            int j = (int)floor(ay / v * pxd + half_px);
-            i = i > q.px - 1 ? q.px - 1 : (i < 0 ? 0 : i);
-            j = j > q.px - 1 ? q.px - 1 : (j < 0 ? 0 : j);
-            const int row = q.px - 1 - j, col = i;
-            const uint32_t tile = (uint32_t)((row / TS) * a.tx + (col / TS));
-            const uint32_t fk = (uint32_t)(((row % TS) * TS + (col % TS)) * 2) + (p >= w.sp ? 1u : 0u);
-            key = (tile << 7) | fk;
-            atomicAdd(&s_h[tile], 1u);
+    constexpr int UNR = 4;          // independent points per thread and iteration (memory-level parallelism)
+    for (int64_t base = w.c_lo + threadIdx.x; base < w.c_hi; base += UNR * AB_THREADS) {
+        double X[UNR], Y[UNR], Z[UNR];
+        uint8_t D[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t p = base + u * AB_THREADS;
+            const bool in = p < w.c_hi;
+            X[u] = in ? a.st.x[p] : 0.0;
+            Y[u] = in ? a.st.y[p] : 0.0;
+            Z[u] = in ? a.st.z[p] : 0.0;
+            D[u] = in ? a.st.dyn[p] : (uint8_t)1;
         }
-        a.key[p - w.lo] = key;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t p = base + u * AB_THREADS;
+            if (p >= w.c_hi) continue;
+            const double x = X[u] - q.origin[0];
+            const double y = Y[u] - q.origin[1];
+            const double z = Z[u] - q.origin[2];
+            double ax = q.R[0] * x; ax = fma(q.R[1], y, ax); ax = fma(q.R[2], z, ax);
+            double ay = q.R[3] * x; ay = fma(q.R[4], y, ay); ay = fma(q.R[5], z, ay);
+            double az = q.R[6] * x; az = fma(q.R[7], y, az); az = fma(q.R[8], z, az);
+            ax += q.dx;
+            ay += q.dy;
+            bool keep = (ax > vlo) && (ax < vhi) && (ay > vlo) && (ay < vhi);
+            if (use_h) keep = keep && (az < q.height_filter);
+            keep = keep && (D[u] != 1);
+            uint32_t key = KEY_INVALID;
+            if (keep) {
+                int i = (int)floor(ax / v * pxd + half_px);
+                int j = (int)floor(ay / v * pxd + half_px);
+                i = i > q.px - 1 ? q.px - 1 : (i < 0 ? 0 : i);
+                j = j > q.px - 1 ? q.px - 1 : (j < 0 ? 0 : j);
+                const int row = q.px - 1 - j, col = i;
+                const uint32_t tile = (uint32_t)((row / TS) * a.tx + (col / TS));
+                const uint32_t fk = (uint32_t)(((row % TS) * TS + (col % TS)) * 2) + (p >= w.sp ? 1u : 0u);
+                key = (tile << 7) | fk;
+                atomicAdd(&s_h[tile], 1u);
+            }
+            a.key[p - w.lo] = key;
+        }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < a.T; t += AB_THREADS) a.bh[(int64_t)blockIdx.x * a.T + t] = s_h[t];
@@ -185,20 +203,41 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_scatter(const BevArgs a)
     __syncthreads();
     const pca_bev_params &q = a.prm;
     const double oz = q.origin[2];
-    for (int64_t p = w.c_lo + threadIdx.x; p < w.c_hi; p += AB_THREADS) {
-        const uint32_t key = a.key[p - w.lo];
-        if (key == KEY_INVALID) continue;
-        const uint32_t pos = atomicAdd(&s_cur[key >> 7], 1u);
-        const uint32_t rgbs = a.st.rgbs[p];
-        const unsigned sem = rgbs >> 24;
-        uint32_t c = rgbs & 0xffffffu;
-        if ((int)sem == q.road_class) c |= FLAG_ROAD;
-        if ((q.dynobj_mask[sem >> 6] >> (sem & 63)) & 1ull) c |= FLAG_DYNOBJ;
-        a.rz[pos] = a.st.z[p] - oz;                         // rotation about z: row 3 of R is (0,0,1)
-        if (I64) reinterpret_cast<double *>(a.ri)[pos] = a.intensity64[p];
-        else reinterpret_cast<float *>(a.ri)[pos] = a.st.intensity[p];
-        a.rc[pos] = c;
-        a.rk[pos] = (uint8_t)(key & 127u);
+    constexpr int UNR = 4;
+    for (int64_t base = w.c_lo + threadIdx.x; base < w.c_hi; base += UNR * AB_THREADS) {
+        uint32_t key[UNR], pos[UNR], rgbs[UNR];
+        double zz[UNR], iv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t p = base + u * AB_THREADS;
+            key[u] = p < w.c_hi ? a.key[p - w.lo] : KEY_INVALID;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t p = base + u * AB_THREADS;
+            const bool ok = key[u] != KEY_INVALID;
+            rgbs[u] = ok ? a.st.rgbs[p] : 0u;
+            zz[u] = ok ? a.st.z[p] : 0.0;
+            if (I64) iv[u] = ok ? a.intensity64[p] : 0.0;
+            else iv[u] = ok ? (double)a.st.intensity[p] : 0.0;
+            pos[u] = ok ? atomicAdd(&s_cur[key[u] >> 7], 1u) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (key[u] == KEY_INVALID) continue;
+            const unsigned sem = rgbs[u] >> 24;
+            uint32_t c = rgbs[u] & 0xffffffu;
+            if ((int)sem == q.road_class) c |= FLAG_ROAD;
+            if ((q.dynobj_mask[sem >> 6] >> (sem & 63)) & 1ull) c |= FLAG_DYNOBJ;
+            const double z = zz[u] - oz;                    // rotation about z: row 3 of R is (0,0,1)
+            if (I64) {
+                RecD r; r.z = z; r.inten = iv[u]; r.c = c; r.fk = key[u] & 127u;
+                reinterpret_cast<RecD *>(a.recs)[pos[u]] = r;
+            } else {
+                RecF r; r.z = z; r.inten = (float)iv[u]; r.c = c; r.fk = key[u] & 127u;
+                reinterpret_cast<RecF *>(a.recs)[pos[u]] = r;
+            }
+        }
     }
 }
 
@@ -214,6 +253,15 @@ struct TileLds {
 
 // adds the colours of one (cell,set) to the block histogram; values come from the LDS-sorted batch or,
 // for a cell too large for LDS, straight from the tile's record streams
+template <bool I64> __device__ __forceinline__ constexpr int REC_C() { return I64 ? 4 : 3; }
+template <bool I64> __device__ __forceinline__ constexpr int REC_FK() { return I64 ? 5 : 4; }
+template <bool I64>
+__device__ __forceinline__ const uint32_t *rec_words(const BevArgs &a, uint32_t r)
+{
+    return reinterpret_cast<const uint32_t *>(a.recs) + (size_t)r * (I64 ? 6 : 5);
+}
+
+template <bool I64>
 __device__ __forceinline__ void hist_add(TileLds &L, const BevArgs &a, const uint32_t *s_rgb, bool from_lds, uint32_t fk,
                                          uint32_t lds_base, uint32_t r_lo, uint32_t r_hi)
 {
@@ -225,7 +273,11 @@ __device__ __forceinline__ void hist_add(TileLds &L, const BevArgs &a, const uin
         uint32_t v = 0;
         if (act) {
             if (from_lds) v = s_rgb[lds_base + i];
-            else { act = a.rk[r_lo + i] == fk; if (act) v = a.rc[r_lo + i]; }
+            else {
+                const uint32_t *w = rec_words<I64>(a, r_lo + i);
+                act = w[REC_FK<I64>()] == fk;
+                if (act) v = w[REC_C<I64>()];
+            }
         }
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -249,6 +301,7 @@ __device__ __forceinline__ void hist_zero(TileLds &L)
 }
 
 // medians of one cell with more than 64 values, whole workgroup
+template <bool I64>
 __device__ __forceinline__ void big_cell_medians(TileLds &L, const BevArgs &a, const uint32_t *s_rgb, bool from_lds, int cell,
                                                  uint32_t batch_base, uint32_t r_lo, uint32_t r_hi)
 {
@@ -257,17 +310,17 @@ __device__ __forceinline__ void big_cell_medians(TileLds &L, const BevArgs &a, c
     const int wave = threadIdx.x >> 6;
     hist_zero(L);
     __syncthreads();
-    hist_add(L, a, s_rgb, from_lds, 2 * cell, base_p, r_lo, r_hi);
+    hist_add<I64>(L, a, s_rgb, from_lds, 2 * cell, base_p, r_lo, r_hi);
     __syncthreads();
     if (wave < 3) { const uint32_t m = hist_med2(L.hist[wave], n_p); if ((threadIdx.x & 63) == 0) L.med2[0][cell][wave] = m; }
     __syncthreads();
-    hist_add(L, a, s_rgb, from_lds, 2 * cell + 1, base_f, r_lo, r_hi);
+    hist_add<I64>(L, a, s_rgb, from_lds, 2 * cell + 1, base_f, r_lo, r_hi);
     __syncthreads();
     if (wave < 3) { const uint32_t m = hist_med2(L.hist[wave], n_p + n_f); if ((threadIdx.x & 63) == 0) L.med2[2][cell][wave] = m; }
     __syncthreads();
     hist_zero(L);
     __syncthreads();
-    hist_add(L, a, s_rgb, from_lds, 2 * cell + 1, base_f, r_lo, r_hi);
+    hist_add<I64>(L, a, s_rgb, from_lds, 2 * cell + 1, base_f, r_lo, r_hi);
     __syncthreads();
     if (wave < 3) { const uint32_t m = hist_med2(L.hist[wave], n_f); if ((threadIdx.x & 63) == 0) L.med2[1][cell][wave] = m; }
     __syncthreads();
@@ -293,18 +346,20 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
 
     // ---- pass 1: per (cell,set) statistics with LDS atomics ----
     for (uint32_t r = r_lo + threadIdx.x; r < r_hi; r += C_THREADS) {
-        const uint32_t k = a.rk[r];
-        const uint32_t c = a.rc[r];
+        uint32_t k, c;
+        double z, iv;
+        if (I64) {
+            const RecD rec = reinterpret_cast<const RecD *>(a.recs)[r];
+            k = rec.fk; c = rec.c; z = rec.z; iv = rec.inten;
+        } else {
+            const RecF rec = reinterpret_cast<const RecF *>(a.recs)[r];
+            k = rec.fk; c = rec.c; z = rec.z;
+            iv = q.intensity_div255 ? (double)rec.inten / 255.0 : (double)rec.inten;
+        }
         atomicAdd(&L.cnt[k], 1u);
-        atomicMin(&L.zk[k], (unsigned long long)f64_order_key(a.rz[r]));
+        atomicMin(&L.zk[k], (unsigned long long)f64_order_key(z));
         if (c & FLAG_DYNOBJ) atomicAdd(&L.dyn[k], 1u);
         if (c & FLAG_ROAD) {
-            double iv;
-            if (I64) iv = reinterpret_cast<const double *>(a.ri)[r];
-            else {
-                const float f = reinterpret_cast<const float *>(a.ri)[r];
-                iv = q.intensity_div255 ? (double)f / 255.0 : (double)f;
-            }
             const double sc = iv * FX_HI, fl = floor(sc);
             atomicAdd(&L.road[k], 1u);
             atomicAdd(&L.ihi[k], (unsigned long long)(long long)fl);
@@ -337,7 +392,7 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
         if (!huge)
             while (c_end < TCELLS && L.off[2 * c_end + 2] - base <= RGB_CAP) ++c_end;
         if (huge) {
-            big_cell_medians(L, a, s_rgb, false, c_begin, base, r_lo, r_hi);
+            big_cell_medians<I64>(L, a, s_rgb, false, c_begin, base, r_lo, r_hi);
         } else {
             const uint32_t n_batch = L.off[2 * c_end] - base;
             if (n_batch) {
@@ -345,9 +400,10 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
                 __syncthreads();
                 const bool all = (c_begin == 0 && c_end == TCELLS);
                 for (uint32_t r = r_lo + threadIdx.x; r < r_hi; r += C_THREADS) {
-                    const uint32_t k = a.rk[r];
+                    const uint32_t *w = rec_words<I64>(a, r);
+                    const uint32_t k = w[REC_FK<I64>()];
                     if (all || ((int)(k >> 1) >= c_begin && (int)(k >> 1) < c_end))
-                        s_rgb[atomicAdd(&L.cur[k], 1u)] = a.rc[r] & 0xffffffu;
+                        s_rgb[atomicAdd(&L.cur[k], 1u)] = w[REC_C<I64>()] & 0xffffffu;
                 }
                 __syncthreads();
                 for (int cell = c_begin + wave; cell < c_end; cell += C_THREADS / 64) {
@@ -365,7 +421,7 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
                 }
                 __syncthreads();
                 for (int cell = c_begin; cell < c_end; ++cell)
-                    if (L.cnt[2 * cell] + L.cnt[2 * cell + 1] > 64) big_cell_medians(L, a, s_rgb, true, cell, base, r_lo, r_hi);
+                    if (L.cnt[2 * cell] + L.cnt[2 * cell + 1] > 64) big_cell_medians<I64>(L, a, s_rgb, true, cell, base, r_lo, r_hi);
             }
         }
         __syncthreads();
@@ -426,8 +482,7 @@ int64_t pca_bev_workspace_bytes(int64_t max_points, int px)
 {
     if (max_points < 1) max_points = 1;
     const int64_t T = (int64_t)tiles_x(px) * tiles_x(px), G = n_groups(max_points);
-    return align256(max_points * 4) + 2 * align256(G * T * 4) + align256((T + 1) * 4) + 2 * align256(max_points * 8) +
-           align256(max_points * 4) + align256(max_points) + 512;
+    return align256(max_points * 4) + 2 * align256(G * T * 4) + align256((T + 1) * 4) + align256(max_points * 24) + 512;
 }
 
 int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensity64, const int64_t *frame_off,
@@ -458,10 +513,7 @@ int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensi
     a.bh = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)a.G * a.T * 4);
     a.boff = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)a.G * a.T * 4);
     a.tile_off = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.T + 1) * 4);
-    a.rz = reinterpret_cast<double *>(w); w += align256(max_points * 8);
-    a.ri = w; w += align256(max_points * 8);
-    a.rc = reinterpret_cast<uint32_t *>(w); w += align256(max_points * 4);
-    a.rk = reinterpret_cast<uint8_t *>(w);
+    a.recs = w;
     a.planes = planes;
     a.planes_f16 = planes_f16;
     const int64_t n_scan = (int64_t)a.T * a.G;
