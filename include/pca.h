@@ -156,11 +156,16 @@ typedef struct {
 int64_t pca_bev_workspace_bytes(int64_t max_points, int px);
 
 /* intensity64 (dev, may be NULL): f64 intensities indexed like the store, overriding store.intensity
- * (for callers whose column 3 is not f32-representable).  max_points bounds the window size. */
+ * (for callers whose column 3 is not f32-representable).  max_points bounds the window size.
+ * pending_T (host, 4x4 row-major, may be NULL): a re-transform that is still owed to the frames
+ * [slot_begin, pending_slot_end) (sem_pc_accum.py:167-183).  It is applied -- and written back to the store,
+ * exactly as pca_retransform would -- by the first kernel of the rasteriser, which reads those coordinates
+ * anyway; this saves one full read of the store per step when every integrate() is followed by a BEV. */
 int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensity64,
                      const int64_t *frame_off /*dev*/, int slot_begin, int slot_split, int slot_end,
-                     int64_t max_points, const pca_bev_params *prm, void *workspace /*dev*/,
-                     int64_t workspace_bytes, double *planes /*dev*/, uint16_t *planes_f16 /*dev*/, void *stream);
+                     int64_t max_points, const pca_bev_params *prm, const double *pending_T, int pending_slot_end,
+                     void *workspace /*dev*/, int64_t workspace_bytes, double *planes /*dev*/,
+                     uint16_t *planes_f16 /*dev*/, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optional per-kernel timing: while enabled every kernel launch is bracketed by HIP events recorded on

@@ -37,6 +37,8 @@ struct BevArgs {
     int slot_begin, slot_split, slot_end;
     int64_t max_points;
     pca_bev_params prm;
+    Mat34 pend_T;         // owed re-transform of slots [slot_begin, pend_slot_end), fused into the hist kernel
+    int pend_slot_end;    // <= slot_begin: none
     int tx, T, G;
     uint32_t *key;        // [max_points]
     uint32_t *bh;         // [G*T]
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_hist(const BevArgs a)
     const pca_bev_params &q = a.prm;
     const double v = q.view, vlo = -0.5 * v, vhi = 0.5 * v, pxd = (double)q.px, half_px = 0.5 * pxd;
     const bool use_h = !(q.height_filter != q.height_filter);
+    const int64_t pend_hi = a.pend_slot_end > a.slot_begin ? a.frame_off[a.pend_slot_end] : w.lo;
     constexpr int UNR = 4;          // independent points per thread and iteration (memory-level parallelism)
     for (int64_t base = w.c_lo + threadIdx.x; base < w.c_hi; base += UNR * AB_THREADS) {
         double X[UNR], Y[UNR], Z[UNR];
@@ -92,6 +95,16 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_hist(const BevArgs a)
             Y[u] = in ? a.st.y[p] : 0.0;
             Z[u] = in ? a.st.z[p] : 0.0;
             D[u] = in ? a.st.dyn[p] : (uint8_t)1;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {                     // owed re-transform: apply and write back
+            const int64_t p = base + u * AB_THREADS;
+            if (p < w.c_hi && p < pend_hi) {
+                const double nx = row4(a.pend_T.m + 0, X[u], Y[u], Z[u]), ny = row4(a.pend_T.m + 4, X[u], Y[u], Z[u]),
+                             nz = row4(a.pend_T.m + 8, X[u], Y[u], Z[u]);
+                X[u] = nx; Y[u] = ny; Z[u] = nz;
+                a.st.x[p] = nx; a.st.y[p] = ny; a.st.z[p] = nz;
+            }
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -487,7 +500,8 @@ int64_t pca_bev_workspace_bytes(int64_t max_points, int px)
 
 int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensity64, const int64_t *frame_off,
                      int slot_begin, int slot_split, int slot_end, int64_t max_points, const pca_bev_params *prm,
-                     void *workspace, int64_t workspace_bytes, double *planes, uint16_t *planes_f16, void *stream)
+                     const double *pending_T, int pending_slot_end, void *workspace, int64_t workspace_bytes,
+                     double *planes, uint16_t *planes_f16, void *stream)
 {
     if (!ctx) return -1;
     if (!store || !frame_off || !prm || !workspace || (!planes && !planes_f16)) { ctx->err = "bev: bad arguments"; return -1; }
@@ -505,6 +519,13 @@ int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensi
     a.slot_begin = slot_begin; a.slot_split = slot_split; a.slot_end = slot_end;
     a.max_points = max_points;
     a.prm = *prm;
+    a.pend_slot_end = slot_begin;
+    for (int i = 0; i < 12; ++i) a.pend_T.m[i] = 0.0;
+    if (pending_T && pending_slot_end > slot_begin) {
+        if (pending_slot_end > slot_end) { ctx->err = "bev: pending_slot_end beyond the window"; return -1; }
+        a.pend_slot_end = pending_slot_end;
+        for (int i = 0; i < 12; ++i) a.pend_T.m[i] = pending_T[i];
+    }
     a.tx = tiles_x(prm->px);
     a.T = a.tx * a.tx;
     a.G = n_groups(max_points);

@@ -95,7 +95,8 @@ def load():
     lib.pca_bev_workspace_bytes.argtypes = [i64, i32]
     lib.pca_bev_workspace_bytes.restype = i64
     lib.pca_bev_generate.argtypes = [
-        vp, C.POINTER(PcaStore), vp, vp, i32, i32, i32, i64, C.POINTER(PcaBevParams), vp, i64, vp, vp, vp
+        vp, C.POINTER(PcaStore), vp, vp, i32, i32, i32, i64, C.POINTER(PcaBevParams), C.POINTER(C.c_double), i32,
+        vp, i64, vp, vp, vp
     ]
     lib.pca_profile_enable.argtypes = [vp, i32]
     lib.pca_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]

@@ -31,6 +31,7 @@ class DeviceStore:
         self.ub_tail = 0         # upper bound of frame_off[tail]
         self.lb_head = 0         # lower bound of frame_off[head] (exact after a sync)
         self._ub = []            # per live frame: upper bound of its size (its input point count)
+        self._pending = None     # (T 4x4, end slot): a re-transform owed to slots [head, end slot)
         self._ws = None
         self._planes16 = {}
         self._planes64 = {}
@@ -80,6 +81,7 @@ class DeviceStore:
         """Make room for n_slots more frames holding at most n_new points in total."""
         if self.tail + n_slots <= self.max_frames and self.ub_tail + n_new <= self.capacity:
             return
+        self.flush_pending()
         off = self.offsets()                       # synchronises: exact numbers
         a, b = int(off[0]), int(off[-1])
         live, nf = b - a, self.n_frames
@@ -115,6 +117,7 @@ class DeviceStore:
         self.head = self.tail = 0
         self.ub_tail = self.lb_head = 0
         self._ub = []
+        self._pending = None
         self.frame_off.zero_()
 
     # ---- K1: KITTI ------------------------------------------------------------------------
@@ -162,15 +165,32 @@ class DeviceStore:
         self._ub.append(n)
 
     # ---- K2 / K3 --------------------------------------------------------------------------
-    def retransform(self, Ts):
-        """Applies the 4x4 transform(s) to every live point, in order (Ts: (4,4) or (k,4,4))."""
+    def retransform(self, Ts, defer=False):
+        """Applies the 4x4 transform(s) to every live point, in order (Ts: (4,4) or (k,4,4)).
+        defer=True (single transform): the transform is only recorded; it is applied by the next consumer
+        of the coordinates -- fused into the BEV rasteriser's first pass if that comes next (it reads every
+        coordinate anyway), otherwise by a K2 launch (`flush_pending`).  Results are bit-identical."""
         if self.n_frames == 0:
             return
+        self.flush_pending()
         Ts = np.ascontiguousarray(Ts, dtype=np.float64).reshape(-1, 16)
+        if defer and Ts.shape[0] == 1:
+            self._pending = (Ts[0].copy(), self.tail)
+            return
+        self._launch_retransform(Ts, self.tail)
+
+    def _launch_retransform(self, Ts, end_slot):
         st = self.c_store()
         ctx = self.ctx
-        ctx.check(ctx.lib.pca_retransform(ctx.h, C.byref(st), self.frame_off.data_ptr(), self.head, self.tail,
+        ctx.check(ctx.lib.pca_retransform(ctx.h, C.byref(st), self.frame_off.data_ptr(), self.head, end_slot,
                                           _lib.f64_array(Ts, Ts.size), Ts.shape[0], ctx.stream()))
+
+    def flush_pending(self):
+        if self._pending is not None:
+            T, end_slot = self._pending
+            self._pending = None
+            if end_slot > self.head:
+                self._launch_retransform(T.reshape(1, 16), end_slot)
 
     def mark_dynamic(self, pairs):
         """pairs: iterable of (frame index in the live window, instance index)."""
@@ -198,9 +218,17 @@ class DeviceStore:
         p16 = torch.empty((21, px, px), dtype=torch.float16, device=self.device)
         p64 = torch.empty((21, px, px), dtype=torch.float64, device=self.device) if want_f64 else None
         st = self.c_store()
+        pend_T, pend_end = None, 0
+        if self._pending is not None:
+            if first_frame == 0 and self._pending[1] <= self.head + last_frame:
+                pend_T, pend_end = _lib.f64_array(self._pending[0], 16), self._pending[1]
+                self._pending = None
+            else:
+                self.flush_pending()
         ctx.check(lib.pca_bev_generate(ctx.h, C.byref(st), None if intensity64 is None else intensity64.data_ptr(),
                                        self.frame_off.data_ptr(), self.head + first_frame, self.head + split_frame,
-                                       self.head + last_frame, max_points, C.byref(prm), self._ws.data_ptr(),
+                                       self.head + last_frame, max_points, C.byref(prm), pend_T, pend_end,
+                                       self._ws.data_ptr(),
                                        self._ws.numel(), None if p64 is None else p64.data_ptr(), p16.data_ptr(),
                                        ctx.stream()))
         return p16, p64
@@ -208,6 +236,7 @@ class DeviceStore:
     # ---- host views (synchronise) -----------------------------------------------------------
     def rows(self, frame=None):
         """(M,10) f64 rows exactly as the reference keeps them in sem_pcs (one frame, or all live points)."""
+        self.flush_pending()
         off = self.offsets()
         lo, hi = (int(off[0]), int(off[-1])) if frame is None else (int(off[frame]), int(off[frame + 1]))
         out = np.empty((hi - lo, 10))

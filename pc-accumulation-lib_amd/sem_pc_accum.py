@@ -93,8 +93,9 @@ class SemanticPointCloudAccumulator:
         self._track.apply_transform(T_new_prev)
 
     def update_sem_pcs(self, T_new_prev):
-        """Every stored point p <- T_new_prev p, in place on the device (K2)."""
-        self.store.retransform(np.asarray(T_new_prev, dtype=np.float64))
+        """Every stored point p <- T_new_prev p, in place on the device (K2; deferred so that a BEV that
+        follows immediately applies it in its first pass -- same roundings, one read of the store less)."""
+        self.store.retransform(np.asarray(T_new_prev, dtype=np.float64), defer=True)
 
     def remove_observations(self):
         """Appends the newest path segment and evicts frames beyond the memory horizon."""
