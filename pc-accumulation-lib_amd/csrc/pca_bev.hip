@@ -10,7 +10,7 @@
 //   level 2 (one workgroup per tile)
 //     bev_tile_cells    pass 1: per (cell,set) counts / exact integer intensity sums / min z by LDS atomics;
 //                       pass 2: LDS counting sort of the colours by (cell,set); per-cell exact medians
-//                       (n <= 64: packed bitonic sort in registers, else 256-bin LDS histogram);
+//                       (n <= 64: bit-sliced radix select, one lane per target; else 256-bin LDS histogram);
 //                       closed-form maps, fp16, tile written back.
 // 'full' = present (+) future is formed per cell (counts add, min of mins, median of the union).
 #include "pca_bev_common.h"
@@ -262,7 +262,72 @@ struct TileLds {
     unsigned long long ihi[NFK], ilo[NFK], zk[NFK];
     uint32_t med2[3][TCELLS][3];                            // [present, future, full][cell][channel]
     uint32_t hist[3][256];                                  // cells with more than 64 values
+    unsigned long long bits[TCELLS][24];                    // cells with <= 64 values: one 64-lane mask per colour bit
 };
+
+// ---- medians of cells with at most 64 values: bit-sliced radix select -------------------------------------
+// Phase 1 (per cell, whole wave): the cell's values sit one per lane (present lanes first); 24 ballots give
+// the 64-bit membership mask of every colour bit, parked in LDS.
+// Phase 2 (per wave): one LANE per (cell, set, channel, lower|upper middle) target -- 18 per cell -- walks the 8
+// bit planes from the top: zeros = cand & ~plane; rank < popcount(zeros) ? keep zeros : (rank -= ..., keep ones,
+// set the bit).  That is ~12 VALU per plane for 64 targets at once instead of a 21-stage sort per channel.
+__device__ __forceinline__ void small_cells_bitplanes(TileLds &L, const uint32_t *s_rgb, uint32_t base, int c_begin, int c_end)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = 0; i < TCELLS / 4; ++i) {
+        const int cell = 4 * i + wave;
+        if (cell < c_begin || cell >= c_end) continue;
+        const uint32_t n = L.cnt[2 * cell] + L.cnt[2 * cell + 1];
+        if (n == 0 || n > 64) continue;
+        const uint32_t v = (uint32_t)lane < n ? s_rgb[L.off[2 * cell] - base + lane] : 0u;
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int b = 0; b < 24; ++b) {
+            const unsigned long long m = __ballot((v >> b) & 1u);
+            mine = (lane == b) ? m : mine;
+        }
+        if (lane < 24) L.bits[cell][lane] = mine;
+    }
+}
+
+__device__ __forceinline__ void small_cells_select(TileLds &L, int c_begin, int c_end)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NT = (TCELLS / 4) * 18;                   // targets of one wave
+    for (int t0 = 0; t0 < NT; t0 += 64) {
+        const int t = t0 + lane;
+        const int i = t / 18, qq = t - 18 * i;
+        const int cell = 4 * i + wave;
+        const int set = qq / 6, ch = (qq % 6) >> 1, upper = qq & 1;
+        bool ok = t < NT && cell >= c_begin && cell < c_end;
+        uint32_t n_p = 0, n_f = 0;
+        if (ok) { n_p = L.cnt[2 * cell]; n_f = L.cnt[2 * cell + 1]; }
+        const uint32_t n = n_p + n_f;
+        ok = ok && n > 0 && n <= 64;
+        const unsigned long long m_p = n_p >= 64 ? ~0ull : ((1ull << n_p) - 1ull);
+        const unsigned long long m_all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+        unsigned long long cand = set == 0 ? m_p : (set == 1 ? (m_all & ~m_p) : m_all);
+        const uint32_t n_s = (uint32_t)__popcll(cand);
+        ok = ok && n_s > 0;
+        uint32_t k = upper ? (n_s >> 1) : ((n_s - 1) >> 1);
+        uint32_t val = 0;
+        if (ok) {
+            const unsigned long long *planes = &L.bits[cell][8 * ch];
+#pragma unroll
+            for (int b = 7; b >= 0; --b) {
+                const unsigned long long B = planes[b];
+                const unsigned long long zeros = cand & ~B;
+                const uint32_t cz = (uint32_t)__popcll(zeros);
+                const bool take0 = k < cz;
+                cand = take0 ? zeros : (cand & B);
+                k = take0 ? k : k - cz;
+                val |= take0 ? 0u : (1u << b);
+            }
+        }
+        const uint32_t other = __shfl_xor(val, 1, 64);      // the partner target (lower <-> upper middle) is the adjacent lane
+        if (ok && !upper) L.med2[set][cell][ch] = val + other;
+    }
+}
 
 // adds the colours of one (cell,set) to the block histogram; values come from the LDS-sorted batch or,
 // for a cell too large for LDS, straight from the tile's record streams
@@ -358,9 +423,28 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
     __syncthreads();
 
     // ---- pass 1: per (cell,set) statistics with LDS atomics ----
-    for (uint32_t r = r_lo + threadIdx.x; r < r_hi; r += C_THREADS) {
-        uint32_t k, c;
-        double z, iv;
+    // If the tile's records fit the LDS colour buffer (the normal case) every thread keeps its <= RPT records'
+    // (key, rank, colour) in registers -- the rank comes back from the counting atomic -- and pass 2 is a pure
+    // LDS scatter without touching memory again.
+    constexpr int RPT = RGB_CAP / C_THREADS;
+    const bool fits = (r_hi - r_lo) <= RGB_CAP;
+    uint32_t kr[RPT], cc[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) { kr[u] = 0xffffffffu; cc[u] = 0; }
+    auto account = [&](uint32_t k, uint32_t c, double z, double iv, bool want_rank) -> uint32_t {
+        uint32_t rank = 0;
+        if (want_rank) rank = atomicAdd(&L.cnt[k], 1u); else atomicAdd(&L.cnt[k], 1u);
+        atomicMin(&L.zk[k], (unsigned long long)f64_order_key(z));
+        if (c & FLAG_DYNOBJ) atomicAdd(&L.dyn[k], 1u);
+        if (c & FLAG_ROAD) {
+            const double sc = iv * FX_HI, fl = floor(sc);
+            atomicAdd(&L.road[k], 1u);
+            atomicAdd(&L.ihi[k], (unsigned long long)(long long)fl);
+            atomicAdd(&L.ilo[k], (unsigned long long)(long long)rint((sc - fl) * FX_LO));
+        }
+        return rank;
+    };
+    auto load = [&](uint32_t r, uint32_t &k, uint32_t &c, double &z, double &iv) {
         if (I64) {
             const RecD rec = reinterpret_cast<const RecD *>(a.recs)[r];
             k = rec.fk; c = rec.c; z = rec.z; iv = rec.inten;
@@ -369,14 +453,33 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
             k = rec.fk; c = rec.c; z = rec.z;
             iv = q.intensity_div255 ? (double)rec.inten / 255.0 : (double)rec.inten;
         }
-        atomicAdd(&L.cnt[k], 1u);
-        atomicMin(&L.zk[k], (unsigned long long)f64_order_key(z));
-        if (c & FLAG_DYNOBJ) atomicAdd(&L.dyn[k], 1u);
-        if (c & FLAG_ROAD) {
-            const double sc = iv * FX_HI, fl = floor(sc);
-            atomicAdd(&L.road[k], 1u);
-            atomicAdd(&L.ihi[k], (unsigned long long)(long long)fl);
-            atomicAdd(&L.ilo[k], (unsigned long long)(long long)rint((sc - fl) * FX_LO));
+    };
+    if (fits) {
+        constexpr int HALF = RPT / 2;                       // two rounds of loads: bounds the registers in flight
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t k[HALF], c[HALF];
+            double z[HALF], iv[HALF];
+#pragma unroll
+            for (int u = 0; u < HALF; ++u) {
+                const uint32_t r = r_lo + (h * HALF + u) * C_THREADS + threadIdx.x;
+                k[u] = 0xffffffffu; c[u] = 0; z[u] = 0; iv[u] = 0;
+                if (r < r_hi) load(r, k[u], c[u], z[u], iv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < HALF; ++u) {
+                if (k[u] == 0xffffffffu) continue;
+                const uint32_t rank = account(k[u], c[u], z[u], iv[u], true);
+                kr[h * HALF + u] = k[u] | (rank << 8);
+                cc[h * HALF + u] = c[u] & 0xffffffu;
+            }
+        }
+    } else {
+        for (uint32_t r = r_lo + threadIdx.x; r < r_hi; r += C_THREADS) {
+            uint32_t k, c;
+            double z, iv;
+            load(r, k, c, z, iv);
+            account(k, c, z, iv, false);
         }
     }
     __syncthreads();
@@ -396,49 +499,52 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
     }
     __syncthreads();
 
-    // ---- medians, in batches of cells whose colours fit the LDS buffer ----
-    int c_begin = 0;
-    while (c_begin < TCELLS) {
-        const uint32_t base = L.off[2 * c_begin];
-        int c_end = c_begin + 1;
-        const bool huge = L.off[2 * c_begin + 2] - base > RGB_CAP;
-        if (!huge)
-            while (c_end < TCELLS && L.off[2 * c_end + 2] - base <= RGB_CAP) ++c_end;
-        if (huge) {
-            big_cell_medians<I64>(L, a, s_rgb, false, c_begin, base, r_lo, r_hi);
-        } else {
-            const uint32_t n_batch = L.off[2 * c_end] - base;
-            if (n_batch) {
-                for (int k = 2 * c_begin + threadIdx.x; k < 2 * c_end; k += C_THREADS) L.cur[k] = L.off[k] - base;
-                __syncthreads();
-                const bool all = (c_begin == 0 && c_end == TCELLS);
-                for (uint32_t r = r_lo + threadIdx.x; r < r_hi; r += C_THREADS) {
-                    const uint32_t *w = rec_words<I64>(a, r);
-                    const uint32_t k = w[REC_FK<I64>()];
-                    if (all || ((int)(k >> 1) >= c_begin && (int)(k >> 1) < c_end))
-                        s_rgb[atomicAdd(&L.cur[k], 1u)] = w[REC_C<I64>()] & 0xffffffu;
-                }
-                __syncthreads();
-                for (int cell = c_begin + wave; cell < c_end; cell += C_THREADS / 64) {
-                    const uint32_t n_p = L.cnt[2 * cell], n_f = L.cnt[2 * cell + 1], n = n_p + n_f;
-                    if (n == 0 || n > 64) continue;
-                    const uint32_t v = (uint32_t)lane < n ? s_rgb[L.off[2 * cell] - base + lane] : 0u;
-                    uint32_t m[3][3];
-                    cell_medians_64(v, n_p, n_f, m);
-                    if (lane == 0) {
+    // ---- medians ----
+    if (fits) {
 #pragma unroll
-                        for (int s3 = 0; s3 < 3; ++s3)
-#pragma unroll
-                            for (int ch = 0; ch < 3; ++ch) L.med2[s3][cell][ch] = m[s3][ch];
-                    }
-                }
-                __syncthreads();
-                for (int cell = c_begin; cell < c_end; ++cell)
-                    if (L.cnt[2 * cell] + L.cnt[2 * cell + 1] > 64) big_cell_medians<I64>(L, a, s_rgb, true, cell, base, r_lo, r_hi);
-            }
-        }
+        for (int u = 0; u < RPT; ++u)
+            if (kr[u] != 0xffffffffu) s_rgb[L.off[kr[u] & 127u] + (kr[u] >> 8)] = cc[u];
         __syncthreads();
-        c_begin = c_end;
+        small_cells_bitplanes(L, s_rgb, 0, 0, TCELLS);
+        __syncthreads();
+        small_cells_select(L, 0, TCELLS);
+        for (int cell = 0; cell < TCELLS; ++cell)
+            if (L.cnt[2 * cell] + L.cnt[2 * cell + 1] > 64) big_cell_medians<I64>(L, a, s_rgb, true, cell, 0, r_lo, r_hi);
+        __syncthreads();
+    } else {
+        // tiles too large for the LDS buffer: batches of cells whose colours fit, re-reading the tile's records
+        int c_begin = 0;
+        while (c_begin < TCELLS) {
+            const uint32_t base = L.off[2 * c_begin];
+            int c_end = c_begin + 1;
+            const bool huge = L.off[2 * c_begin + 2] - base > RGB_CAP;
+            if (!huge)
+                while (c_end < TCELLS && L.off[2 * c_end + 2] - base <= RGB_CAP) ++c_end;
+            if (huge) {
+                big_cell_medians<I64>(L, a, s_rgb, false, c_begin, base, r_lo, r_hi);
+            } else {
+                const uint32_t n_batch = L.off[2 * c_end] - base;
+                if (n_batch) {
+                    for (int k = 2 * c_begin + threadIdx.x; k < 2 * c_end; k += C_THREADS) L.cur[k] = L.off[k] - base;
+                    __syncthreads();
+                    for (uint32_t r = r_lo + threadIdx.x; r < r_hi; r += C_THREADS) {
+                        const uint32_t *w = rec_words<I64>(a, r);
+                        const uint32_t k = w[REC_FK<I64>()];
+                        if ((int)(k >> 1) >= c_begin && (int)(k >> 1) < c_end)
+                            s_rgb[atomicAdd(&L.cur[k], 1u)] = w[REC_C<I64>()] & 0xffffffu;
+                    }
+                    __syncthreads();
+                    small_cells_bitplanes(L, s_rgb, base, c_begin, c_end);
+                    __syncthreads();
+                    small_cells_select(L, c_begin, c_end);
+                    for (int cell = c_begin; cell < c_end; ++cell)
+                        if (L.cnt[2 * cell] + L.cnt[2 * cell + 1] > 64)
+                            big_cell_medians<I64>(L, a, s_rgb, true, cell, base, r_lo, r_hi);
+                }
+            }
+            __syncthreads();
+            c_begin = c_end;
+        }
     }
 
     // ---- closed-form maps: thread -> (set, cell) ----
