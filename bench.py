@@ -111,7 +111,7 @@ def cpu_baseline(steps=20):
             lo += int(np.sum(sizes[:ev]))
             sizes = sizes[ev:]
         if do_bev:
-            d = hl.incremental_path_dists(track.seg_dists)
+            d = hl.incremental_path_dists(track.seg_array())
             idx = int(((d - BEV_HORIZON_M) > 0).argmax())
             origin = np.array(track.poses[idx])
             ego = np.array(track.poses[:idx]) - origin
@@ -240,6 +240,23 @@ def main():
         step(bev_buf, k)
     prof = ctx.profile_read()
     ctx.profile(False)
+
+    # ---- K1 alone, batched: 64 frames (7.68 M points) per launch -- the shape in which the fused
+    #      project+sample+filter kernel is throughput- rather than launch-latency-bound ----
+    from pca_amd.device_store import DeviceStore
+    k1_batch = 64
+    tmp = DeviceStore(capacity=k1_batch * N_PTS, max_frames=k1_batch + 1)
+    frames = [dict(pts=pool[k % POOL][1], rgb=pool[k % POOL][0], sem=pool[k % POOL][2]) for k in range(k1_batch)]
+    tmp.append_kitti(frames, P_VELO_FRAME, IMG_H, IMG_W, FILTERS)           # warm-up
+    torch.cuda.synchronize()
+    ctx.profile(True)
+    for _ in range(5):
+        tmp.clear()
+        tmp.append_kitti(frames, P_VELO_FRAME, IMG_H, IMG_W, FILTERS)
+    k1b = ctx.profile_read()['kitti_project_sample_filter']
+    ctx.profile(False)
+    k1b_kept = int(tmp.offsets()[-1])
+    del tmp
     builtins.print = real_print
 
     if rank != 0:
@@ -276,6 +293,12 @@ def main():
                             'GBps': alg[k] / (units[k] * 1e-6) / 1e9,
                             'frac': alg[k] / (units[k] * 1e-6) / 1e9 / HBM_PEAK_GBS} for k in units},
                 'kernels': kern}
+    k1b_us = 1e3 * k1b[0] / k1b[1]
+    k1b_bytes = 16.0 * N_PTS * k1_batch + 4.0 * (k1b_kept * 19.0 / 14.0 / 0.99) + 40.0 * k1b_kept
+    roofline['k1_batched'] = {'frames_per_launch': k1_batch, 'points_per_launch': N_PTS * k1_batch, 'kept': k1b_kept,
+                              'avg_launch_us': k1b_us, 'alg_bytes': k1b_bytes, 'GBps': k1b_bytes / (k1b_us * 1e-6) / 1e9,
+                              'frac': k1b_bytes / (k1b_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              'Mpoints_per_s': N_PTS * k1_batch / k1b_us}
 
     out = {
         'metric': 'Mpoints/s projected+accumulated and BEV frames/s @256x256; 1/2/4/8 GPU',

@@ -32,6 +32,7 @@ class DeviceStore:
         self.lb_head = 0         # lower bound of frame_off[head] (exact after a sync)
         self._ub = []            # per live frame: upper bound of its size (its input point count)
         self._pending = None     # (T 4x4, end slot): a re-transform owed to slots [head, end slot)
+        self._k1_cache = None
         self._ws = None
         self._planes16 = {}
         self._planes64 = {}
@@ -40,6 +41,7 @@ class DeviceStore:
     def _alloc(self, cap):
         d = self.device
         self.capacity = cap
+        self._cstore = None
         self.x = torch.empty(cap, dtype=torch.float64, device=d)
         self.y = torch.empty(cap, dtype=torch.float64, device=d)
         self.z = torch.empty(cap, dtype=torch.float64, device=d)
@@ -52,8 +54,10 @@ class DeviceStore:
         return (self.x, self.y, self.z, self.intensity, self.rgbs, self.inst, self.dyn)
 
     def c_store(self):
-        return PcaStore(self.x.data_ptr(), self.y.data_ptr(), self.z.data_ptr(), self.intensity.data_ptr(),
-                        self.rgbs.data_ptr(), self.inst.data_ptr(), self.dyn.data_ptr(), self.capacity)
+        if self._cstore is None:
+            self._cstore = PcaStore(self.x.data_ptr(), self.y.data_ptr(), self.z.data_ptr(), self.intensity.data_ptr(),
+                                    self.rgbs.data_ptr(), self.inst.data_ptr(), self.dyn.data_ptr(), self.capacity)
+        return self._cstore
 
     @property
     def n_frames(self):
@@ -140,9 +144,13 @@ class DeviceStore:
             descs[k].tile0 = tile0
             tile0 += lib.pca_kitti_tiles(n)
         st = self.c_store()
-        Pc = _lib.f64_array(P, 12)
+        key = (id(P), id(filters))
+        if self._k1_cache is None or self._k1_cache[0] != key:
+            # the accumulator passes the same calibration / filter objects every frame
+            self._k1_cache = (key, _lib.f64_array(P, 12), _lib.class_mask(filters), P, filters)
+        Pc, fmask = self._k1_cache[1], self._k1_cache[2]
         ctx.check(lib.pca_kitti_project_sample_filter(ctx.h, descs, len(frames), Pc, int(H), int(W),
-                                                      _lib.class_mask(filters), C.byref(st),
+                                                      fmask, C.byref(st),
                                                       self.frame_off.data_ptr(), self.tail, ctx.stream()))
         self.tail += len(frames)
         self.ub_tail += n_in

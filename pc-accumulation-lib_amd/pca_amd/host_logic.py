@@ -54,7 +54,18 @@ class PoseTrack:
 
     def __init__(self):
         self._P = np.zeros((0, 3))
-        self.seg_dists = []
+        self._D = np.zeros(0)            # segment distances between consecutive poses
+
+    @property
+    def seg_dists(self):
+        return self._D.tolist()
+
+    @seg_dists.setter
+    def seg_dists(self, value):
+        self._D = np.array(value, dtype=np.float64).reshape(-1)
+
+    def seg_array(self):
+        return self._D
 
     @property
     def poses(self):
@@ -85,18 +96,18 @@ class PoseTrack:
 
     def push_segment(self):
         """Appends the distance between the two newest poses; returns the total path length."""
-        self.seg_dists.append(pose_dist(self._P[-1], self._P[-2]))
-        return np.sum(self.seg_dists)
+        self._D = np.append(self._D, pose_dist(self._P[-1], self._P[-2]))
+        return np.sum(self._D)
 
     def evict_beyond(self, horizon_dist, path_length):
         """Number of oldest frames to drop so that the remaining path fits the horizon (0 if it fits)."""
         if not path_length > horizon_dist:
             return 0
-        incr = incremental_path_dists(self.seg_dists)
+        incr = incremental_path_dists(self._D)
         incr -= path_length - horizon_dist
         k = int((incr > 0.).argmax())
         self._P = self._P[k:]
-        self.seg_dists = self.seg_dists[k:]
+        self._D = self._D[k:]
         return k
 
 

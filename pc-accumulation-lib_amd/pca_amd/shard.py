@@ -74,7 +74,7 @@ def sample_frames(positions, accum_horizon, bev_horizon, min_spacing):
         previous_idx -= removed
         if len(track) < 2:
             continue
-        d = hl.incremental_path_dists(track.seg_dists)
+        d = hl.incremental_path_dists(track.seg_array())
         if d[-1] < bev_horizon:
             continue
         present_idx = int(((d - bev_horizon) > 0).argmax())

@@ -116,7 +116,7 @@ class SemanticPointCloudAccumulator:
         return self.seg_dists
 
     def get_incremental_path_dists(self) -> np.array:
-        return hl.incremental_path_dists(np.array(self.seg_dists))
+        return hl.incremental_path_dists(self._track.seg_array())
 
     def get_pose(self, idx: int = None) -> np.array:
         return self._track.as_array() if idx is None else self._track.pose(idx)
