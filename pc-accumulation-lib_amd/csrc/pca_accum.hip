@@ -3,10 +3,32 @@
 //   K2  retransform                      K3  mark_dynamic
 // All are HBM-bound streaming kernels (no MFMA: the only contractions are 3x4 / 4x4 per point).
 #include "pca_common.h"
+#include <cstdlib>
 
-#define TILE_PTS 1024      // points per tile
-#define BLK 256            // threads per workgroup (4 waves)
-#define PPT 4              // points per thread; point (k, t) of a tile is tile*1024 + k*256 + t
+// Compaction tiles: 4096 points per workgroup of 1024 threads.  Large tiles keep the number of tiles in flight
+// (= the distance the decoupled look-back has to walk when all workgroups run in lock step) small and
+// amortise ticket / look-back / barrier costs over more points.
+#define PPT 4              // points per thread; point (k, t) of a tile is tile*TILE + k*BLK + t
+#define K1_DEFAULT_BLK 512 // threads per compaction workgroup (tile = 4 * BLK points); PCA_K1_BLK overrides (tuning)
+#define SBLK 256           // workgroup size of the plain streaming kernels (K0n, K2, K3)
+
+// loads through the global address space (pointers that arrive inside structs are generic to the compiler)
+template <typename T>
+__device__ __forceinline__ T ldg(const T *p)
+{
+    return *reinterpret_cast<const __attribute__((address_space(1))) T *>(reinterpret_cast<uintptr_t>(p));
+}
+struct __attribute__((packed)) U32u { uint32_t v; };
+__device__ __forceinline__ uint32_t ldg_u32_unaligned(const uint8_t *p)     // one global_load_dword at any byte address
+{
+    return reinterpret_cast<const __attribute__((address_space(1))) U32u *>(reinterpret_cast<uintptr_t>(p))->v;
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg4(const float *p)      // one 16-byte global load
+{
+    const f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(reinterpret_cast<uintptr_t>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Stable block-level compaction: given keep[k] for the PPT points of each thread (point order =
@@ -19,6 +41,7 @@ struct TileScan {
     uint64_t excl;         // kept points of all earlier tiles of the launch
 };
 
+template <int BLK>
 __device__ __forceinline__ TileScan tile_compact(const bool keep[PPT], uint64_t *state, int tile, uint32_t epoch)
 {
     __shared__ uint32_t s_wtot[PPT][BLK / PCA_WAVE];
@@ -79,21 +102,47 @@ struct K1Args {
     uint64_t *state;
     uint32_t *ticket;   // [0] ticket, [1] status
     uint32_t epoch;
+    unsigned long long *dbg;   // diagnostic stamps (PCA_K1_STAMPS=1), else nullptr
 };
 
+#define K1_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
+// velo2frame + velo2img of one point: pixel index v*W+u, or -1 if outside the frustum (sem_pc_accum.py:347-394)
+__device__ __forceinline__ int project_pixel(const Mat34 &P, float xf, float yf, float zf, int W, int H)
+{
+    const double x = (double)xf, y = (double)yf, z = (double)zf;
+    const double fx = row4(P.m + 0, x, y, z);
+    const double fy = row4(P.m + 4, x, y, z);
+    double d = row4(P.m + 8, x, y, z);
+    if (d == 0.0) d = -1e-6;
+    const double ad = fabs(d);
+    const double uf = rint(fx / ad);
+    const double vf = rint(fy / ad);
+    const bool ok = (uf >= 0.0) && (uf < (double)W) && (vf >= 0.0) && (vf < (double)H) && (d > 0.0) && (d < __builtin_huge_val());
+    return ok ? (int)vf * W + (int)uf : -1;
+}
+
+template <int BLK>
 __global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a)
 {
+    constexpr int TILE_PTS = PPT * BLK;
+    K1_STAMP(0);
     const int tile = draw_tile(a.ticket, a.total_tiles);
-    // frame of this tile (wave-uniform scalar search; batches are at most a few hundred frames)
+    K1_STAMP(1);
+    // frame of this tile: one lane-parallel probe per 64 frames (tile0 is ascending), a single memory round trip
+    // instead of a chain of dependent binary-search loads
     int f = 0;
     pca_kitti_frame fr = a.one;
     if (a.frames) {
-        int lo = 0, hi = a.n_frames - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (a.frames[mid].tile0 <= tile) lo = mid; else hi = mid - 1;
+        const int lane = threadIdx.x & 63;
+        int below = 0;
+        for (int f0 = 0; f0 < a.n_frames; f0 += 64) {
+            const bool le = (f0 + lane < a.n_frames) && (ldg(&a.frames[f0 + lane].tile0) <= tile);
+            const int c = (int)__popcll(__ballot(le));
+            below += c;
+            if (c < 64) break;
         }
-        f = lo;
+        f = below - 1;
         fr = a.frames[f];
     }
     const int tin = tile - fr.tile0;                       // tile index inside the frame
@@ -103,45 +152,61 @@ __global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a)
     bool keep[PPT];
     float4 q[PPT];
     uint32_t packed[PPT];
-    const float4 *pts = reinterpret_cast<const float4 *>(fr.pts);
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int64_t p = base_pt + k * BLK + threadIdx.x;
         keep[k] = false;
         packed[k] = 0;
         q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < fr.n) q[k] = pts[p];                       // 16 B / lane, fully coalesced
+        if (p < fr.n) q[k] = ldg4(fr.pts + 4 * p);         // 16 B / lane, fully coalesced
     }
+    K1_STAMP(2);
+    if (fr.n > 0 && fr.sem_gt) {                           // use_gt_sem: no projection, rgb = 0
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int64_t p = base_pt + k * BLK + threadIdx.x;
-        if (p >= fr.n) continue;
-        if (fr.sem_gt) {                                   // use_gt_sem: no projection, rgb = 0
-            const unsigned c = fr.sem_gt[p];
+        for (int k = 0; k < PPT; ++k) {
+            const int64_t p = base_pt + k * BLK + threadIdx.x;
+            if (p >= fr.n) continue;
+            const unsigned c = ldg(fr.sem_gt + p);
             keep[k] = !in_mask(a.filt, c);
             packed[k] = (uint32_t)c << 24;
-            continue;
         }
-        const double x = (double)q[k].x, y = (double)q[k].y, z = (double)q[k].z;
-        const double fx = row4(a.P.m + 0, x, y, z);
-        const double fy = row4(a.P.m + 4, x, y, z);
-        double d = row4(a.P.m + 8, x, y, z);
-        if (d == 0.0) d = -1e-6;
-        const double ad = fabs(d);
-        const double uf = rint(fx / ad);
-        const double vf = rint(fy / ad);
-        const bool ok = (uf >= 0.0) && (uf < (double)a.W) && (vf >= 0.0) && (vf < (double)a.H) && (d > 0.0) &&
-                        (d < __builtin_huge_val());
-        if (!ok) continue;
-        const int64_t pix = (int64_t)(int)vf * a.W + (int)uf;
-        const unsigned c = fr.sem[pix];
-        if (in_mask(a.filt, c)) continue;
-        const uint8_t *px = fr.rgb + pix * 3;
-        packed[k] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)c << 24);
-        keep[k] = true;
+    } else if (fr.n > 0) {
+        // straight-line, predicated: all projections, then all gathers (independent loads in flight), then the filter
+        bool ok[PPT];
+        int64_t pix[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int64_t p = base_pt + k * BLK + threadIdx.x;
+            const int px = project_pixel(a.P, q[k].x, q[k].y, q[k].z, a.W, a.H);
+            ok[k] = (p < fr.n) && px >= 0;
+            pix[k] = ok[k] ? px : 0;                                     // pixel 0 is always a valid address
+        }
+        // two gathers per point: the class byte and ONE unaligned dword holding r,g,b (address-divergent loads
+        // cost the texture addresser a pass per distinct line, so their number matters more than their bytes)
+        unsigned c[PPT], rgb[PPT];
+        const int64_t last = (int64_t)a.H * a.W * 3 - 4;   // last legal 4-byte window of the image
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            c[k] = ldg(fr.sem + pix[k]);
+            int64_t off = pix[k] * 3;
+            if (last >= 0) {
+                const int sh = off > last ? (int)(off - last) * 8 : 0;
+                off = off > last ? last : off;
+                rgb[k] = (ldg_u32_unaligned(fr.rgb + off) >> sh) & 0xffffffu;
+            } else {                                        // image smaller than four bytes
+                rgb[k] = (uint32_t)ldg(fr.rgb + off) | ((uint32_t)ldg(fr.rgb + off + 1) << 8) | ((uint32_t)ldg(fr.rgb + off + 2) << 16);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            keep[k] = ok[k] && !in_mask(a.filt, c[k]);
+            packed[k] = rgb[k] | (c[k] << 24);
+        }
     }
 
-    const TileScan sc = tile_compact(keep, a.state, tile, a.epoch);
+    K1_STAMP(3);
+    const TileScan sc = tile_compact<BLK>(keep, a.state, tile, a.epoch);
+    K1_STAMP(4);
     const int64_t origin = a.frame_off[a.first_slot];      // written by an earlier launch (stream order)
     const int64_t tile_base = origin + (int64_t)sc.excl;
     bool overflow = false;
@@ -161,6 +226,8 @@ __global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a)
     if (overflow) atomicOr(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
     if (threadIdx.x == 0 && tin == ftiles - 1)             // last tile of the frame closes its segment
         a.frame_off[a.first_slot + f + 1] = tile_base + sc.total;
+    K1_STAMP(5);
+    if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)tile;
 }
 
 // =============================================================================================
@@ -183,8 +250,10 @@ struct K1nArgs {
     uint32_t epoch;
 };
 
+template <int BLK>
 __global__ __launch_bounds__(BLK) void k1n_nusc(const K1nArgs a)
 {
+    constexpr int TILE_PTS = PPT * BLK;
     const int tile = draw_tile(a.ticket, a.total_tiles);
     const int64_t base_pt = (int64_t)tile * TILE_PTS;
     bool keep[PPT];
@@ -210,7 +279,7 @@ __global__ __launch_bounds__(BLK) void k1n_nusc(const K1nArgs a)
     }
     if (bad_uv) atomicOr(a.ticket + 1, PCA_STATUS_UV_OUT_OF_IMAGE);
 
-    const TileScan sc = tile_compact(keep, a.state, tile, a.epoch);
+    const TileScan sc = tile_compact<BLK>(keep, a.state, tile, a.epoch);
     const int64_t tile_base = a.frame_off[a.slot] + (int64_t)sc.excl;
     bool overflow = false;
 #pragma unroll
@@ -249,9 +318,9 @@ struct K0nArgs {
     int64_t *cam_idx;   // [n]
 };
 
-__global__ __launch_bounds__(BLK) void k0n_project(const K0nArgs a)
+__global__ __launch_bounds__(SBLK) void k0n_project(const K0nArgs a)
 {
-    for (int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x; p < a.n; p += (int64_t)gridDim.x * BLK) {
+    for (int64_t p = (int64_t)blockIdx.x * SBLK + threadIdx.x; p < a.n; p += (int64_t)gridDim.x * SBLK) {
         const double x = a.pc[3 * p], y = a.pc[3 * p + 1], z = a.pc[3 * p + 2];
         const double ex = row4(a.T_ego_from_lidar.m + 0, x, y, z);
         const double ey = row4(a.T_ego_from_lidar.m + 4, x, y, z);
@@ -300,12 +369,12 @@ __device__ __forceinline__ void apply_chain(const K2Args &a, double &x, double &
     }
 }
 
-__global__ __launch_bounds__(BLK) void k2_retransform(const K2Args a)
+__global__ __launch_bounds__(SBLK) void k2_retransform(const K2Args a)
 {
     const int64_t lo = a.frame_off[a.slot_begin], hi = a.frame_off[a.slot_end];
     // 16-byte vector body over even-aligned pairs, scalar head/tail
     const int64_t lo2 = (lo + 1) & ~1ll, hi2 = hi & ~1ll;
-    const int64_t gtid = (int64_t)blockIdx.x * BLK + threadIdx.x, gsz = (int64_t)gridDim.x * BLK;
+    const int64_t gtid = (int64_t)blockIdx.x * SBLK + threadIdx.x, gsz = (int64_t)gridDim.x * SBLK;
     if (gtid == 0) {
         if (lo < lo2 && lo < hi) { double x = a.x[lo], y = a.y[lo], z = a.z[lo]; apply_chain(a, x, y, z); a.x[lo] = x; a.y[lo] = y; a.z[lo] = z; }
         if (hi2 < hi && hi2 >= lo2) { double x = a.x[hi2], y = a.y[hi2], z = a.z[hi2]; apply_chain(a, x, y, z); a.x[hi2] = x; a.y[hi2] = y; a.z[hi2] = z; }
@@ -333,12 +402,12 @@ struct K3Args {
     int32_t inst_idx[MAX_PAIRS];
 };
 
-__global__ __launch_bounds__(BLK) void k3_mark_dynamic(const K3Args a)
+__global__ __launch_bounds__(SBLK) void k3_mark_dynamic(const K3Args a)
 {
     const int pr = blockIdx.y;
     const int64_t lo = a.frame_off[a.slot[pr]], hi = a.frame_off[a.slot[pr] + 1];
     const int32_t want = a.inst_idx[pr];
-    for (int64_t p = lo + (int64_t)blockIdx.x * BLK + threadIdx.x; p < hi; p += (int64_t)gridDim.x * BLK)
+    for (int64_t p = lo + (int64_t)blockIdx.x * SBLK + threadIdx.x; p < hi; p += (int64_t)gridDim.x * SBLK)
         if (a.inst[p] == want) a.dyn[p] = 1;
 }
 
@@ -347,8 +416,28 @@ __global__ __launch_bounds__(BLK) void k3_mark_dynamic(const K3Args a)
 // =============================================================================================
 extern "C" {
 
-int pca_kitti_tile_points(void) { return TILE_PTS; }
-int pca_kitti_tiles(int32_t n) { return n > 0 ? (n + TILE_PTS - 1) / TILE_PTS : 1; }
+static int k1_blk()
+{
+    static int blk = 0;
+    if (!blk) {
+        const char *e = getenv("PCA_K1_BLK");
+        const int v = e ? atoi(e) : K1_DEFAULT_BLK;
+        blk = (v == 256 || v == 512 || v == 1024) ? v : K1_DEFAULT_BLK;
+    }
+    return blk;
+}
+
+// diagnostic: copies the stamps of the last K1 launch (8 words per workgroup) to `out`; returns the workgroup count
+int pca_debug_k1_stamps(pca_ctx *ctx, unsigned long long *out, int max_blocks)
+{
+    if (!ctx || !ctx->dbg) return 0;
+    const int n = ctx->dbg_blocks < max_blocks ? ctx->dbg_blocks : max_blocks;
+    if (hipMemcpy(out, ctx->dbg, sizeof(unsigned long long) * 8 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+
+int pca_kitti_tile_points(void) { return PPT * k1_blk(); }
+int pca_kitti_tiles(int32_t n) { const int t = PPT * k1_blk(); return n > 0 ? (n + t - 1) / t : 1; }
 
 int pca_kitti_project_sample_filter(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames, const double P[12],
                                     int H, int W, const uint64_t filter_mask[4], const pca_store *store,
@@ -392,7 +481,17 @@ int pca_kitti_project_sample_filter(pca_ctx *ctx, const pca_kitti_frame *frames,
     a.state = ctx->tile_state;
     a.ticket = ctx->ticket;
     a.epoch = pca_ctx_next_epoch(ctx, s);
-    PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti, dim3(total), dim3(BLK), s, a);
+    a.dbg = nullptr;
+    if (getenv("PCA_K1_STAMPS")) {
+        if (!ctx->dbg) { PCA_CHECK(ctx, hipMalloc(&ctx->dbg, sizeof(unsigned long long) * 8 * 65536)); }
+        if (total <= 65536) a.dbg = ctx->dbg;
+        ctx->dbg_blocks = total;
+    }
+    switch (k1_blk()) {
+        case 256: PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti<256>, dim3(total), dim3(256), s, a); break;
+        case 1024: PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti<1024>, dim3(total), dim3(1024), s, a); break;
+        default: PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti<512>, dim3(total), dim3(512), s, a); break;
+    }
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }
@@ -416,7 +515,11 @@ int pca_nusc_sample_filter_transform(pca_ctx *ctx, const double *pc, const int64
     a.st = *store; a.frame_off = frame_off; a.slot = slot;
     a.state = ctx->tile_state; a.ticket = ctx->ticket;
     a.epoch = pca_ctx_next_epoch(ctx, s);
-    PCA_LAUNCH(ctx, PCA_K_NUSC, k1n_nusc, dim3(total), dim3(BLK), s, a);
+    switch (k1_blk()) {
+        case 256: PCA_LAUNCH(ctx, PCA_K_NUSC, k1n_nusc<256>, dim3(total), dim3(256), s, a); break;
+        case 1024: PCA_LAUNCH(ctx, PCA_K_NUSC, k1n_nusc<1024>, dim3(total), dim3(1024), s, a); break;
+        default: PCA_LAUNCH(ctx, PCA_K_NUSC, k1n_nusc<512>, dim3(total), dim3(512), s, a); break;
+    }
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }
@@ -439,8 +542,8 @@ int pca_nusc_project_cams(pca_ctx *ctx, const double *pc_lidar, int32_t n, const
         a.wh[j][0] = wh[2 * j]; a.wh[j][1] = wh[2 * j + 1];
     }
     a.pc_in_ego = pc_in_ego; a.uv = uv; a.cam_idx = cam_idx;
-    const int grid = (n + BLK - 1) / BLK < 2048 ? (n + BLK - 1) / BLK : 2048;
-    PCA_LAUNCH(ctx, PCA_K_PROJECT_CAMS, k0n_project, dim3(grid), dim3(BLK), s, a);
+    const int grid = (n + SBLK - 1) / SBLK < 2048 ? (n + SBLK - 1) / SBLK : 2048;
+    PCA_LAUNCH(ctx, PCA_K_PROJECT_CAMS, k0n_project, dim3(grid), dim3(SBLK), s, a);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }
@@ -460,7 +563,7 @@ int pca_retransform(pca_ctx *ctx, const pca_store *store, const int64_t *frame_o
         a.n_T = (n_T - t0) < MAX_CHAIN ? (n_T - t0) : MAX_CHAIN;
         for (int t = 0; t < a.n_T; ++t)
             for (int i = 0; i < 12; ++i) a.T[t].m[i] = Ts[(int64_t)(t0 + t) * 16 + i];
-        PCA_LAUNCH(ctx, PCA_K_RETRANSFORM, k2_retransform, dim3(2048), dim3(BLK), s, a);
+        PCA_LAUNCH(ctx, PCA_K_RETRANSFORM, k2_retransform, dim3(2048), dim3(SBLK), s, a);
         PCA_CHECK(ctx, hipGetLastError());
     }
     return 0;
@@ -478,7 +581,7 @@ int pca_mark_dynamic(pca_ctx *ctx, const pca_store *store, const int64_t *frame_
         a.inst = store->inst; a.dyn = store->dyn; a.frame_off = frame_off;
         a.n_pairs = (n_pairs - p0) < MAX_PAIRS ? (n_pairs - p0) : MAX_PAIRS;
         for (int i = 0; i < a.n_pairs; ++i) { a.slot[i] = slots[p0 + i]; a.inst_idx[i] = inst_idx[p0 + i]; }
-        PCA_LAUNCH(ctx, PCA_K_MARK_DYNAMIC, k3_mark_dynamic, dim3(64, a.n_pairs), dim3(BLK), s, a);
+        PCA_LAUNCH(ctx, PCA_K_MARK_DYNAMIC, k3_mark_dynamic, dim3(64, a.n_pairs), dim3(SBLK), s, a);
         PCA_CHECK(ctx, hipGetLastError());
     }
     return 0;

@@ -23,6 +23,8 @@ struct pca_ctx {
     pca_kitti_frame *frames_dev = nullptr;
     int frames_cap = 0;
     uint32_t *status_host = nullptr;  // pinned
+    unsigned long long *dbg = nullptr; // diagnostic stamps of the last K1 launch (PCA_K1_STAMPS)
+    int dbg_blocks = 0;
     // optional per-kernel event timing
     struct Ev { hipEvent_t a, b; int kid; };
     bool profiling = false;
@@ -137,31 +139,43 @@ __device__ __forceinline__ uint64_t lb_exclusive_prefix(uint64_t *state, int til
     if (lane == 0) lb_store(&state[tile], lb_pack(LB_FLAG_AGG, epoch, aggregate));
     uint64_t excl = 0;
     int hi = tile - 1;                      // newest predecessor of the current window
-    while (true) {
-        const int idx = hi - lane;          // lane 0 looks at the closest predecessor
-        uint64_t w = 0;
-        bool valid = true, pfx = false;
-        if (idx >= 0) {
-            w = lb_load(&state[idx]);
-            const uint64_t flag = w >> 62;
-            const bool mine = (uint32_t)((w >> 40) & 0x3fffffu) == (epoch & 0x3fffffu);
-            valid = mine && flag != 0;
-            pfx = valid && flag == LB_FLAG_PFX;
+    // LB_W windows of 64 predecessors are fetched per round trip (independent loads), then consumed in order:
+    // when all workgroups run in lock step the walk is as long as the number of tiles in flight.
+    constexpr int LB_W = 4;
+    bool done = false;
+    while (!done) {
+        uint64_t w[LB_W];
+#pragma unroll
+        for (int j = 0; j < LB_W; ++j) {
+            const int idx = hi - 64 * j - lane;
+            w[j] = idx >= 0 ? lb_load(&state[idx]) : 0;
         }
-        const uint64_t pfx_mask = __ballot(pfx);
-        const uint64_t inv_mask = __ballot(!valid);
-        // lanes below the first prefix (or all 64) must be valid before the window can be consumed
-        const int first_pfx = pfx_mask ? (int)__ffsll((unsigned long long)pfx_mask) - 1 : 64;
-        const uint64_t need = (first_pfx >= 64) ? ~0ull : ((1ull << first_pfx) - 1) | (1ull << first_pfx);
-        if (inv_mask & need) {              // somebody has not published yet: poll again
-            __builtin_amdgcn_s_sleep(1);
-            continue;
+#pragma unroll
+        for (int j = 0; j < LB_W; ++j) {
+            if (done) continue;
+            const int idx = hi - lane;      // lane 0 looks at the closest predecessor of this window
+            bool valid = true, pfx = false;
+            if (idx >= 0) {
+                const uint64_t flag = w[j] >> 62;
+                const bool mine = (uint32_t)((w[j] >> 40) & 0x3fffffu) == (epoch & 0x3fffffu);
+                valid = mine && flag != 0;
+                pfx = valid && flag == LB_FLAG_PFX;
+            }
+            const uint64_t pfx_mask = __ballot(pfx);
+            const uint64_t inv_mask = __ballot(!valid);
+            // lanes up to the first prefix (or all 64) must be valid before the window can be consumed
+            const int first_pfx = pfx_mask ? (int)__ffsll((unsigned long long)pfx_mask) - 1 : 64;
+            const uint64_t need = (first_pfx >= 63) ? ~0ull : ((2ull << first_pfx) - 1ull);
+            if (inv_mask & need) {          // somebody has not published yet: fetch again from this window on
+                __builtin_amdgcn_s_sleep(1);
+                break;
+            }
+            uint64_t v = (idx >= 0 && lane <= first_pfx) ? (w[j] & LB_VAL_MASK) : 0;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            excl += v;
+            if (first_pfx < 64 || hi - 64 < 0) done = true;
+            else hi -= 64;
         }
-        uint64_t v = (idx >= 0 && lane <= first_pfx) ? (w & LB_VAL_MASK) : 0;
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        excl += v;
-        if (first_pfx < 64 || hi - 64 < 0) break;
-        hi -= 64;
     }
     if (lane == 0) lb_store(&state[tile], lb_pack(LB_FLAG_PFX, epoch, excl + aggregate));
     return excl;
