@@ -150,10 +150,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (no CPU fallback)'
-    torch.cuda.set_device(local_rank)
+    # PCA_BENCH_BACKEND=gloo + fewer GPUs than ranks: rehearsal of the multi-rank control flow on a one-GPU box
+    backend = os.environ.get('PCA_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))   # RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     import sem_pc_accum
@@ -208,8 +214,10 @@ def main():
     acc.store.check_status()
     bev_buf = torch.empty((args.steps, 21, PX, PX), dtype=torch.float16, device='cuda')
     gathered = None
+    coll_dev = 'cuda' if backend == 'nccl' else 'cpu'
     if world > 1:
-        gathered = [torch.empty_like(bev_buf) for _ in range(world)] if rank == 0 else None
+        gathered = [torch.empty((args.steps, 21, PX, PX), dtype=torch.float16, device=coll_dev)
+                    for _ in range(world)] if rank == 0 else None
 
     def barrier():
         if world > 1:
@@ -222,13 +230,16 @@ def main():
     for k in range(args.steps):
         step(bev_buf, k)
     if world > 1:                                     # finished BEV tensors -> rank 0 over RCCL / xGMI
-        dist.gather(bev_buf, gathered, dst=0)
+        dist.gather(bev_buf if backend == 'nccl' else bev_buf.cpu(), gathered, dst=0)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        if rank == 0:                                 # every rank's last BEV arrived and is a plausible probability map
+            for g in gathered:
+                assert float(g[-1, 0].float().min()) > 0.0 and float(g[-1, 0].float().max()) < 1.0
     acc.store.check_status()
     stored = int(acc.store.offsets()[-1] - acc.store.offsets()[0])
     n_live = acc.store.n_frames
@@ -240,6 +251,28 @@ def main():
         step(bev_buf, k)
     prof = ctx.profile_read()
     ctx.profile(False)
+
+    # ---- PCIe-inclusive variant of the step (host numpy inputs as the unchanged drivers pass them, BEV dict of
+    #      host fp16 arrays out): reported beside, never as, `value` ----
+    host_pool = [(f[0].cpu().numpy(), f[1].cpu().numpy(), f[2].cpu().numpy()) for f in pool]
+
+    class HostSemSeg:
+        def pred(self, rgb):
+            return host_sem[id(rgb)][None, None]
+    host_sem = {id(h[0]): h[2] for h in host_pool}
+    acc.semseg_model = HostSemSeg()
+    n_host = min(args.steps, 30)
+    torch.cuda.synchronize()
+    th0 = time.perf_counter()
+    for k in range(n_host):
+        rgb_h, pc_h, _ = host_pool[k % POOL]
+        acc.integrate([(rgb_h, pc_h, None)])
+        idx = present_index(acc)
+        bevs = acc.generate_bev(idx, 1, gen_future=True)
+    torch.cuda.synchronize()
+    host_elapsed = time.perf_counter() - th0
+    assert bevs[0]['rgb_full'].shape == (3, PX, PX)
+    acc.semseg_model = model
 
     # ---- K1 alone, batched: 64 frames (7.68 M points) per launch -- the shape in which the fused
     #      project+sample+filter kernel is throughput- rather than launch-latency-bound ----
@@ -319,6 +352,9 @@ def main():
                    'points_per_frame': N_PTS, 'image': [IMG_H, IMG_W], 'bev_px': PX, 'view_m': VIEW_M,
                    'sharding': 'one independent sequence per GPU; BEV tensors gathered to rank 0 (RCCL)'},
         'roofline': roofline,
+        'pcie_inclusive': {'Mpoints_per_s': N_PTS * n_host / host_elapsed / 1e6, 'bev_frames_per_s': n_host / host_elapsed,
+                           'ms_per_step': 1e3 * host_elapsed / n_host, 'steps': n_host,
+                           'note': 'host numpy inputs (4 MB H2D per frame) and host fp16 BEV dict (2.75 MB D2H) per step'},
     }
     if not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()

@@ -156,14 +156,23 @@ class BEVGenerator(ABC):
             return [hl.transform_traj(t, rot_mat, trans_dx, trans_dy, aug_view_size, self.pixel_size)
                     for t in traj_list]
 
-        trajs_present = to_grid([ego_present] + oth_present)
+        split = trajs.get('_ego_split')          # set by the accumulators: the ego polylines are slices of one array
+        if split is not None and pc_future is not None:
+            ego_p, ego_f, ego_a = hl.transform_ego_split(ego_full, split, rot_mat, trans_dx, trans_dy, aug_view_size,
+                                                        self.pixel_size)
+            trajs_present = [ego_p] + to_grid(oth_present)
+            trajs_future = [ego_f] + to_grid(oth_future)
+            trajs_full = [ego_a] + to_grid(oth_full)
+        else:
+            trajs_present = to_grid([ego_present] + oth_present)
         if lanes is not None:
             lanes = [lane for lane in to_grid(lanes) if lane.shape[0] > 0]
         if pc_future is None:
             # the reference only defines the future/full trajectories inside `if pc_future is not None`
             raise UnboundLocalError("local variable 'trajs_future' referenced before assignment")
-        trajs_future = to_grid([ego_future] + oth_future)
-        trajs_full = to_grid([ego_full] + oth_full)
+        if split is None:
+            trajs_future = to_grid([ego_future] + oth_future)
+            trajs_full = to_grid([ego_full] + oth_full)
 
         self._frame = (rot_mat, trans_dx, trans_dy, aug_view_size)
         self._device_only = device_only

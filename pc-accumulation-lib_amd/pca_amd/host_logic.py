@@ -194,6 +194,48 @@ def crop_trajectory(traj, view, thresh=1e-4):
     return out
 
 
+def _crop_edges(traj, view, thresh=1e-4):
+    """Per-edge emission of crop_trajectory: returns (rows (M,3), first output row of every edge (E+1,))."""
+    n = traj.shape[0]
+    if n < 2:
+        return np.zeros((0, 3)), np.zeros(max(n, 1), dtype=np.int64)
+    h = 0.5 * view
+    lo = -h
+    x, y = traj[:, 0], traj[:, 1]
+    inside = (lo < x) & (x < h) & (lo < y) & (y < h)
+    a_in, b_in = inside[:-1], inside[1:]
+    crossing = a_in != b_in
+    per_edge = a_in.astype(np.int64) + crossing.astype(np.int64)
+    start = np.concatenate([[0], np.cumsum(per_edge)])
+    out = np.empty((int(start[-1]), 3))
+    ka = np.nonzero(a_in)[0]
+    out[start[ka]] = traj[ka, :3]
+    bbox = [lo, lo, h, h]
+    for k in np.nonzero(crossing)[0]:
+        ix, iy, _ = bisect_box_crossing(traj[k, 0], traj[k, 1], traj[k + 1, 0], traj[k + 1, 1], bbox, thresh)
+        out[start[k] + (1 if a_in[k] else 0)] = (ix, iy, traj[k, 2])
+    return out, start
+
+
+def transform_ego_split(full, split, rot_mat, dx, dy, view, px):
+    """The three ego trajectories of one sample -- present = full[:split], future = full[split:], full -- in
+    grid coordinates, from ONE rotate / translate / clip / floor pass.  Every step is row- or edge-local, so
+    the slices equal what three separate transform_traj calls return (the present set simply lacks the edge
+    split-1 -> split, the future set starts at edge split)."""
+    t = np.array(full, dtype=np.float64)
+    t[:, :3] = np.matmul(rot_mat, t[:, :3].T).T
+    t[:, 0] += dx
+    t[:, 1] += dy
+    rows, start = _crop_edges(t, view)
+    rows = pos2grid_inplace(rows, view, px)
+    n = t.shape[0]
+    empty = np.zeros((0, 3))
+    e_p = max(split - 1, 0)                                  # edges 0 .. split-2 belong to the present polyline
+    present = rows[:start[e_p]].copy() if split >= 2 else empty
+    future = rows[start[split]:].copy() if n - split >= 2 else empty
+    return present, future, rows
+
+
 def transform_traj(traj, rot_mat, dx, dy, view, px):
     """rotate -> translate -> clip -> grid coordinates, for one (k,3) trajectory.  Mutates `traj` like the
     reference (bev_generator.py:226-231)."""

@@ -211,7 +211,8 @@ class SemanticPointCloudAccumulator:
             raise ValueError('need at least one array to concatenate')     # np.concatenate([]) in the reference
         win = DeviceWindow(self.store, split, origin)
         pcs = {'pc_present': win.part('present')}
-        trajs = {'ego_traj_present': poses[:present_idx] - origin}
+        rel = poses - origin
+        trajs = {'ego_traj_present': rel[:present_idx]}
         others = other_trajs if other_trajs is not None else ([], [], [])
         trajs['other_trajs_present'] = [np.concatenate([t]) - origin for t in others[0]]
         if gt_lanes is not None:
@@ -221,8 +222,9 @@ class SemanticPointCloudAccumulator:
                 raise ValueError('need at least one array to concatenate')
             pcs['pc_future'] = win.part('future')
             pcs['pc_full'] = win.part('full')
-            trajs['ego_traj_future'] = poses[present_idx:] - origin
-            trajs['ego_traj_full'] = poses - origin
+            trajs['ego_traj_future'] = rel[present_idx:]
+            trajs['ego_traj_full'] = rel
+            trajs['_ego_split'] = split
             trajs['other_trajs_future'] = [np.concatenate([t]) - origin for t in others[1]]
             trajs['other_trajs_full'] = [np.concatenate([t]) - origin for t in others[2]]
         else:
@@ -243,8 +245,8 @@ class SemanticPointCloudAccumulator:
         for k, v in trajs.items():
             if isinstance(v, list):
                 out[k] = [np.array(t) for t in v]
-            elif v is None:
-                out[k] = None
+            elif v is None or isinstance(v, int):
+                out[k] = v
             else:
                 out[k] = np.array(v)
         return out

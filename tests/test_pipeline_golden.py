@@ -163,3 +163,21 @@ def test_host_logic_utils(golden):
     assert np.array_equal(np.array([a1, a2, b1, b2]), g['wp_params'])
     assert np.array_equal(hl.warp_dense_probmaps(g['wp_in'], a1, a2, b1, b2), g['wp_out'])
     assert np.array_equal(hl.warp_sparse_points(g['ws_in'].copy(), a1, a2, 13.8, 16, 32), g['ws_out'])
+
+
+def test_ego_split_transform_equals_three_separate_transforms():
+    """The accumulators transform the ego polyline once and slice it; must equal the reference's three calls."""
+    rng = np.random.default_rng(12)
+    for trial in range(200):
+        n = int(rng.integers(2, 60))
+        step = rng.uniform(0.3, 3.0)
+        ang = np.cumsum(rng.normal(0, 0.15, n))
+        pts = np.stack([np.cumsum(step * np.cos(ang)), np.cumsum(step * np.sin(ang)), rng.normal(0, 0.1, n)], 1)
+        pts -= pts[int(rng.integers(0, n))]
+        split = int(rng.integers(1, n))
+        R = hl.rotation_matrix_3d(rng.uniform(0, 6.28))
+        dx, dy, view, px = rng.uniform(-2, 2), rng.uniform(-2, 2), float(rng.choice([10., 20., 51.2])), 64
+        p, f, a = hl.transform_ego_split(pts, split, R, dx, dy, view, px)
+        want = [hl.transform_traj(t.copy(), R, dx, dy, view, px) for t in (pts[:split], pts[split:], pts)]
+        for got, w in zip((p, f, a), want):
+            assert got.shape == w.shape and np.array_equal(got, w), (trial, n, split)
