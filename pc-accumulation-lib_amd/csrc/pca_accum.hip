@@ -42,34 +42,41 @@ struct TileScan {
 };
 
 template <int BLK>
-__device__ __forceinline__ TileScan tile_compact(const bool keep[PPT], uint64_t *state, int tile, uint32_t epoch)
+__device__ __forceinline__ TileScan tile_compact(const bool keep[PPT], uint64_t *state, int tile, uint32_t epoch,
+                                                 bool skip_lookback = false)
 {
-    __shared__ uint32_t s_wtot[PPT][BLK / PCA_WAVE];
+    constexpr int NW = BLK / PCA_WAVE;
+    static_assert(PPT * NW <= 64, "the per-(row, wave) totals are scanned by one wave");
+    __shared__ uint32_t s_wtot[PPT * NW];      // kept points per (row k, wave), k-major = point order
+    __shared__ uint32_t s_woff[PPT * NW + 1];  // exclusive prefix of s_wtot, [PPT*NW] = tile total
     __shared__ uint64_t s_excl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t lane_rank[PPT];
+    TileScan r;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const uint64_t b = __ballot(keep[k]);
-        lane_rank[k] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wtot[k][wave] = (uint32_t)__popcll(b);
+        r.local[k] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wtot[k * NW + wave] = (uint32_t)__popcll(b);
     }
     __syncthreads();
-    TileScan r;
-    uint32_t run = 0;
-#pragma unroll
-    for (int k = 0; k < PPT; ++k)
-#pragma unroll
-        for (int w = 0; w < BLK / PCA_WAVE; ++w) {
-            if (w == wave) r.local[k] = run + lane_rank[k];
-            run += s_wtot[k][w];
-        }
-    r.total = run;
     if (wave == 0) {
-        const uint64_t e = lb_exclusive_prefix(state, tile, (uint64_t)run, epoch);
+        const uint32_t v = lane < PPT * NW ? s_wtot[lane] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane < PPT * NW) s_woff[lane] = inc - v;
+        const uint32_t total = __shfl(inc, 63, 64);
+        if (lane == 0) s_woff[PPT * NW] = total;
+        const uint64_t e = skip_lookback ? 0 : lb_exclusive_prefix(state, tile, (uint64_t)total, epoch);
         if (lane == 0) s_excl = e;
     }
     __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) r.local[k] += s_woff[k * NW + wave];
+    r.total = s_woff[PPT * NW];
     r.excl = s_excl;
     return r;
 }
@@ -102,7 +109,11 @@ struct K1Args {
     uint64_t *state;
     uint32_t *ticket;   // [0] ticket, [1] status
     uint32_t epoch;
+    unsigned long long *ticket64;      // monotonic ticket counter of the persistent kernel
+    unsigned long long ticket_base;    // its value when this launch starts
+    int one_tile_each;                 // grid == total_tiles: no second draw needed
     unsigned long long *dbg;   // diagnostic stamps (PCA_K1_STAMPS=1), else nullptr
+    int dbg_skip;              // diagnostic ablation (PCA_K1_SKIP bits: 1 look-back, 2 gathers, 4 stores); results invalid
 };
 
 #define K1_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -205,14 +216,14 @@ __global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a)
     }
 
     K1_STAMP(3);
-    const TileScan sc = tile_compact<BLK>(keep, a.state, tile, a.epoch);
+    const TileScan sc = tile_compact<BLK>(keep, a.state, tile, a.epoch, a.dbg_skip & 1);
     K1_STAMP(4);
     const int64_t origin = a.frame_off[a.first_slot];      // written by an earlier launch (stream order)
     const int64_t tile_base = origin + (int64_t)sc.excl;
     bool overflow = false;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-        if (!keep[k]) continue;
+        if (!keep[k] || (a.dbg_skip & 4)) continue;
         const int64_t o = tile_base + sc.local[k];
         if (o >= a.st.capacity) { overflow = true; continue; }
         a.st.x[o] = (double)q[k].x;
@@ -222,12 +233,195 @@ __global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a)
         a.st.rgbs[o] = packed[k];
         a.st.inst[o] = 0;
         a.st.dyn[o] = 0;
+        __builtin_amdgcn_sched_barrier(0);                 // one point's 7 store addresses at a time (registers)
     }
     if (overflow) atomicOr(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
     if (threadIdx.x == 0 && tin == ftiles - 1)             // last tile of the frame closes its segment
         a.frame_off[a.first_slot + f + 1] = tile_base + sc.total;
     K1_STAMP(5);
     if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)tile;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent, software-pipelined form of K1 (batched launches).  A workgroup loops over tiles handed out by a
+// monotonic ticket.  Per iteration:
+//   A  draw tile i+1, load / project / gather / filter, block scan, PUBLISH its aggregate;
+//   B  finish tile i: decoupled look-back (its predecessors have had a whole tile-time to publish, so the walk is
+//      short and its latency sits behind stage A instead of in front of the stores), append its records;
+//   C  park tile i+1's records in LDS as the new pending tile.
+// Every aggregate is published before the workgroup ever waits, and a wait only concerns tiles whose tickets were
+// drawn earlier, so progress never depends on dispatch order or residency.
+// ---------------------------------------------------------------------------------------------
+template <int BLK>
+__global__ __launch_bounds__(BLK) void k1_kitti_persistent(const K1Args a)
+{
+    constexpr int TILE_PTS = PPT * BLK;
+    constexpr int NW = BLK / PCA_WAVE;
+    __shared__ float4 s_q[TILE_PTS];           // pending tile: x, y, z, intensity of every point
+    __shared__ uint32_t s_packed[TILE_PTS];    // rgb | class<<24
+    __shared__ uint32_t s_rank[TILE_PTS];      // rank among the tile's kept points, 0xffffffff = dropped
+    __shared__ uint32_t s_wtot[PPT * NW];
+    __shared__ uint32_t s_woff[PPT * NW + 1];
+    __shared__ long long s_bcast[2];           // [0] ticket / tile of stage A, [1] exclusive prefix of stage B
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t origin = a.frame_off[a.first_slot];
+    bool have_pending = false;
+    int p_tile = 0, p_f = 0, p_last = 0;
+    uint32_t p_total = 0;
+    bool first = true;
+
+    for (;;) {
+        // ---------------- stage A: next tile ----------------
+        bool have_cur = false;
+        int tile = 0, f = 0, tin = 0, ftiles = 1;
+        if (first || !a.one_tile_each) {
+            if (threadIdx.x == 0)
+                s_bcast[0] = (long long)(atomicAdd(a.ticket64, 1ull) - a.ticket_base);
+            __syncthreads();
+            const long long t = s_bcast[0];
+            have_cur = t < (long long)a.total_tiles;
+            tile = (int)t;
+        }
+        first = false;
+        bool keep[PPT];
+        float4 q[PPT];
+        uint32_t packed[PPT], rank[PPT];
+        uint32_t total = 0;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) { keep[k] = false; packed[k] = 0; rank[k] = 0; q[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if (have_cur) {
+            pca_kitti_frame fr = a.one;
+            if (a.frames) {
+                int below = 0;
+                for (int f0 = 0; f0 < a.n_frames; f0 += 64) {
+                    const bool le = (f0 + lane < a.n_frames) && (ldg(&a.frames[f0 + lane].tile0) <= tile);
+                    const int c = (int)__popcll(__ballot(le));
+                    below += c;
+                    if (c < 64) break;
+                }
+                f = below - 1;
+                fr = a.frames[f];
+            }
+            tin = tile - fr.tile0;
+            ftiles = fr.n > 0 ? (fr.n + TILE_PTS - 1) / TILE_PTS : 1;
+            const int64_t base_pt = (int64_t)tin * TILE_PTS;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int64_t p = base_pt + k * BLK + threadIdx.x;
+                if (p < fr.n) q[k] = ldg4(fr.pts + 4 * p);
+            }
+            if (fr.n > 0 && fr.sem_gt) {
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int64_t p = base_pt + k * BLK + threadIdx.x;
+                    if (p >= fr.n) continue;
+                    const unsigned c = ldg(fr.sem_gt + p);
+                    keep[k] = !in_mask(a.filt, c);
+                    packed[k] = (uint32_t)c << 24;
+                }
+            } else if (fr.n > 0) {
+                bool ok[PPT];
+                int64_t pix[PPT];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int64_t p = base_pt + k * BLK + threadIdx.x;
+                    const int px = project_pixel(a.P, q[k].x, q[k].y, q[k].z, a.W, a.H);
+                    ok[k] = (p < fr.n) && px >= 0;
+                    pix[k] = ok[k] ? px : 0;
+                }
+                unsigned c[PPT], rgb[PPT];
+                const int64_t last = (int64_t)a.H * a.W * 3 - 4;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    c[k] = ldg(fr.sem + pix[k]);
+                    int64_t off = pix[k] * 3;
+                    if (last >= 0) {
+                        const int sh = off > last ? (int)(off - last) * 8 : 0;
+                        off = off > last ? last : off;
+                        rgb[k] = (ldg_u32_unaligned(fr.rgb + off) >> sh) & 0xffffffu;
+                    } else {
+                        rgb[k] = (uint32_t)ldg(fr.rgb + off) | ((uint32_t)ldg(fr.rgb + off + 1) << 8) | ((uint32_t)ldg(fr.rgb + off + 2) << 16);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    keep[k] = ok[k] && !in_mask(a.filt, c[k]);
+                    packed[k] = rgb[k] | (c[k] << 24);
+                }
+            }
+            // block scan of the keep flags (point order: row k, then thread)
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const uint64_t b = __ballot(keep[k]);
+                rank[k] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+                if (lane == 0) s_wtot[k * NW + wave] = (uint32_t)__popcll(b);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const uint32_t v = lane < PPT * NW ? s_wtot[lane] : 0u;
+                uint32_t inc = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += t;
+                }
+                if (lane < PPT * NW) s_woff[lane] = inc - v;
+                if (lane == 63) {
+                    s_woff[PPT * NW] = inc;
+                    lb_publish_aggregate(a.state, tile, (uint64_t)inc, a.epoch);      // before any waiting
+                }
+            }
+            __syncthreads();
+            total = s_woff[PPT * NW];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) rank[k] = keep[k] ? rank[k] + s_woff[k * NW + wave] : 0xffffffffu;
+        }
+
+        // ---------------- stage B: finish the pending tile ----------------
+        if (have_pending) {
+            if (wave == 0) {
+                const uint64_t e = lb_walk(a.state, p_tile, (uint64_t)p_total, a.epoch);
+                if (lane == 0) s_bcast[1] = (long long)e;
+            }
+            __syncthreads();
+            const int64_t tile_base = origin + s_bcast[1];
+            bool overflow = false;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int i = k * BLK + threadIdx.x;
+                const uint32_t r = s_rank[i];
+                if (r == 0xffffffffu) continue;
+                const int64_t o = tile_base + r;
+                if (o >= a.st.capacity) { overflow = true; continue; }
+                const float4 v = s_q[i];
+                a.st.x[o] = (double)v.x;
+                a.st.y[o] = (double)v.y;
+                a.st.z[o] = (double)v.z;
+                a.st.intensity[o] = v.w;
+                a.st.rgbs[o] = s_packed[i];
+                a.st.inst[o] = 0;
+                a.st.dyn[o] = 0;
+            }
+            if (overflow) atomicOr(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
+            if (threadIdx.x == 0 && p_last) a.frame_off[a.first_slot + p_f + 1] = tile_base + p_total;
+            __syncthreads();                                 // pending LDS consumed
+        }
+
+        // ---------------- stage C: the current tile becomes the pending one ----------------
+        if (have_cur) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int i = k * BLK + threadIdx.x;
+                s_q[i] = q[k];
+                s_packed[i] = packed[k];
+                s_rank[i] = rank[k];
+            }
+            p_tile = tile; p_f = f; p_last = (tin == ftiles - 1); p_total = total;
+        }
+        have_pending = have_cur;
+        if (!have_cur) break;
+        __syncthreads();
+    }
 }
 
 // =============================================================================================
@@ -481,16 +675,31 @@ int pca_kitti_project_sample_filter(pca_ctx *ctx, const pca_kitti_frame *frames,
     a.state = ctx->tile_state;
     a.ticket = ctx->ticket;
     a.epoch = pca_ctx_next_epoch(ctx, s);
+    a.ticket64 = nullptr; a.ticket_base = 0; a.one_tile_each = 0;
     a.dbg = nullptr;
+    a.dbg_skip = getenv("PCA_K1_SKIP") ? atoi(getenv("PCA_K1_SKIP")) : 0;
     if (getenv("PCA_K1_STAMPS")) {
         if (!ctx->dbg) { PCA_CHECK(ctx, hipMalloc(&ctx->dbg, sizeof(unsigned long long) * 8 * 65536)); }
         if (total <= 65536) a.dbg = ctx->dbg;
         ctx->dbg_blocks = total;
     }
-    switch (k1_blk()) {
-        case 256: PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti<256>, dim3(total), dim3(256), s, a); break;
-        case 1024: PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti<1024>, dim3(total), dim3(1024), s, a); break;
-        default: PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti<512>, dim3(total), dim3(512), s, a); break;
+    // persistent pipelined kernel: tiles are pulled by at most `resident` workgroups (3 x 512 threads fit a CU:
+    // 48 KB LDS and 70 VGPRs each); a single frame (fewer tiles than that) runs one tile per workgroup
+    const bool legacy = getenv("PCA_K1_LEGACY") != nullptr;
+    if (!legacy && k1_blk() == 512) {
+        const int resident = 256 * 3;
+        const int grid = total < resident ? total : resident;
+        a.ticket64 = ctx->ticket64;
+        a.ticket_base = ctx->ticket64_base;
+        a.one_tile_each = grid == total;
+        ctx->ticket64_base += (unsigned long long)total + (a.one_tile_each ? 0 : grid);
+        PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti_persistent<512>, dim3(grid), dim3(512), s, a);
+    } else {
+        switch (k1_blk()) {
+            case 256: PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti<256>, dim3(total), dim3(256), s, a); break;
+            case 1024: PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti<1024>, dim3(total), dim3(1024), s, a); break;
+            default: PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti<512>, dim3(total), dim3(512), s, a); break;
+        }
     }
     PCA_CHECK(ctx, hipGetLastError());
     return 0;

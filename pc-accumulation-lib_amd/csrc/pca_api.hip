@@ -79,6 +79,8 @@ int pca_ctx_create(int device, pca_ctx **out)
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->ticket, 2 * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(ctx->ticket, 0, 2 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&ctx->ticket64, sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->ticket64, 0, sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(&ctx->status_host, sizeof(uint32_t)) != hipSuccess) {
         delete ctx;
         return -1;
@@ -93,6 +95,7 @@ void pca_ctx_destroy(pca_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->tile_state) (void)hipFree(ctx->tile_state);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
+    if (ctx->ticket64) (void)hipFree(ctx->ticket64);
     if (ctx->frames_dev) (void)hipFree(ctx->frames_dev);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     prof_fold(ctx);

@@ -19,6 +19,8 @@ struct pca_ctx {
     uint64_t *tile_state = nullptr;   // dev [tile_cap]
     int64_t tile_cap = 0;
     uint32_t *ticket = nullptr;       // dev [2]: [0] ticket counter, [1] status bits
+    unsigned long long *ticket64 = nullptr;   // dev: monotonic ticket of the persistent K1 (never reset)
+    unsigned long long ticket64_base = 0;     // host mirror: draws issued so far
     uint32_t epoch = 0;               // 22-bit launch tag of tile_state entries
     pca_kitti_frame *frames_dev = nullptr;
     int frames_cap = 0;
@@ -127,16 +129,18 @@ __device__ __forceinline__ uint64_t lb_load(const uint64_t *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Called by ALL lanes of ONE wave (the first wave of the block).  Publishes this tile's aggregate,
-// walks back over predecessors, publishes the inclusive prefix, returns the exclusive prefix.
-__device__ __forceinline__ uint64_t lb_exclusive_prefix(uint64_t *state, int tile, uint64_t aggregate, uint32_t epoch)
+// Publishes the tile's aggregate (tile 0: its inclusive prefix straight away).  One lane.
+__device__ __forceinline__ void lb_publish_aggregate(uint64_t *state, int tile, uint64_t aggregate, uint32_t epoch)
+{
+    lb_store(&state[tile], lb_pack(tile == 0 ? LB_FLAG_PFX : LB_FLAG_AGG, epoch, aggregate));
+}
+
+// Called by ALL lanes of ONE wave after the aggregate was published: walks back over the predecessors,
+// publishes the inclusive prefix, returns the exclusive prefix.
+__device__ __forceinline__ uint64_t lb_walk(uint64_t *state, int tile, uint64_t aggregate, uint32_t epoch)
 {
     const int lane = threadIdx.x & 63;
-    if (tile == 0) {
-        if (lane == 0) lb_store(&state[0], lb_pack(LB_FLAG_PFX, epoch, aggregate));
-        return 0;
-    }
-    if (lane == 0) lb_store(&state[tile], lb_pack(LB_FLAG_AGG, epoch, aggregate));
+    if (tile == 0) return 0;
     uint64_t excl = 0;
     int hi = tile - 1;                      // newest predecessor of the current window
     // LB_W windows of 64 predecessors are fetched per round trip (independent loads), then consumed in order:
@@ -179,4 +183,11 @@ __device__ __forceinline__ uint64_t lb_exclusive_prefix(uint64_t *state, int til
     }
     if (lane == 0) lb_store(&state[tile], lb_pack(LB_FLAG_PFX, epoch, excl + aggregate));
     return excl;
+}
+
+// publish + walk in one go (non-pipelined users)
+__device__ __forceinline__ uint64_t lb_exclusive_prefix(uint64_t *state, int tile, uint64_t aggregate, uint32_t epoch)
+{
+    if ((threadIdx.x & 63) == 0) lb_publish_aggregate(state, tile, aggregate, epoch);
+    return lb_walk(state, tile, aggregate, epoch);
 }
