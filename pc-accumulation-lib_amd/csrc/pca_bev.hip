@@ -41,8 +41,8 @@ struct BevArgs {
     int pend_slot_end;    // <= slot_begin: none
     int tx, T, G;
     uint32_t *key;        // [max_points]
-    uint32_t *bh;         // [G*T]
-    uint32_t *boff;       // [G*T]
+    uint32_t *bh;         // [T][G] kept records per (tile, workgroup)
+    uint32_t *boff;       // [T][G] exclusive scan of bh in that order
     uint32_t *tile_off;   // [T+1]
     void *recs;           // RecF / RecD [max_points], tile-ordered; c = r | g<<8 | b<<16 | FLAG_*
     double *planes;
@@ -137,16 +137,19 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_hist(const BevArgs a)
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < a.T; t += AB_THREADS) a.bh[(int64_t)blockIdx.x * a.T + t] = s_h[t];
+    // tile-major layout [tile][workgroup]: the scan then streams, the strided accesses ride along here and in the scatter
+    for (int t = threadIdx.x; t < a.T; t += AB_THREADS) a.bh[(int64_t)t * a.G + blockIdx.x] = s_h[t];
 }
 
 // ---------------------------------------------------------------------------------------------
 // level 1b: exclusive scan of bh in (tile-major, workgroup-minor) order -> boff, tile_off
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bev_tile_scan(const BevArgs a)
+#define SCAN_THREADS 1024
+#define SCAN_TILE (4 * SCAN_THREADS)       // few large scan tiles: the look-back then spans at most one window
+__global__ __launch_bounds__(SCAN_THREADS) void bev_tile_scan(const BevArgs a)
 {
     __shared__ int s_tile;
-    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_w[SCAN_THREADS / 64];
     __shared__ uint64_t s_excl;
     const int n = a.T * a.G;
     if (threadIdx.x == 0) {
@@ -157,20 +160,10 @@ __global__ __launch_bounds__(256) void bev_tile_scan(const BevArgs a)
     __syncthreads();
     const int tile = s_tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int base = tile * 1024 + threadIdx.x * 4;
+    const int base = tile * SCAN_TILE + threadIdx.x * 4;    // bh and boff are both [tile][workgroup]: contiguous
     uint32_t c[4];
-    int64_t src[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = base + k;
-        src[k] = -1;
-        c[k] = 0;
-        if (i < n) {
-            const int t = i / a.G, b = i - t * a.G;
-            src[k] = (int64_t)b * a.T + t;
-            c[k] = a.bh[src[k]];
-        }
-    }
+    for (int k = 0; k < 4; ++k) c[k] = (base + k < n) ? a.bh[base + k] : 0u;
     const uint32_t tsum = c[0] + c[1] + c[2] + c[3];
     uint32_t inc = tsum;
 #pragma unroll
@@ -180,28 +173,32 @@ __global__ __launch_bounds__(256) void bev_tile_scan(const BevArgs a)
     }
     if (lane == 63) s_w[wave] = inc;
     __syncthreads();
-    uint32_t wbase = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        if (w < wave) wbase += s_w[w];
-        total += s_w[w];
-    }
     if (wave == 0) {
+        const uint32_t v = lane < SCAN_THREADS / 64 ? s_w[lane] : 0u;
+        uint32_t winc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(winc, o, 64);
+            if (lane >= o) winc += t;
+        }
+        if (lane < SCAN_THREADS / 64) s_w[lane] = winc - v;                // exclusive wave offsets
+        const uint32_t total = __shfl(winc, 63, 64);
         const uint64_t e = lb_exclusive_prefix(a.state, tile, (uint64_t)total, a.epoch);
-        if (lane == 0) s_excl = e;
+        if (lane == 0) s_excl = (e << 32) | total;                          // both fit 32 bits (checked by the host)
     }
     __syncthreads();
-    uint32_t run = (uint32_t)s_excl + wbase + (inc - tsum);
+    const uint32_t excl = (uint32_t)(s_excl >> 32), total = (uint32_t)s_excl;
+    uint32_t run = excl + s_w[wave] + (inc - tsum);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (src[k] >= 0) {
-            a.boff[src[k]] = run;
-            const int i = base + k;
+        const int i = base + k;
+        if (i < n) {
+            a.boff[i] = run;
             if (i % a.G == 0) a.tile_off[i / a.G] = run;
         }
         run += c[k];
     }
-    if (tile == a.scan_tiles - 1 && threadIdx.x == 255) a.tile_off[a.T] = (uint32_t)s_excl + total;
+    if (tile == a.scan_tiles - 1 && threadIdx.x == SCAN_THREADS - 1) a.tile_off[a.T] = excl + total;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -212,7 +209,7 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_scatter(const BevArgs a)
 {
     extern __shared__ uint32_t s_cur[];                     // [T]
     const Window w = chunk_of(a);
-    for (int t = threadIdx.x; t < a.T; t += AB_THREADS) s_cur[t] = a.boff[(int64_t)blockIdx.x * a.T + t];
+    for (int t = threadIdx.x; t < a.T; t += AB_THREADS) s_cur[t] = a.boff[(int64_t)t * a.G + blockIdx.x];
     __syncthreads();
     const pca_bev_params &q = a.prm;
     const double oz = q.origin[2];
@@ -644,14 +641,14 @@ int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensi
     a.planes = planes;
     a.planes_f16 = planes_f16;
     const int64_t n_scan = (int64_t)a.T * a.G;
-    a.scan_tiles = (int)((n_scan + 1023) / 1024);
+    a.scan_tiles = (int)((n_scan + SCAN_TILE - 1) / SCAN_TILE);
     if (pca_ctx_reserve_tiles(ctx, a.scan_tiles, s)) return -1;
     a.state = ctx->tile_state;
     a.ticket = ctx->ticket;
     a.epoch = pca_ctx_next_epoch(ctx, s);
     const size_t lds = (size_t)a.T * 4;
     PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_hist, dim3(a.G), dim3(AB_THREADS), lds, s, a);
-    PCA_LAUNCH(ctx, PCA_K_BEV_SCAN, bev_tile_scan, dim3(a.scan_tiles), dim3(256), s, a);
+    PCA_LAUNCH(ctx, PCA_K_BEV_SCAN, bev_tile_scan, dim3(a.scan_tiles), dim3(SCAN_THREADS), s, a);
     if (intensity64) {
         PCA_LAUNCH_SHM(ctx, PCA_K_BEV_SCATTER, bev_tile_scatter<true>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
         PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_tile_cells<true>, dim3(a.T), dim3(C_THREADS), s, a);
