@@ -14,13 +14,14 @@
 //                       closed-form maps, fp16, tile written back.
 // 'full' = present (+) future is formed per cell (counts add, min of mins, median of the union).
 #include "pca_bev_common.h"
+#include <cstdlib>
 
 #define KEY_INVALID 0xffffffffu
 #define TS 8                      // tile side [cells]
 #define TCELLS (TS * TS)
 #define NFK (2 * TCELLS)          // fine keys per tile: cell_in_tile*2 + set
 #define AB_THREADS 1024           // workgroup size of the hist / scatter kernels
-#define MAX_G 256                 // workgroups of the hist / scatter kernels
+#define MAX_G 512                 // workgroups of the hist / scatter kernels
 #define C_THREADS 256             // workgroup size of the tile kernel
 #define RGB_CAP 4096              // colour records resident in LDS per batch of cells
 #define FLAG_ROAD (1u << 24)
@@ -588,8 +589,16 @@ static inline int64_t align256(int64_t v) { return (v + 255) & ~255ll; }
 static inline int tiles_x(int px) { return (px + TS - 1) / TS; }
 static inline int n_groups(int64_t max_points)
 {
-    int64_t g = (max_points + 16383) / 16384;
-    return (int)(g < 1 ? 1 : (g > MAX_G ? MAX_G : g));
+    static int max_g = 0, per_g = 0;
+    if (!max_g) {                                           // PCA_BEV_G / PCA_BEV_CHUNK: tuning overrides
+        const char *e = getenv("PCA_BEV_G"), *c = getenv("PCA_BEV_CHUNK");
+        max_g = e ? atoi(e) : MAX_G;
+        per_g = c ? atoi(c) : 8192;
+        if (max_g < 1 || max_g > 1024) max_g = MAX_G;
+        if (per_g < 1024) per_g = 8192;
+    }
+    int64_t g = (max_points + per_g - 1) / per_g;
+    return (int)(g < 1 ? 1 : (g > max_g ? max_g : g));
 }
 
 extern "C" {

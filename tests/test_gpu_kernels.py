@@ -361,3 +361,51 @@ def test_stress_config4_scaled_properties(T):
     # rgb == 0 everywhere (GT-semantics mode): medians are exactly the fill colour
     assert float(p64[2:5].abs().max()) == 0.0
     assert T.equal(p16.double()[0], p64[0].half().double())
+
+
+@pytest.mark.parametrize('px,view', [(7, 10.0), (30, 33.0), (100, 51.2), (512, 160.0), (1024, 200.0)])
+def test_bev_grid_sizes_and_partial_tiles(T, orc, px, view):
+    """Grids that are not a multiple of the 8x8 tile, smaller than one tile, and the largest supported one."""
+    rng = np.random.default_rng(px)
+    n = 40000
+    rows = np.zeros((n, 10))
+    rows[:, :2] = rng.uniform(-0.55 * view, 0.55 * view, (n, 2))
+    rows[:, 2] = rng.uniform(-2, 4, n)
+    rows[:, 3] = rng.uniform(0, 1, n).astype(np.float32)
+    rows[:, 4:7] = rng.integers(0, 256, (n, 3))
+    rows[:, 7] = rng.choice([0, 1, 13, 17], n)
+    rows[:, 9] = rng.random(n) < 0.05
+    p16, p64, _ = run_dev_bev(T, rows[:15000], rows[15000:], view, px, 3.0, (20., 20., 0.5), False, 0.9, 0.3, -0.2)
+    ref = run_orc_bev(orc, rows[:15000], rows[15000:], view, px, 3.0, (20., 20., 0.5), False, 0.9, 0.3, -0.2)
+    assert_planes_match(p16, p64, ref, f'px={px}')
+
+
+def test_bev_empty_and_out_of_view_windows(T, orc):
+    empty = np.zeros((0, 10))
+    far = np.zeros((100, 10))
+    far[:, 0] = 1e6
+    for rows_p, rows_f in ((empty, empty), (far, empty), (empty, far)):
+        p16, p64, _ = run_dev_bev(T, rows_p, rows_f, 20, 32, None, (20., 20., 0.5), False, 0.0)
+        ref = run_orc_bev(orc, rows_p, rows_f, 20, 32, None, (20., 20., 0.5), False, 0.0)
+        assert_planes_match(p16, p64, ref)
+        assert np.all(p64[0] == 0.5) and np.all(p64[6] == 0.0)
+
+
+def test_bev_dense_tile_goes_through_batches(T, orc):
+    """One 8x8 tile holding more colour records than fit its LDS buffer, spread over many cells (batch path),
+    plus cells above 64 values (histogram path) next to small ones (radix-select path)."""
+    rng = np.random.default_rng(21)
+    n = 30000
+    rows = np.zeros((n, 10))
+    # view 32 m, 64 px -> cell 0.5 m, tile 4 m: put 20k points into the tile [0,4) x [0,4)
+    rows[:20000, :2] = rng.uniform(0.01, 3.99, (20000, 2))
+    rows[20000:, :2] = rng.uniform(-15.9, 15.9, (10000, 2))
+    rows[:, 2] = rng.uniform(-1, 2, n)
+    rows[:, 3] = rng.integers(0, 256, n) / 255.
+    rows[:, 4:7] = rng.integers(0, 256, (n, 3))
+    rows[:, 7] = rng.choice([0, 2, 13], n)
+    perm = rng.permutation(n)
+    rows = rows[perm]
+    p16, p64, _ = run_dev_bev(T, rows[:12000], rows[12000:], 32, 64, None, (1., 30., 0.12), True, 0.0)
+    ref = run_orc_bev(orc, rows[:12000], rows[12000:], 32, 64, None, (1., 30., 0.12), True, 0.0)
+    assert_planes_match(p16, p64, ref, 'dense tile')
