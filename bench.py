@@ -199,10 +199,7 @@ def main():
             return None
         pcs, trajs = acc._window_inputs(idx, True)
         gen = acc.sem_bev_generator
-        bev = gen.generate(pcs, trajs, device_only=True)
-        if bev_out is not None:
-            bev_out[slot].copy_(bev['planes_f16'])
-        return bev
+        return gen.generate(pcs, trajs, device_only=True, out=None if bev_out is None else bev_out[slot])
 
     # ---- untimed: fill the accumulation window, then W warm-up steps ----
     while present_index(acc) is None or len(acc.poses) < 195:

@@ -80,6 +80,7 @@ class BEVGenerator(ABC):
         self._tmp = {}                      # scratch device stores of the host-array path
         self._frame = None
         self._device_only = False
+        self._out16 = None
 
     def __getstate__(self):                 # device handles never travel through pickle
         d = dict(self.__dict__)
@@ -102,13 +103,13 @@ class BEVGenerator(ABC):
             self._tmp[key] = DeviceStore(capacity=1 << 16, max_frames=4)
         return self._tmp[key]
 
-    def rasterise(self, pc_present, pc_future, pc_full, rot_mat, dx, dy, aug_view_size, want_f64=False):
+    def rasterise(self, pc_present, pc_future, pc_full, rot_mat, dx, dy, aug_view_size, want_f64=False, out16=None):
         """Returns (planes_f16, planes_f64|None) as cuda tensors [21,px,px], set-major
         {present,future,full} x {road,intensity,r,g,b,dynamic,elevation}."""
         if isinstance(pc_present, WindowPart):
             w = pc_present.window
             prm = self._raster_params(w.origin, rot_mat, dx, dy, aug_view_size, w.store.intensity_div255)
-            return w.store.bev(w.split, prm, want_f64=want_f64, first_frame=w.first, last_frame=w.last)
+            return w.store.bev(w.split, prm, want_f64=want_f64, first_frame=w.first, last_frame=w.last, out16=out16)
         # host arrays: 'present' and 'future' share one launch; 'full' is an independent input in the
         # reference's interface, so it gets its own launch (as the present set of a second window)
         zero = np.zeros(3)
@@ -138,10 +139,11 @@ class BEVGenerator(ABC):
                  trans_dy: float = 0.,
                  zoom_scalar: float = 1.,
                  do_warping: bool = False,
-                 device_only: bool = False):
+                 device_only: bool = False,
+                 out=None):
         """device_only=True (extension): the 21 planes stay in HBM -- the returned dict holds one cuda
         float16 tensor 'planes_f16' [21,px,px] instead of 15 host arrays (used by the sharded runner and
-        the benchmark, where BEVs are gathered with RCCL)."""
+        the benchmark, where BEVs are gathered with RCCL); `out` may name the cuda tensor to write into."""
         pc_present, pc_future, pc_full = self.extract_pc_dict(pcs)
         ego_present, ego_future, ego_full = self.extract_ego_traj_dict(trajs)
         oth_present, oth_future, oth_full = self.extract_other_traj_dicts(trajs)
@@ -176,6 +178,7 @@ class BEVGenerator(ABC):
 
         self._frame = (rot_mat, trans_dx, trans_dy, aug_view_size)
         self._device_only = device_only
+        self._out16 = out if device_only else None
         return self.generate_bev(pc_present, pc_future, pc_full, trajs_present, trajs_future, trajs_full, lanes)
 
     def preprocess_pc_and_trajs(self, pc, trajs, rot_ang, trans_dx, trans_dy, aug_view_size):

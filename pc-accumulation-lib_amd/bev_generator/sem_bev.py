@@ -31,14 +31,14 @@ class SemBEVGenerator(BEVGenerator):
         self._frame = None
 
     # ------------------------------------------------------------------------------------------
-    def generate_bev_device(self, pc_present, pc_future, pc_full, want_f64=False):
+    def generate_bev_device(self, pc_present, pc_future, pc_full, want_f64=False, out16=None):
         """Device tensors only: (planes_f16, planes_f64|None), [21,px,px].  Used by the sharded runner and
         the benchmark, where BEVs stay in HBM until they are gathered."""
         if self._frame is None:
             rot_mat, dx, dy, view = np.eye(3), 0., 0., float(self.view_size)
         else:
             rot_mat, dx, dy, view = self._frame
-        return self.rasterise(pc_present, pc_future, pc_full, rot_mat, dx, dy, view, want_f64)
+        return self.rasterise(pc_present, pc_future, pc_full, rot_mat, dx, dy, view, want_f64, out16=out16)
 
     def generate_bev(self, pc_present, pc_future, pc_full, trajs_present, trajs_future, trajs_full,
                      gt_lane_trajs=None):
@@ -48,8 +48,9 @@ class SemBEVGenerator(BEVGenerator):
             # called directly with the reference's pre-gridded rows: put every point at its cell centre
             pc_present, pc_future, pc_full = (self._grid_rows_to_metres(p) for p in (pc_present, pc_future, pc_full))
         device_only, self._device_only = self._device_only, False
+        out16, self._out16 = self._out16, None
         p16, p64 = self.generate_bev_device(pc_present, pc_future, pc_full,
-                                            want_f64=self.do_warp and not device_only)
+                                            want_f64=self.do_warp and not device_only, out16=out16)
         self._frame = None
         if device_only:
             out = {'planes_f16': p16, 'trajs_present': trajs_present, 'trajs_future': trajs_future,

@@ -213,7 +213,7 @@ class DeviceStore:
                                            ctx.stream()))
 
     # ---- BEV ------------------------------------------------------------------------------
-    def bev(self, split_frame, prm, want_f64=False, intensity64=None, first_frame=0, last_frame=None):
+    def bev(self, split_frame, prm, want_f64=False, intensity64=None, first_frame=0, last_frame=None, out16=None):
         """Rasterises live frames [first_frame, last_frame) with 'present' = frames before split_frame.
         Returns (planes_f16 [21,px,px] cuda float16, planes_f64 or None)."""
         ctx, lib = self.ctx, self.ctx.lib
@@ -223,7 +223,9 @@ class DeviceStore:
         need = lib.pca_bev_workspace_bytes(max_points, px)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
-        p16 = torch.empty((21, px, px), dtype=torch.float16, device=self.device)
+        if out16 is not None:
+            assert out16.dtype == torch.float16 and out16.is_contiguous() and tuple(out16.shape) == (21, px, px)
+        p16 = out16 if out16 is not None else torch.empty((21, px, px), dtype=torch.float16, device=self.device)
         p64 = torch.empty((21, px, px), dtype=torch.float64, device=self.device) if want_f64 else None
         st = self.c_store()
         pend_T, pend_end = None, 0
