@@ -34,8 +34,6 @@ class DeviceStore:
         self._pending = None     # (T 4x4, end slot): a re-transform owed to slots [head, end slot)
         self._k1_cache = None
         self._ws = None
-        self._planes16 = {}
-        self._planes64 = {}
 
     # ---- memory ----------------------------------------------------------------------------
     def _alloc(self, cap):
