@@ -23,9 +23,24 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         self.H_velo_cam = calib_params['h_velo_cam']
         self.P_cam_frame = calib_params['p_cam_frame']
         self.P_velo_frame = calib_params['p_velo_frame']
-        self.pose_provider = self._icp_pose
+        self.pose_provider = self._default_pose_provider()
 
     # ---- pose input ----------------------------------------------------------------------------
+    def _default_pose_provider(self):
+        """Pose source without touching the driver: PCA_KITTI_T_FILE=<.npy of (F,4,4) T_new_prev, one per frame>
+        or PCA_POSE_PROVIDER=<module>:<callable(pc) -> 4x4>; otherwise the reference's Open3D ICP call."""
+        import os
+        path = os.environ.get('PCA_KITTI_T_FILE')
+        if path:
+            Ts = iter(np.load(path))
+            return lambda pc: next(Ts)
+        spec = os.environ.get('PCA_POSE_PROVIDER')
+        if spec:
+            import importlib
+            mod, _, fn = spec.partition(':')
+            return getattr(importlib.import_module(mod), fn)
+        return self._icp_pose
+
     def _icp_pose(self, pc):
         try:
             import open3d as o3d

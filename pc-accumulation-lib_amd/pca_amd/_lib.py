@@ -124,6 +124,9 @@ class Context:
     @classmethod
     def get(cls, device=None):
         import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError('pca_amd needs an AMD GPU (torch.cuda.is_available() is False); '
+                               'there is no CPU fallback')
         idx = torch.cuda.current_device() if device is None else torch.device(device).index or 0
         if idx not in cls._by_device:
             cls._by_device[idx] = Context(idx)

@@ -211,3 +211,128 @@ def test_helper_methods_match_reference(golden):
     assert np.array_equal(sem_rows, g['sem_sem'])
     both = np.concatenate((rgb_rows, sem_rows[:, -1:]), axis=1)
     assert np.array_equal(acc.filter_semseg_pc(both), g['filtered'])
+
+
+def test_driver_shaped_run_on_fake_kitti_tree(tmp_path, monkeypatch):
+    """The call sequence of run_kitti360_bev_gen.py (dataloader -> calibration -> accumulator -> trigger ->
+    generate_bev -> pickle + png) on a synthetic KITTI-360 tree, GT semantics, poses from PCA_KITTI_T_FILE;
+    the last BEV and the stored points are checked against the oracle pipeline."""
+    from fake_kitti import SEQ, write_tree
+    from oracle import oracle as orc
+
+    from datasets.kitti360_utils import get_camera_intrinsics, get_transf_matrices
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    from obs_dataloaders.kitti360_obs_dataloader import Kitti360Dataloader
+    from pca_amd import host_logic as hl
+    root = str(tmp_path / 'KITTI-360')
+    n_frames = 40
+    frames, Ts, _ = write_tree(root, first_idx=130, n_frames=n_frames)
+    monkeypatch.setenv('PCA_KITTI_T_FILE', os.path.join(root, 'T_new_prev.npy'))
+    filters = [10, 11, 12, 16, 18, 255]
+    h_cam_velo, h_velo_cam = get_transf_matrices(root)
+    p_cam_frame = get_camera_intrinsics(root)
+    calib = {'h_velo_cam': h_velo_cam, 'p_cam_frame': p_cam_frame, 'p_velo_frame': np.matmul(p_cam_frame, h_velo_cam)}
+    bev_params = dict(BEV_KITTI, view_size=30, pixel_size=64)
+    acc = Kitti360SemanticPointCloudAccumulator(20., calib, 1e3, 'none.onnx', filters, SEM_IDXS, True, bev_params)
+    loader = Kitti360Dataloader(root, 1, [SEQ], [130], [130 + n_frames])
+    bev_horizon, previous_idx, n_bev, last = 6, 0, 0, None
+    for observations in loader:
+        previous_idx -= acc.integrate(observations)
+        if len(acc.poses) < 2:
+            continue
+        d = acc.get_incremental_path_dists()
+        if d[-1] < bev_horizon:
+            continue
+        present_idx = ((d - bev_horizon) > 0).argmax()
+        if d[-1] - d[present_idx] < bev_horizon:
+            continue
+        if acc.dist(acc.get_pose(previous_idx), acc.get_pose(present_idx)) < 1:
+            continue
+        previous_idx = present_idx
+        bevs = acc.generate_bev(present_idx, 1, gen_future=True)
+        out_dir = str(tmp_path / 'bevs' / 'subdir000')
+        os.makedirs(out_dir, exist_ok=True)
+        acc.write_compressed_pickle(bevs[0], f'bev_{n_bev:03d}.pkl', out_dir)
+        acc.viz_bev(bevs[0], os.path.join(out_dir, f'viz_{n_bev:03d}.png'), acc.get_rgb(present_idx),
+                    acc.get_semseg(present_idx))
+        n_bev += 1
+        last = (bevs[0], int(present_idx))
+    assert n_bev >= 5 and len(os.listdir(str(tmp_path / 'bevs' / 'subdir000'))) == 2 * n_bev
+
+    # oracle replay of the same sequence
+    idx2idx = loader.idx2idx
+    st = orc.Store(n_frames * 3000)
+    track = hl.PoseTrack()
+    sizes, lo = [], 0
+    for k, (pc, img, lab) in enumerate(frames):
+        sem = lab.astype(np.int16).copy()[:, None]
+        from datasets.kitti360_utils import conv_semantic_ids
+        sem = conv_semantic_ids(sem, idx2idx)[:, 0].astype(np.uint8)
+        if len(track):
+            track.apply_transform(Ts[k])
+            orc.retransform(st, Ts[k], lo, st.n)
+        sizes.append(orc.kitti_project_sample_filter(st, pc, calib['p_velo_frame'], None, None, sem, 1, 1, filters))
+        track.append([0., 0., 0.])
+        if len(track) > 1:
+            ev = track.evict_beyond(20., track.push_segment())
+            lo += int(np.sum(sizes[:ev]))
+            sizes = sizes[ev:]
+    assert np.array_equal(np.concatenate(acc.sem_pcs), st.rows(lo))
+    assert np.array_equal(np.array(acc.poses), np.array(track.poses))
+    bev, pidx = last
+    origin = np.array(track.poses[pidx])
+    ego = np.array(track.poses[:pidx]) - origin
+    R = hl.rotation_matrix_3d(hl.heading_rot_ang(ego))
+    prm = orc.make_bev_params(origin, R, 0., 0., 30, 64, None, 20., 20., 0.5, 0, [13, 14, 15, 17], False)
+    sub = orc.Store(st.n - lo + 1)
+    for name in ('x', 'y', 'z', 'intensity', 'rgbs', 'inst', 'dyn'):
+        getattr(sub, name)[:st.n - lo] = getattr(st, name)[lo:st.n]
+    sub.n = st.n - lo
+    ref = orc.bev(sub, int(np.sum(sizes[:pidx])), prm)
+    F = ref['f16']
+    for s, name in enumerate(('present', 'future', 'full')):
+        assert np.array_equal(bev[f'road_{name}'].view(np.uint16), F[7 * s].view(np.uint16))
+        assert np.array_equal(bev[f'elevation_{name}'].view(np.uint16), F[7 * s + 6].view(np.uint16))
+        assert np.array_equal(bev[f'dynamic_{name}'].view(np.uint16), F[7 * s + 5].view(np.uint16))
+        assert np.abs(bev[f'intensity_{name}'].view(np.uint16).astype(int) - F[7 * s + 1].view(np.uint16).astype(int)).max() <= 1
+
+
+def test_long_stream_with_window_slides_and_growth():
+    """1200 frames through a deliberately small store: the live window has to slide to the front many times and
+    the slot table has to grow; state must stay identical to the oracle's."""
+    import torch
+    from oracle import oracle as orc
+    from pca_amd import host_logic as hl
+    from pca_amd.device_store import DeviceStore
+    rng = np.random.default_rng(8)
+    st = DeviceStore(capacity=6000, max_frames=16)
+    ost = orc.Store(1200 * 300)
+    track = hl.PoseTrack()
+    P = np.array([[40., 0, 48, 0], [0, 40., 32, 0], [0, 0, 1, 0]])
+    sizes, lo = [], 0
+    T = np.eye(4)
+    T[:3, :3] = hl.rotation_matrix_3d(0.01)
+    T[:3, 3] = [-1.0, 0.02, 0.0]
+    for k in range(1200):
+        n = int(rng.integers(50, 300))
+        pc = np.stack([rng.uniform(-9, 9, n), rng.uniform(-9, 9, n), rng.uniform(-1, 2, n), rng.uniform(0, 1, n)],
+                      1).astype(np.float32)
+        sem = rng.integers(0, 19, n).astype(np.uint8)
+        if len(track):
+            track.apply_transform(T)
+            st.retransform(T, defer=(k % 3 == 0))
+            orc.retransform(ost, T, lo, ost.n)
+        st.append_kitti([dict(pts=torch.from_numpy(pc).cuda(), sem_gt=torch.from_numpy(sem).cuda())], P, 1, 1,
+                        [10, 11, 12, 16, 18, 255])
+        sizes.append(orc.kitti_project_sample_filter(ost, pc, P, None, None, sem, 1, 1, [10, 11, 12, 16, 18, 255]))
+        track.append([0., 0., 0.])
+        if len(track) > 1:
+            ev = track.evict_beyond(25., track.push_segment())
+            st.evict(ev)
+            lo += int(np.sum(sizes[:ev]))
+            sizes = sizes[ev:]
+        if k in (0, 17, 400, 1199):
+            assert np.array_equal(st.sizes(), np.array(sizes))
+            assert np.array_equal(st.rows(), ost.rows(lo))
+    st.check_status()
+    assert st.max_frames > 16 and st.capacity >= 6000

@@ -1,0 +1,32 @@
+"""The reference's OWN driver script, unchanged, resolves every import against the drop-in root and gets as far
+as the first device call (where, without a GPU, the product fails loudly).  Runs only where the reference
+checkout exists (the build container); the GPU box has no /root/reference."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import PKG
+from fake_kitti import write_tree
+
+REF_DRIVER = '/root/reference/run_kitti360_bev_gen.py'
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DRIVER), reason='reference checkout not present')
+def test_unchanged_kitti_driver_runs_up_to_the_device(tmp_path):
+    import torch
+    root = str(tmp_path / 'KITTI-360')
+    write_tree(root, first_idx=130, n_frames=3)          # the driver starts sequence 0000 at frame 130
+    env = dict(os.environ, PYTHONPATH=PKG, PCA_KITTI_T_FILE=os.path.join(root, 'T_new_prev.npy'),
+               PYTHONDONTWRITEBYTECODE='1')
+    r = subprocess.run([sys.executable, '-m', 'pca_amd.run', REF_DRIVER, root, 'none.onnx', '--use_gt_sem', '--bev_pixel_size', '32',
+                        '--accum_horizon_dist', '20', '--bev_horizon_dist', '5'], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert 'ModuleNotFoundError' not in out and 'ImportError' not in out, out[-2000:]
+    assert 'kitti360_sem_pc_accum.py' in out and 'integrate' in out, out[-2000:]
+    if not torch.cuda.is_available():
+        # no GPU here: the first integrate() must die loudly in the product, not fall back to anything
+        assert 'no CPU fallback' in out, out[-2000:]
+        assert PKG in out
