@@ -63,6 +63,7 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         dev = self.store.device
 
         def up(a, dtype):
+            a = getattr(a, 'dev', a)             # pca_amd.ingest.DeviceImage
             if isinstance(a, torch.Tensor):
                 return a.to(device=dev, dtype=dtype).contiguous()
             return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype_np[dtype])).to(dev)
@@ -72,7 +73,7 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         semseg = None
         if sem_gt is None:
             semseg = self.semseg_model.pred(rgb)[0, 0]
-            img = rgb if isinstance(rgb, torch.Tensor) else np.array(rgb)
+            img = rgb if isinstance(rgb, torch.Tensor) or hasattr(rgb, 'dev') else np.array(rgb)
             frame['rgb'] = up(img, torch.uint8)
             frame['sem'] = up(semseg, torch.uint8)
             H, W = frame['sem'].shape

@@ -1,0 +1,66 @@
+"""Output writer: the reference writes each BEV sample as gzip(pickle(dict)) synchronously
+(sem_pc_accum.py:280-294); once a sample costs < 1 ms on the GPU that dominates.  AsyncBevWriter does the device->host
+copy, pickling and compression on worker threads.  Same container, same dict schema (README.md:60-99 of the reference)."""
+import gzip
+import os
+import pickle
+import queue
+import threading
+
+import numpy as np
+
+
+class AsyncBevWriter:
+
+    def __init__(self, n_threads=4, compresslevel=9, max_pending=64):
+        self.q = queue.Queue(maxsize=max_pending)
+        self.compresslevel = compresslevel
+        self.errors = []
+        self.threads = [threading.Thread(target=self._work, daemon=True) for _ in range(n_threads)]
+        for t in self.threads:
+            t.start()
+
+    @staticmethod
+    def _to_host(bev):
+        """Accepts the reference dict (host arrays) or the device_only form {'planes_f16': cuda [21,px,px], trajs}."""
+        if 'planes_f16' not in bev:
+            return bev
+        from bev_generator.sem_bev import SemBEVGenerator
+        planes = bev['planes_f16'].cpu().numpy()
+        out = SemBEVGenerator.pack_bev(planes, bev['trajs_present'], bev['trajs_future'], bev['trajs_full'],
+                                       bev.get('gt_lanes'))
+        for k, v in bev.items():
+            if k not in out and k != 'planes_f16':
+                out[k] = v
+        return out
+
+    def _work(self):
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            bev, filename, write_dir = job
+            try:
+                os.makedirs(write_dir, exist_ok=True)
+                blob = pickle.dumps(self._to_host(bev))
+                with gzip.open(os.path.join(write_dir, f'{filename}.gz'), 'wb', compresslevel=self.compresslevel) as f:
+                    f.write(blob)
+            except Exception as e:              # reported by close(); the reference prints IOErrors and goes on
+                self.errors.append(e)
+            finally:
+                self.q.task_done()
+
+    def submit(self, bev, filename, write_dir):
+        """Same arguments as SemanticPointCloudAccumulator.write_compressed_pickle."""
+        if 'planes_f16' in bev:                  # snapshot: the caller may reuse the device buffer
+            bev = dict(bev, planes_f16=bev['planes_f16'].clone())
+        self.q.put((bev, filename, write_dir))
+
+    def close(self):
+        self.q.join()
+        for _ in self.threads:
+            self.q.put(None)
+        for t in self.threads:
+            t.join()
+        if self.errors:
+            raise self.errors[0]

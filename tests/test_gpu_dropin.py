@@ -336,3 +336,60 @@ def test_long_stream_with_window_slides_and_growth():
             assert np.array_equal(st.rows(), ost.rows(lo))
     st.check_status()
     assert st.max_frames > 16 and st.capacity >= 6000
+
+
+def test_prefetching_loader_and_async_writer(tmp_path, monkeypatch):
+    """Ingest + writer (the 'next' rows either side of the path): same observations, same stored points, same
+    files as the synchronous loader / writer."""
+    from fake_kitti import SEQ, write_tree
+
+    from datasets.kitti360_utils import get_camera_intrinsics, get_transf_matrices
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    from obs_dataloaders.kitti360_obs_dataloader import Kitti360Dataloader
+    from pca_amd.ingest import PrefetchingLoader, compose_label_lut
+    from pca_amd.writer import AsyncBevWriter
+    root = str(tmp_path / 'KITTI-360')
+    n_frames = 24
+    write_tree(root, first_idx=0, n_frames=n_frames)
+    _, h_velo_cam = get_transf_matrices(root)
+    p_cam = get_camera_intrinsics(root)
+    calib = {'h_velo_cam': h_velo_cam, 'p_cam_frame': p_cam, 'p_velo_frame': np.matmul(p_cam, h_velo_cam)}
+    Ts = np.load(os.path.join(root, 'T_new_prev.npy'))
+
+    def run(loader, writer):
+        acc = Kitti360SemanticPointCloudAccumulator(50., calib, 1e3, 'none', KITTI_FILTERS, SEM_IDXS, True,
+                                                    dict(BEV_KITTI, view_size=30, pixel_size=32))
+        it = iter(Ts)
+        acc.pose_provider = lambda pc: next(it)
+        for observations in loader:
+            acc.integrate(observations)
+        bev = acc.generate_bev(12, 1, gen_future=True)[0]
+        bev_dev = acc.sem_bev_generator.generate(*acc._window_inputs(12, True), device_only=True)
+        if writer is None:
+            acc.write_compressed_pickle(bev, 'a.pkl', str(tmp_path / 'sync'))
+        else:
+            writer.submit(bev, 'a.pkl', str(tmp_path / 'async'))
+            writer.submit(bev_dev, 'b.pkl', str(tmp_path / 'async'))
+        return np.concatenate(acc.sem_pcs), bev, acc
+
+    os.makedirs(str(tmp_path / 'sync'))
+    base = Kitti360Dataloader(root, 1, [SEQ], [0], [n_frames])
+    rows_a, bev_a, acc = run(base, None)
+    w = AsyncBevWriter(n_threads=2)
+    rows_b, bev_b, _ = run(PrefetchingLoader(Kitti360Dataloader(root, 1, [SEQ], [0], [n_frames]), depth=3), w)
+    w.close()
+    assert np.array_equal(rows_a, rows_b)
+    for k in bev_a:
+        if not k.startswith('trajs'):
+            assert np.array_equal(bev_a[k].view(np.uint16), bev_b[k].view(np.uint16)), k
+    rd = acc.read_compressed_pickle
+    sync, a, b = rd(str(tmp_path / 'sync' / 'a.pkl.gz')), rd(str(tmp_path / 'async' / 'a.pkl.gz')), rd(str(tmp_path / 'async' / 'b.pkl.gz'))
+    assert set(sync) == set(a) == set(b)
+    for k in sync:
+        if not k.startswith('trajs'):
+            assert np.array_equal(sync[k], a[k]) and np.array_equal(sync[k], b[k]), k
+    # composed label table == the reference's sequential remap
+    from datasets.kitti360_utils import conv_semantic_ids
+    table, lo = compose_label_lut(base.idx2idx)
+    ids = np.arange(-1, 46, dtype=np.int16)[:, None]
+    assert np.array_equal(table[:47], conv_semantic_ids(ids.copy(), base.idx2idx)[:, 0])
