@@ -55,7 +55,7 @@ class PrefetchingLoader:
         img, pc, sem_gt = obs
         host_img = np.ascontiguousarray(np.asarray(img), dtype=np.uint8)
         pin = [torch.from_numpy(np.ascontiguousarray(pc, dtype=np.float32)).pin_memory(),
-               torch.from_numpy(host_img).pin_memory(),
+               torch.from_numpy(host_img.copy()).pin_memory(),
                torch.from_numpy(np.ascontiguousarray(np.asarray(sem_gt)[:, -1]).astype(np.uint8)).pin_memory()]
         with torch.cuda.stream(self.stream):
             dev = [t.to(self.device, non_blocking=True) for t in pin]
