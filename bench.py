@@ -62,6 +62,58 @@ def synth_frame(seq, frame):
     return pc, img, sem
 
 
+N_BEAMS, N_AZ = 64, 1875                  # ring model: 64 x 1875 = 120 000 returns per revolution
+SENSOR_H = 1.73
+
+
+def ring_frame(seq, frame):
+    """Ring-model frame: a 64-beam spinning lidar over a ground plane with boxes (parked cars,
+    facades) -- point density falls off as 1/r^2, so the cells next to the driven path hold hundreds to
+    thousands of points.  This is the contention / load-imbalance case; the uniform K-shape frame is the
+    throughput case.  The street scene slides by 1 m per frame."""
+    rng = np.random.default_rng(1000 * seq + frame + 500_000)
+    az = np.repeat(np.linspace(-np.pi, np.pi, N_AZ, endpoint=False)[None], N_BEAMS, 0).ravel()
+    el = np.repeat(np.deg2rad(np.linspace(2.0, -24.8, N_BEAMS))[:, None], N_AZ, 1).ravel()
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], 1)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        t = np.where(d[:, 2] < 0, -SENSOR_H / d[:, 2], np.inf)
+    kind = np.zeros(len(t), np.int8)                                 # 0 ground, 1 car, 2 facade
+    shift = float(frame % 25)
+    boxes = []
+    for j in range(-4, 5):
+        x0 = 25.0 * j - shift
+        boxes += [(x0, 12.0, 9.0, 3.0, 8.0, 2), (x0 + 12.5, -12.0, 9.0, 3.0, 8.0, 2)]          # facades
+        boxes += [(x0 + 5.0, 4.6, 2.2, 0.9, 1.5, 1), (x0 + 17.0, -4.6, 2.2, 0.9, 1.5, 1)]        # parked cars
+    for cx, cy, hx, hy, h, kd in boxes:
+        lo = np.array([cx - hx, cy - hy, -SENSOR_H]); hi = np.array([cx + hx, cy + hy, -SENSOR_H + h])
+        with np.errstate(divide='ignore', invalid='ignore'):
+            t1 = lo / d; t2 = hi / d
+        tn = np.nanmax(np.minimum(t1, t2), 1); tf = np.nanmin(np.maximum(t1, t2), 1)
+        hit = (tn <= tf) & (tn > 0) & (tn < t)
+        t = np.where(hit, tn, t); kind[hit] = kd
+    miss = ~np.isfinite(t) | (t > 80.0)
+    t = np.where(miss, 80.0, t) + rng.normal(0, 0.02, len(t))
+    xyz = d * t[:, None]
+    inten = np.where(kind == 0, 0.3, 0.5) + rng.normal(0, 0.03, len(t))
+    lane = (kind == 0) & ((np.abs(np.abs(xyz[:, 1]) - 1.75) < 0.1))
+    inten = np.clip(np.where(lane, 0.9, inten), 0, 1)
+    pc = np.concatenate([xyz, inten[:, None]], 1).astype(np.float32)
+    # image-space semantics: road trapezoid / sidewalk below the horizon row, facades + vegetation + sky above, cars
+    v, u = np.mgrid[0:IMG_H, 0:IMG_W]
+    sem = np.full((IMG_H, IMG_W), 2, np.uint8)
+    sem[(v < 120)] = 10
+    sem[(v >= 120) & (v < 200) & ((u // 64) % 3 == 0)] = 8
+    below = v > 238
+    half = 60 + (v - 238) * 6.0
+    sem[below] = 1
+    sem[below & (np.abs(u - 682) < half)] = 0
+    for cu in (250, 1100):
+        sem[250:300, cu:cu + 120] = 13
+    palette = rng.integers(0, 256, (256, 3), dtype=np.uint8)
+    img = (palette[sem].astype(np.int16) + rng.integers(-8, 9, (IMG_H, IMG_W, 3))).clip(0, 255).astype(np.uint8)
+    return pc, img, sem
+
+
 class ResidentSemSeg:
     """Stand-in for the external ONNX CNN (not part of the hot path): hands back the semseg map that is
     already resident in HBM for the image it is asked about."""
@@ -84,6 +136,74 @@ def present_index(acc):
     if d[-1] - d[idx] < BEV_HORIZON_M:
         return None
     return idx
+
+
+def make_accumulator(frame_fn, seq):
+    """Drop-in accumulator over a pool of synthetic frames resident in HBM."""
+    import torch
+    import sem_pc_accum
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    model = ResidentSemSeg()
+    sem_pc_accum.SemSegONNX = lambda path: model
+    bev_params = dict(type='sem', view_size=VIEW_M, pixel_size=PX, max_trans_radius=0., zoom_thresh=0., do_warp=False,
+                      int_scaler=20., int_sep_scaler=20., int_mid_threshold=0.5, height_filter=None)
+    calib = {'h_velo_cam': np.linalg.inv(CAM_TO_VELO), 'p_cam_frame': P_RECT, 'p_velo_frame': P_VELO_FRAME}
+    acc = Kitti360SemanticPointCloudAccumulator(HORIZON_M, calib, 1e3, 'resident', FILTERS, SEM_IDXS, False, bev_params)
+    acc._store_args = dict(capacity=1 << 26, max_frames=1 << 14)
+    T = t_new_prev()
+    acc.pose_provider = lambda pc: T
+    pool = []
+    for k in range(POOL):
+        pc, img, sem = frame_fn(seq, k)
+        f = (torch.from_numpy(img).cuda(), torch.from_numpy(pc).cuda(), torch.from_numpy(sem).cuda())
+        model.by_ptr[f[0].data_ptr()] = f[2]
+        pool.append(f)
+    return acc, pool, model
+
+
+def ring_model_pass(steps):
+    """The same step on ring-model frames (rank 0 only, after the headline measurement): steady-state time per
+    step and per-kernel HIP-event times.  Reported beside the headline number, never as `value`."""
+    import torch
+    from pca_amd import _lib
+    acc, pool, _ = make_accumulator(ring_frame, 0)
+    n = [0]
+
+    def step(out=None):
+        rgb, pc, _ = pool[n[0] % POOL]
+        n[0] += 1
+        acc.integrate([(rgb, pc, None)])
+        idx = present_index(acc)
+        if idx is None:
+            return
+        pcs, trajs = acc._window_inputs(idx, True)
+        acc.sem_bev_generator.generate(pcs, trajs, device_only=True, out=out)
+
+    while present_index(acc) is None or len(acc.poses) < 195:
+        step()
+    out = torch.empty((21, PX, PX), dtype=torch.float16, device='cuda')
+    for _ in range(5):
+        step(out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx = _lib.Context.get()
+    ctx.profile(True)
+    for _ in range(steps):
+        step(out)
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    acc.store.check_status()
+    stored = int(acc.store.offsets()[-1] - acc.store.offsets()[0])
+    occ = out[14].float()                                  # road plane of 'full': != 0.5 where a cell was observed
+    return {'Mpoints_per_s': N_PTS * steps / dt / 1e6, 'bev_frames_per_s': steps / dt, 'ms_per_step': 1e3 * dt / steps,
+            'steps': steps, 'stored_pts': stored, 'live_frames': acc.store.n_frames,
+            'observed_cells': int((occ != 0.5).sum().item()),
+            'kernels_avg_us': {k: 1e3 * v[0] / v[1] for k, v in prof.items() if v[1]},
+            'note': '64 beams x 1875 azimuths over a ground plane with boxes; density ~1/r^2 (contention case)'}
 
 
 def cpu_baseline(steps=20):
@@ -142,6 +262,9 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--scene', choices=['uniform', 'ring'], default='uniform',
+                    help='uniform = SURVEY 8d K-shape frame (headline); ring = 64-beam ring model')
+    ap.add_argument('--no-ring', action='store_true', help='skip the additional ring-model pass')
     args = ap.parse_args()
 
     import torch
@@ -162,27 +285,10 @@ def main():
             dist.init_process_group(backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
-    import sem_pc_accum
-    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
     from pca_amd import _lib
-
-    model = ResidentSemSeg()
-    sem_pc_accum.SemSegONNX = lambda path: model
-    bev_params = dict(type='sem', view_size=VIEW_M, pixel_size=PX, max_trans_radius=0., zoom_thresh=0., do_warp=False,
-                      int_scaler=20., int_sep_scaler=20., int_mid_threshold=0.5, height_filter=None)
-    calib = {'h_velo_cam': np.linalg.inv(CAM_TO_VELO), 'p_cam_frame': P_RECT, 'p_velo_frame': P_VELO_FRAME}
-    acc = Kitti360SemanticPointCloudAccumulator(HORIZON_M, calib, 1e3, 'resident', FILTERS, SEM_IDXS, False, bev_params)
-    acc._store_args = dict(capacity=1 << 26, max_frames=1 << 14)
-    T = t_new_prev()
-    acc.pose_provider = lambda pc: T
-
+    frame_fn = ring_frame if args.scene == 'ring' else synth_frame
     # ---- inputs resident in HBM: every rank works on its own sequence (scene shard) ----
-    pool = []
-    for k in range(POOL):
-        pc, img, sem = synth_frame(rank, k)
-        f = (torch.from_numpy(img).cuda(), torch.from_numpy(pc).cuda(), torch.from_numpy(sem).cuda())
-        model.by_ptr[f[0].data_ptr()] = f[2]
-        pool.append(f)
+    acc, pool, model = make_accumulator(frame_fn, rank)
 
     import builtins
     real_print = builtins.print
@@ -287,6 +393,9 @@ def main():
     ctx.profile(False)
     k1b_kept = int(tmp.offsets()[-1])
     del tmp
+    ring = None
+    if rank == 0 and not args.no_ring and args.scene == 'uniform':
+        ring = ring_model_pass(min(args.steps, 50))
     builtins.print = real_print
 
     if rank != 0:
@@ -308,7 +417,7 @@ def main():
         'kitti_project_sample_filter': 16.0 * N_PTS + 4.0 * m_proj + 40.0 * m_kept,
         'bev': 40.0 * stored + 21.0 * PX * PX * 4.0 + (48.0 * (stored - sizes[-1]) if k2_fused else 0.0),
     }
-    bev_us = sum(kern[k]['avg_us'] for k in ('bev_bin', 'bev_scan', 'bev_scatter', 'bev_cells') if k in kern)
+    bev_us = sum(kern[k]['avg_us'] for k in ('bev_bin', 'bev_scan', 'bev_scatter', 'bev_cells', 'bev_cells_heavy') if k in kern)
     units = {'kitti_project_sample_filter': kern['kitti_project_sample_filter']['avg_us'], 'bev': bev_us}
     if not k2_fused:
         alg['retransform'] = 48.0 * stored
@@ -363,6 +472,8 @@ def main():
                            'ms_per_step': 1e3 * host_elapsed / n_host, 'steps': n_host,
                            'note': 'host numpy inputs (4 MB H2D per frame) and host fp16 BEV dict (2.75 MB D2H) per step'},
     }
+    if ring is not None:
+        out['ring_model'] = ring
     if not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))

@@ -50,6 +50,7 @@ typedef struct {
 /* status bits accumulated on the device, read back with pca_status() */
 #define PCA_STATUS_STORE_OVERFLOW 1u /* a kernel wanted to write past store.capacity (points dropped)     */
 #define PCA_STATUS_UV_OUT_OF_IMAGE 2u /* NuScenes: pixel coords outside (1, wh-1): reference AssertionError */
+#define PCA_STATUS_NEGATIVE_INTENSITY 4u /* BEV: a negative f32 intensity (pass intensity64 for such data)   */
 
 int pca_version(void);
 int pca_ctx_create(int device, pca_ctx **out);
@@ -167,6 +168,18 @@ int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensi
                      void *workspace /*dev*/, int64_t workspace_bytes, double *planes /*dev*/,
                      uint16_t *planes_f16 /*dev*/, void *stream);
 
+/* Same rasteriser with EXTRA REDUCERS (opt-in; the reference's live code has none of them -- mean elevation /
+ * mean intensity exist only in its unused legacy utils/bev_generation.py:249-294).  extra_planes: dev f64
+ * [3 sets][PCA_BEV_EXTRA_PLANES][px][px], per set {max z, mean z} over the static points of a cell (0 where
+ * unobserved, like the elevation plane) and {mean raw intensity} over its road points (0 where none).
+ * Sums are exact fixed-point integers: the result does not depend on the order of the points. */
+#define PCA_BEV_EXTRA_PLANES 3
+int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *intensity64,
+                        const int64_t *frame_off /*dev*/, int slot_begin, int slot_split, int slot_end,
+                        int64_t max_points, const pca_bev_params *prm, const double *pending_T, int pending_slot_end,
+                        void *workspace /*dev*/, int64_t workspace_bytes, double *planes /*dev*/,
+                        uint16_t *planes_f16 /*dev*/, double *extra_planes /*dev, may be NULL*/, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Optional per-kernel timing: while enabled every kernel launch is bracketed by HIP events recorded on
  * the call's stream.  pca_profile_read synchronises, returns the accumulated time / launch count of one
@@ -174,7 +187,7 @@ int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensi
  * ------------------------------------------------------------------------------------------------ */
 enum {
     PCA_K_KITTI = 0, PCA_K_NUSC, PCA_K_PROJECT_CAMS, PCA_K_RETRANSFORM, PCA_K_MARK_DYNAMIC,
-    PCA_K_BEV_BIN, PCA_K_BEV_SCAN, PCA_K_BEV_SCATTER, PCA_K_BEV_CELLS, PCA_K_COUNT
+    PCA_K_BEV_BIN, PCA_K_BEV_SCAN, PCA_K_BEV_SCATTER, PCA_K_BEV_CELLS, PCA_K_BEV_CELLS_HEAVY, PCA_K_COUNT
 };
 int pca_profile_enable(pca_ctx *ctx, int on);
 int pca_profile_read(pca_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);

@@ -61,14 +61,9 @@ __device__ __forceinline__ TileScan tile_compact(const bool keep[PPT], uint64_t 
     __syncthreads();
     if (wave == 0) {
         const uint32_t v = lane < PPT * NW ? s_wtot[lane] : 0u;
-        uint32_t inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
+        const uint32_t inc = wave_incl_scan_add(v);
         if (lane < PPT * NW) s_woff[lane] = inc - v;
-        const uint32_t total = __shfl(inc, 63, 64);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         if (lane == 0) s_woff[PPT * NW] = total;
         const uint64_t e = skip_lookback ? 0 : lb_exclusive_prefix(state, tile, (uint64_t)total, epoch);
         if (lane == 0) s_excl = e;
@@ -359,12 +354,7 @@ __global__ __launch_bounds__(BLK) void k1_kitti_persistent(const K1Args a)
             __syncthreads();
             if (wave == 0) {
                 const uint32_t v = lane < PPT * NW ? s_wtot[lane] : 0u;
-                uint32_t inc = v;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t t = __shfl_up(inc, o, 64);
-                    if (lane >= o) inc += t;
-                }
+                const uint32_t inc = wave_incl_scan_add(v);
                 if (lane < PPT * NW) s_woff[lane] = inc - v;
                 if (lane == 63) {
                     s_woff[PPT * NW] = inc;
@@ -687,7 +677,7 @@ int pca_kitti_project_sample_filter(pca_ctx *ctx, const pca_kitti_frame *frames,
     // 48 KB LDS and 70 VGPRs each); a single frame (fewer tiles than that) runs one tile per workgroup
     const bool legacy = getenv("PCA_K1_LEGACY") != nullptr;
     if (!legacy && k1_blk() == 512) {
-        const int resident = 256 * 3;
+        const int resident = ctx->n_cu * 3;
         const int grid = total < resident ? total : resident;
         a.ticket64 = ctx->ticket64;
         a.ticket_base = ctx->ticket64_base;

@@ -85,6 +85,8 @@ int pca_ctx_create(int device, pca_ctx **out)
         delete ctx;
         return -1;
     }
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) ctx->n_cu = n_cu;
     *out = ctx;
     return 0;
 }

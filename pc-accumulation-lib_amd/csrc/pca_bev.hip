@@ -8,10 +8,12 @@
 //     bev_tile_scatter  records {z, intensity, rgb|flags, fine key} -> tile-ordered SoA streams; the position
 //                       comes from an LDS cursor per tile (returning LDS atomics)
 //   level 2 (one workgroup per tile)
-//     bev_tile_cells    pass 1: per (cell,set) counts / exact integer intensity sums / min z by LDS atomics;
-//                       pass 2: LDS counting sort of the colours by (cell,set); per-cell exact medians
-//                       (n <= 64: bit-sliced radix select, one lane per target; else 256-bin LDS histogram);
-//                       closed-form maps, fp16, tile written back.
+//     bev_tile_cells    tiles of at most RGB_CAP records.  pass 1: per (cell,set) counts / exact integer intensity
+//                       sums / min z by LDS atomics; pass 2: LDS counting sort of the colours by (cell,set); exact
+//                       medians per cell (n <= 64: bit-sliced radix select, one lane per target; else a per-wave
+//                       256-bin histogram); closed-form maps, fp16, tile written back.
+//     bev_tile_cells_heavy  the other tiles: 1024 threads, 256-bin histograms of 32 cells at a time filled
+//                       straight from the record stream (two passes over the tile's records, no sort).
 // 'full' = present (+) future is formed per cell (counts add, min of mins, median of the union).
 #include "pca_bev_common.h"
 #include <cstdlib>
@@ -27,9 +29,13 @@
 #define FLAG_ROAD (1u << 24)
 #define FLAG_DYNOBJ (1u << 25)
 
-// tile-ordered records: one packed stream (5 or 6 dwords) so that a (workgroup, tile) run is one contiguous write
-struct __attribute__((packed, aligned(4))) RecF { double z; float inten; uint32_t c; uint32_t fk; };   // 20 B
-struct RecD { double z; double inten; uint32_t c; uint32_t fk; };                                      // 24 B
+// tile-ordered records: one packed stream so that a (workgroup, tile) run is one contiguous write.
+// RecF is exactly one 16-byte access (a 20-byte record cost five strided dword loads per lane: the texture
+// addresser, not HBM, then bounds the per-tile passes):
+//   iw = f32 intensity bits (sign bit is free: intensities are >= 0) | set << 31
+//   cw = r | g<<8 | b<<16 | FLAG_ROAD | FLAG_DYNOBJ | cell_in_tile << 26
+struct __attribute__((aligned(16))) RecF { double z; uint32_t iw; uint32_t cw; };                     // 16 B
+struct RecD { double z; double inten; uint32_t c; uint32_t fk; };                                      // 24 B (f64 intensities)
 
 struct BevArgs {
     pca_store st;
@@ -45,13 +51,16 @@ struct BevArgs {
     uint32_t *bh;         // [T][G] kept records per (tile, workgroup)
     uint32_t *boff;       // [T][G] exclusive scan of bh in that order
     uint32_t *tile_off;   // [T+1]
+    uint32_t *heavy;      // [2+T]: count, cursor, ids of the tiles bev_tile_cells leaves to bev_tile_cells_heavy
     void *recs;           // RecF / RecD [max_points], tile-ordered; c = r | g<<8 | b<<16 | FLAG_*
     double *planes;
     uint16_t *planes_f16;
+    double *extra;        // [3 sets][PCA_BEV_EXTRA_PLANES][px][px] or NULL
     uint64_t *state;
     uint32_t *ticket;
     uint32_t epoch;
     int scan_tiles;
+    int dbg;
 };
 
 struct Window { int64_t lo, hi, sp, c_lo, c_hi; };
@@ -153,6 +162,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void bev_tile_scan(const BevArgs a)
     __shared__ uint32_t s_w[SCAN_THREADS / 64];
     __shared__ uint64_t s_excl;
     const int n = a.T * a.G;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { a.heavy[0] = 0; a.heavy[1] = 0; }
     if (threadIdx.x == 0) {
         const uint32_t t = atomicAdd(a.ticket, 1u);
         if ((int)t == a.scan_tiles - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -166,24 +176,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void bev_tile_scan(const BevArgs a)
 #pragma unroll
     for (int k = 0; k < 4; ++k) c[k] = (base + k < n) ? a.bh[base + k] : 0u;
     const uint32_t tsum = c[0] + c[1] + c[2] + c[3];
-    uint32_t inc = tsum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-    }
+    const uint32_t inc = wave_incl_scan_add(tsum);
     if (lane == 63) s_w[wave] = inc;
     __syncthreads();
     if (wave == 0) {
         const uint32_t v = lane < SCAN_THREADS / 64 ? s_w[lane] : 0u;
-        uint32_t winc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(winc, o, 64);
-            if (lane >= o) winc += t;
-        }
+        const uint32_t winc = wave_incl_scan_add(v);
         if (lane < SCAN_THREADS / 64) s_w[lane] = winc - v;                // exclusive wave offsets
-        const uint32_t total = __shfl(winc, 63, 64);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)winc, 63);
         const uint64_t e = lb_exclusive_prefix(a.state, tile, (uint64_t)total, a.epoch);
         if (lane == 0) s_excl = (e << 32) | total;                          // both fit 32 bits (checked by the host)
     }
@@ -245,7 +245,11 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_scatter(const BevArgs a)
                 RecD r; r.z = z; r.inten = iv[u]; r.c = c; r.fk = key[u] & 127u;
                 reinterpret_cast<RecD *>(a.recs)[pos[u]] = r;
             } else {
-                RecF r; r.z = z; r.inten = (float)iv[u]; r.c = c; r.fk = key[u] & 127u;
+                const float fi = (float)iv[u];
+                if (fi < 0.0f) atomicOr(a.ticket + 1, PCA_STATUS_NEGATIVE_INTENSITY);
+                RecF r; r.z = z;
+                r.iw = (__float_as_uint(fi) & 0x7fffffffu) | ((key[u] & 1u) << 31);
+                r.cw = c | (((key[u] & 127u) >> 1) << 26);
                 reinterpret_cast<RecF *>(a.recs)[pos[u]] = r;
             }
         }
@@ -253,14 +257,220 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_scatter(const BevArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// level 2: one workgroup per tile
+// level 2: one workgroup per tile.  Tiles whose records fit the LDS colour buffer take bev_tile_cells (256
+// threads, 4 workgroups per CU); the others -- the cells next to the driven path of a real accumulation hold
+// hundreds to thousands of points -- take bev_tile_cells_heavy (1024 threads, direct 256-bin histograms).
 // ---------------------------------------------------------------------------------------------
-struct TileLds {
-    uint32_t cnt[NFK], road[NFK], dyn[NFK], off[NFK + 1], cur[NFK];
+struct TileStats {
+    uint32_t cnt[NFK], road[NFK], dyn[NFK];
     unsigned long long ihi[NFK], ilo[NFK], zk[NFK];
+    unsigned long long zmaxk[NFK], zhi[NFK], zlo[NFK];      // extra reducers (max z, exact sum of z): only with a.extra
     uint32_t med2[3][TCELLS][3];                            // [present, future, full][cell][channel]
-    uint32_t hist[3][256];                                  // cells with more than 64 values
-    unsigned long long bits[TCELLS][24];                    // cells with <= 64 values: one 64-lane mask per colour bit
+};
+
+__device__ __forceinline__ void stats_init(TileStats &S, int nthreads)
+{
+    for (int k = threadIdx.x; k < NFK; k += nthreads) {
+        S.cnt[k] = 0; S.road[k] = 0; S.dyn[k] = 0; S.ihi[k] = 0; S.ilo[k] = 0; S.zk[k] = ~0ull;
+        S.zmaxk[k] = 0; S.zhi[k] = 0; S.zlo[k] = 0;
+    }
+    for (int k = threadIdx.x; k < 3 * TCELLS * 3; k += nthreads) (&S.med2[0][0][0])[k] = 0;
+}
+
+// Per (cell,set) statistics of the records a wave holds one per lane; returns each record's rank inside its
+// (cell,set).  Records that arrive together are neighbours in space (consecutive lidar returns), so in a real
+// accumulation most of a wave shares one (cell,set) -- and 64 LDS atomics on one address cost 2 cycles per lane on
+// the CU's only LDS pipe (tools/experiments/lds_atomics.hip).  Groups of at least AGG_MIN lanes holding the leading
+// lane's key are therefore reduced on the VALU (DPP) and accounted by one lane; what is left takes per-lane atomics.
+// Must be called by the whole wave (valid = this lane holds a record).
+#define AGG_MIN 12
+__device__ __forceinline__ uint32_t stats_account_wave(TileStats &S, bool extra, bool valid, uint32_t k, uint32_t c, double z,
+                                                       double iv)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long zkey = f64_order_key(z);
+    const bool road = valid && (c & FLAG_ROAD), dynobj = valid && (c & FLAG_DYNOBJ);
+    long long ihi = 0, ilo = 0;
+    if (road) {
+        const double sc = iv * FX_HI, fl = floor(sc);
+        ihi = (long long)fl;
+        ilo = (long long)rint((sc - fl) * FX_LO);
+    }
+    uint32_t rank = 0;
+    uint64_t todo = __ballot(valid);
+    for (int round = 0; round < 4 && todo; ++round) {
+        const int lead = (int)__ffsll((unsigned long long)todo) - 1;
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)k, lead);
+        const bool in = ((todo >> lane) & 1ull) && k == k0;
+        const uint64_t m = __ballot(in);
+        const uint32_t g = (uint32_t)__popcll(m);
+        const uint64_t rm = __ballot(in && road);
+        // sums are formed in 32-bit pieces: ihi below 2^25 per record (intensity < 32), ilo <= 2^40 in two 20-bit halves
+        if (g < AGG_MIN || __ballot(in && road && ((unsigned long long)ihi >> 25) != 0)) break;
+        const uint32_t zh = (uint32_t)(zkey >> 32), zl = (uint32_t)zkey;
+        const uint32_t mh = wave_reduce_min(in ? zh : 0xffffffffu);
+        const uint32_t ml = wave_reduce_min(in && zh == mh ? zl : 0xffffffffu);
+        uint32_t s_ihi = 0, s_il0 = 0, s_il1 = 0;
+        if (rm) {
+            const bool r = in && road;
+            s_ihi = wave_reduce_add(r ? (uint32_t)ihi : 0u);
+            s_il0 = wave_reduce_add(r ? (uint32_t)ilo & 0xfffffu : 0u);
+            s_il1 = wave_reduce_add(r ? (uint32_t)((unsigned long long)ilo >> 20) : 0u);
+        }
+        const uint32_t n_dyn = (uint32_t)__popcll(__ballot(in && dynobj));
+        uint32_t base = 0;
+        if (lane == lead) {
+            base = atomicAdd(&S.cnt[k0], g);
+            atomicMin(&S.zk[k0], ((unsigned long long)mh << 32) | ml);
+            if (n_dyn) atomicAdd(&S.dyn[k0], n_dyn);
+            if (rm) {
+                atomicAdd(&S.road[k0], (uint32_t)__popcll(rm));
+                atomicAdd(&S.ihi[k0], (unsigned long long)s_ihi);
+                atomicAdd(&S.ilo[k0], ((unsigned long long)s_il1 << 20) + s_il0);
+            }
+        }
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, lead);
+        if (in) rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (extra && in) {
+            const double sc = z * FX_HI, fl = floor(sc);
+            atomicMax(&S.zmaxk[k], zkey);
+            atomicAdd(&S.zhi[k], (unsigned long long)(long long)fl);
+            atomicAdd(&S.zlo[k], (unsigned long long)(long long)rint((sc - fl) * FX_LO));
+        }
+        todo &= ~m;
+    }
+    if ((todo >> lane) & 1ull) {
+        rank = atomicAdd(&S.cnt[k], 1u);
+        atomicMin(&S.zk[k], zkey);
+        if (extra) {
+            const double sc = z * FX_HI, fl = floor(sc);
+            atomicMax(&S.zmaxk[k], zkey);
+            atomicAdd(&S.zhi[k], (unsigned long long)(long long)fl);
+            atomicAdd(&S.zlo[k], (unsigned long long)(long long)rint((sc - fl) * FX_LO));
+        }
+        if (dynobj) atomicAdd(&S.dyn[k], 1u);
+        if (road) {
+            atomicAdd(&S.road[k], 1u);
+            atomicAdd(&S.ihi[k], (unsigned long long)ihi);
+            atomicAdd(&S.ilo[k], (unsigned long long)ilo);
+        }
+    }
+    return rank;
+}
+
+template <bool I64>
+__device__ __forceinline__ void load_rec(const BevArgs &a, uint32_t r, uint32_t &k, uint32_t &c, double &z, double &iv)
+{
+    if (I64) {
+        const RecD rec = reinterpret_cast<const RecD *>(a.recs)[r];
+        k = rec.fk; c = rec.c; z = rec.z; iv = rec.inten;
+    } else {
+        const RecF rec = reinterpret_cast<const RecF *>(a.recs)[r];
+        k = ((rec.cw >> 26) << 1) | (rec.iw >> 31);
+        c = rec.cw & 0x03ffffffu;
+        z = rec.z;
+        const double raw = (double)__uint_as_float(rec.iw & 0x7fffffffu);
+        iv = a.prm.intensity_div255 ? raw / 255.0 : raw;
+    }
+}
+// fine key and colour only
+template <bool I64>
+__device__ __forceinline__ void load_rec_key_colour(const BevArgs &a, uint32_t r, uint32_t &k, uint32_t &c)
+{
+    if (I64) {
+        const RecD *rec = reinterpret_cast<const RecD *>(a.recs) + r;
+        k = rec->fk; c = rec->c & 0xffffffu;
+    } else {
+        const uint2 w = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(a.recs) + (size_t)r * 16 + 8);
+        k = ((w.y >> 26) << 1) | (w.x >> 31);
+        c = w.y & 0xffffffu;
+    }
+}
+
+// closed-form maps of the tile (thread -> (set, cell)), staged in LDS, then written row by row
+__device__ __forceinline__ void tile_finalize_write(const BevArgs &a, const TileStats &S, double (*s_out)[TCELLS], int tile,
+                                                    int nthreads)
+{
+    const pca_bev_params &q = a.prm;
+    const bool extra = a.extra != nullptr;
+    if (threadIdx.x < 3 * TCELLS) {
+        const int s = threadIdx.x / TCELLS, cell = threadIdx.x % TCELLS;
+        const int kp = 2 * cell, kf = 2 * cell + 1;
+        uint32_t n, n_r, n_d;
+        long long ihi, ilo, zhi, zlo;
+        unsigned long long zk, zmaxk;
+        if (s < 2) {
+            const int k = s ? kf : kp;
+            n = S.cnt[k]; n_r = S.road[k]; n_d = S.dyn[k]; ihi = (long long)S.ihi[k]; ilo = (long long)S.ilo[k];
+            zk = S.zk[k]; zmaxk = S.zmaxk[k]; zhi = (long long)S.zhi[k]; zlo = (long long)S.zlo[k];
+        } else {
+            n = S.cnt[kp] + S.cnt[kf]; n_r = S.road[kp] + S.road[kf]; n_d = S.dyn[kp] + S.dyn[kf];
+            ihi = (long long)S.ihi[kp] + (long long)S.ihi[kf];
+            ilo = (long long)S.ilo[kp] + (long long)S.ilo[kf];
+            zk = S.zk[kp] < S.zk[kf] ? S.zk[kp] : S.zk[kf];
+            zmaxk = S.zmaxk[kp] > S.zmaxk[kf] ? S.zmaxk[kp] : S.zmaxk[kf];
+            zhi = (long long)S.zhi[kp] + (long long)S.zhi[kf];
+            zlo = (long long)S.zlo[kp] + (long long)S.zlo[kf];
+        }
+        double o[7];
+        finalize_cell(q, n, n_r, n_d, ihi, ilo, n ? f64_from_order_key(zk) : 0.0, S.med2[s][cell], o);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s_out[7 * s + k][cell] = o[k];
+        if (extra) {
+            const double isum = (double)ihi * FX_HI_INV + (double)ilo * FX_LO_INV;
+            const double zsum = (double)zhi * FX_HI_INV + (double)zlo * FX_LO_INV;
+            s_out[21 + 3 * s + 0][cell] = n ? f64_from_order_key(zmaxk) : 0.0;
+            s_out[21 + 3 * s + 1][cell] = n ? zsum / (double)n : 0.0;
+            s_out[21 + 3 * s + 2][cell] = n_r ? isum / (double)n_r : 0.0;
+        }
+    }
+    __syncthreads();
+    const int row0 = (tile / a.tx) * TS, col0 = (tile % a.tx) * TS;
+    const int64_t ncell = (int64_t)q.px * q.px;
+    const int n_planes = extra ? 21 + PCA_BEV_EXTRA_PLANES * 3 : 21;
+    for (int idx = threadIdx.x; idx < n_planes * TCELLS; idx += nthreads) {
+        const int plane = idx / TCELLS, lc = idx % TCELLS;
+        const int row = row0 + lc / TS, col = col0 + lc % TS;
+        if (row >= q.px || col >= q.px) continue;
+        const double v = s_out[plane][lc];
+        if (plane < 21) {
+            const int64_t o = (int64_t)plane * ncell + (int64_t)row * q.px + col;
+            if (a.planes) a.planes[o] = v;
+            if (a.planes_f16) a.planes_f16[o] = f64_to_f16_bits(v);
+        } else {
+            a.extra[(int64_t)(plane - 21) * ncell + (int64_t)row * q.px + col] = v;
+        }
+    }
+}
+#define OUT_STAGE_BYTES ((21 + 3 * PCA_BEV_EXTRA_PLANES) * TCELLS * 8)
+
+// ---- medians from 16-bit-packed 256-bin histograms (bin b = half b&1 of dword b>>1), one wave ----------------
+__device__ __forceinline__ uint4 hist16_bins(const uint32_t *row)
+{
+    const uint2 w = reinterpret_cast<const uint2 *>(row)[threadIdx.x & 63];
+    return make_uint4(w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16);
+}
+__device__ __forceinline__ void hist16_add(uint32_t *row, unsigned val, uint32_t times)
+{
+    atomicAdd(&row[val >> 1], times << (16 * (val & 1)));
+}
+// present / future / full medians of one (cell, channel) from its two packed histograms
+__device__ __forceinline__ void hist16_medians(TileStats &S, const uint32_t *row_p, const uint32_t *row_f, int cell, int ch,
+                                               uint32_t n_p, uint32_t n_f)
+{
+    const uint4 p = hist16_bins(row_p), f = hist16_bins(row_f);
+    const uint4 u = make_uint4(p.x + f.x, p.y + f.y, p.z + f.z, p.w + f.w);
+    const uint32_t m_p = hist_med2_regs(p, n_p), m_f = hist_med2_regs(f, n_f), m_u = hist_med2_regs(u, n_p + n_f);
+    if ((threadIdx.x & 63) == 0) { S.med2[0][cell][ch] = m_p; S.med2[1][cell][ch] = m_f; S.med2[2][cell][ch] = m_u; }
+}
+
+struct TileLds {
+    TileStats S;
+    uint32_t off[NFK + 1];
+    union {
+        unsigned long long bits[TCELLS][24];                // cells with <= 64 values: one 64-lane mask per colour bit
+        uint32_t whist[C_THREADS / 64][2][3][128];          // cells with more: per-wave packed histograms [set][channel]
+    };
 };
 
 // ---- medians of cells with at most 64 values: bit-sliced radix select -------------------------------------
@@ -269,15 +479,14 @@ struct TileLds {
 // Phase 2 (per wave): one LANE per (cell, set, channel, lower|upper middle) target -- 18 per cell -- walks the 8
 // bit planes from the top: zeros = cand & ~plane; rank < popcount(zeros) ? keep zeros : (rank -= ..., keep ones,
 // set the bit).  That is ~12 VALU per plane for 64 targets at once instead of a 21-stage sort per channel.
-__device__ __forceinline__ void small_cells_bitplanes(TileLds &L, const uint32_t *s_rgb, uint32_t base, int c_begin, int c_end)
+__device__ __forceinline__ void small_cells_bitplanes(TileLds &L, const uint32_t *s_rgb)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = 0; i < TCELLS / 4; ++i) {
         const int cell = 4 * i + wave;
-        if (cell < c_begin || cell >= c_end) continue;
-        const uint32_t n = L.cnt[2 * cell] + L.cnt[2 * cell + 1];
+        const uint32_t n = L.S.cnt[2 * cell] + L.S.cnt[2 * cell + 1];
         if (n == 0 || n > 64) continue;
-        const uint32_t v = (uint32_t)lane < n ? s_rgb[L.off[2 * cell] - base + lane] : 0u;
+        const uint32_t v = (uint32_t)lane < n ? s_rgb[L.off[2 * cell] + lane] : 0u;
         unsigned long long mine = 0;
 #pragma unroll
         for (int b = 0; b < 24; ++b) {
@@ -288,7 +497,7 @@ __device__ __forceinline__ void small_cells_bitplanes(TileLds &L, const uint32_t
     }
 }
 
-__device__ __forceinline__ void small_cells_select(TileLds &L, int c_begin, int c_end)
+__device__ __forceinline__ void small_cells_select(TileLds &L)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NT = (TCELLS / 4) * 18;                   // targets of one wave
@@ -297,9 +506,9 @@ __device__ __forceinline__ void small_cells_select(TileLds &L, int c_begin, int 
         const int i = t / 18, qq = t - 18 * i;
         const int cell = 4 * i + wave;
         const int set = qq / 6, ch = (qq % 6) >> 1, upper = qq & 1;
-        bool ok = t < NT && cell >= c_begin && cell < c_end;
+        bool ok = t < NT;
         uint32_t n_p = 0, n_f = 0;
-        if (ok) { n_p = L.cnt[2 * cell]; n_f = L.cnt[2 * cell + 1]; }
+        if (ok) { n_p = L.S.cnt[2 * cell]; n_f = L.S.cnt[2 * cell + 1]; }
         const uint32_t n = n_p + n_f;
         ok = ok && n > 0 && n <= 64;
         const unsigned long long m_p = n_p >= 64 ? ~0ull : ((1ull << n_p) - 1ull);
@@ -322,263 +531,242 @@ __device__ __forceinline__ void small_cells_select(TileLds &L, int c_begin, int 
                 val |= take0 ? 0u : (1u << b);
             }
         }
-        const uint32_t other = __shfl_xor(val, 1, 64);      // the partner target (lower <-> upper middle) is the adjacent lane
-        if (ok && !upper) L.med2[set][cell][ch] = val + other;
+        // the partner target (lower <-> upper middle) is the adjacent lane: quad_perm [1,0,3,2]
+        const uint32_t other = dpp_or<0xb1>(0u, val);
+        if (ok && !upper) L.S.med2[set][cell][ch] = val + other;
     }
 }
 
-// adds the colours of one (cell,set) to the block histogram; values come from the LDS-sorted batch or,
-// for a cell too large for LDS, straight from the tile's record streams
-template <bool I64> __device__ __forceinline__ constexpr int REC_C() { return I64 ? 4 : 3; }
-template <bool I64> __device__ __forceinline__ constexpr int REC_FK() { return I64 ? 5 : 4; }
-template <bool I64>
-__device__ __forceinline__ const uint32_t *rec_words(const BevArgs &a, uint32_t r)
+// ---- cells with more than 64 values in a tile whose colours sit sorted in LDS: every wave takes cells on its
+// own (no workgroup barrier), histogramming into 16-bit counters (a fitting tile holds <= RGB_CAP values)
+__device__ __forceinline__ void wave_cells_hist(TileLds &L, const uint32_t *s_rgb)
 {
-    return reinterpret_cast<const uint32_t *>(a.recs) + (size_t)r * (I64 ? 6 : 5);
-}
-
-template <bool I64>
-__device__ __forceinline__ void hist_add(TileLds &L, const BevArgs &a, const uint32_t *s_rgb, bool from_lds, uint32_t fk,
-                                         uint32_t lds_base, uint32_t r_lo, uint32_t r_hi)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t n_iter = from_lds ? L.cnt[fk] : (r_hi - r_lo);
-    for (uint32_t i0 = 0; i0 < n_iter; i0 += C_THREADS) {
-        const uint32_t i = i0 + threadIdx.x;
-        bool act = i < n_iter;
-        uint32_t v = 0;
-        if (act) {
-            if (from_lds) v = s_rgb[lds_base + i];
-            else {
-                const uint32_t *w = rec_words<I64>(a, r_lo + i);
-                act = w[REC_FK<I64>()] == fk;
-                if (act) v = w[REC_C<I64>()];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *h = &L.whist[wave][0][0][0];
+    for (int i = 0; i < TCELLS / 4; ++i) {
+        const int cell = 4 * i + wave;
+        const uint32_t n_p = L.S.cnt[2 * cell], n_f = L.S.cnt[2 * cell + 1], n = n_p + n_f;
+        if (n <= 64) continue;
+        for (int k = lane; k < 2 * 3 * 128 / 4; k += 64) reinterpret_cast<uint4 *>(h)[k] = make_uint4(0, 0, 0, 0);
+        const uint32_t base = L.off[2 * cell];
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            const uint32_t idx = i0 + lane;
+            const bool act = idx < n;
+            const uint32_t v = act ? s_rgb[base + idx] : 0u;
+            const uint32_t set = idx >= n_p ? 1u : 0u;
+            // a wave of identical colours in one set (e.g. rgb == 0 with GT semantics) adds once per channel
+            const uint32_t tag = act ? (v | (set << 24)) : 0xffffffffu;
+            const uint32_t first = __builtin_amdgcn_readfirstlane(tag);
+            const uint64_t actm = __ballot(act);
+            if (__ballot(tag == first) == actm && first != 0xffffffffu) {
+                if (lane == (int)__ffsll((unsigned long long)actm) - 1) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch)
+                        hist16_add(&L.whist[wave][set][ch][0], (v >> (8 * ch)) & 255u, (uint32_t)__popcll(actm));
+                }
+            } else if (act) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) hist16_add(&L.whist[wave][set][ch][0], (v >> (8 * ch)) & 255u, 1u);
             }
         }
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const unsigned val = (v >> (8 * ch)) & 255u;
-            const unsigned key = act ? val : 0xffffffffu;
-            // an all-equal wave (e.g. rgb == 0 with GT semantics) adds once instead of conflicting 64 ways
-            const unsigned first = __builtin_amdgcn_readfirstlane(key);
-            const uint64_t same = __ballot(key == first), actm = __ballot(act);
-            if (actm && first != 0xffffffffu && same == actm) {
-                if (lane == (int)__ffsll((unsigned long long)actm) - 1) atomicAdd(&L.hist[ch][first], (uint32_t)__popcll(actm));
-            } else if (act) {
-                atomicAdd(&L.hist[ch][val], 1u);
-            }
-        }
+        for (int ch = 0; ch < 3; ++ch) hist16_medians(L.S, &L.whist[wave][0][ch][0], &L.whist[wave][1][ch][0], cell, ch, n_p, n_f);
     }
-}
-
-__device__ __forceinline__ void hist_zero(TileLds &L)
-{
-    for (int i = threadIdx.x; i < 3 * 256; i += C_THREADS) (&L.hist[0][0])[i] = 0;
-}
-
-// medians of one cell with more than 64 values, whole workgroup
-template <bool I64>
-__device__ __forceinline__ void big_cell_medians(TileLds &L, const BevArgs &a, const uint32_t *s_rgb, bool from_lds, int cell,
-                                                 uint32_t batch_base, uint32_t r_lo, uint32_t r_hi)
-{
-    const uint32_t n_p = L.cnt[2 * cell], n_f = L.cnt[2 * cell + 1];
-    const uint32_t base_p = L.off[2 * cell] - batch_base, base_f = L.off[2 * cell + 1] - batch_base;
-    const int wave = threadIdx.x >> 6;
-    hist_zero(L);
-    __syncthreads();
-    hist_add<I64>(L, a, s_rgb, from_lds, 2 * cell, base_p, r_lo, r_hi);
-    __syncthreads();
-    if (wave < 3) { const uint32_t m = hist_med2(L.hist[wave], n_p); if ((threadIdx.x & 63) == 0) L.med2[0][cell][wave] = m; }
-    __syncthreads();
-    hist_add<I64>(L, a, s_rgb, from_lds, 2 * cell + 1, base_f, r_lo, r_hi);
-    __syncthreads();
-    if (wave < 3) { const uint32_t m = hist_med2(L.hist[wave], n_p + n_f); if ((threadIdx.x & 63) == 0) L.med2[2][cell][wave] = m; }
-    __syncthreads();
-    hist_zero(L);
-    __syncthreads();
-    hist_add<I64>(L, a, s_rgb, from_lds, 2 * cell + 1, base_f, r_lo, r_hi);
-    __syncthreads();
-    if (wave < 3) { const uint32_t m = hist_med2(L.hist[wave], n_f); if ((threadIdx.x & 63) == 0) L.med2[1][cell][wave] = m; }
-    __syncthreads();
 }
 
 template <bool I64>
 __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
 {
     __shared__ TileLds L;
-    __shared__ __align__(16) unsigned char s_buf[RGB_CAP * 4 > 21 * TCELLS * 8 ? RGB_CAP * 4 : 21 * TCELLS * 8];
+    __shared__ __align__(16) unsigned char s_buf[RGB_CAP * 4 > OUT_STAGE_BYTES ? RGB_CAP * 4 : OUT_STAGE_BYTES];
     uint32_t *s_rgb = reinterpret_cast<uint32_t *>(s_buf);
-    double(*s_out)[TCELLS] = reinterpret_cast<double(*)[TCELLS]>(s_buf);       // reused after the medians
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const pca_bev_params &q = a.prm;
     const int tile = blockIdx.x;
     const uint32_t r_lo = a.tile_off[tile], r_hi = a.tile_off[tile + 1];
-
-    for (int k = threadIdx.x; k < NFK; k += C_THREADS) {
-        L.cnt[k] = 0; L.road[k] = 0; L.dyn[k] = 0; L.ihi[k] = 0; L.ilo[k] = 0; L.zk[k] = ~0ull;
+    if (r_hi - r_lo > RGB_CAP) {                            // bev_tile_cells_heavy's: queue it
+        if (threadIdx.x == 0) a.heavy[2 + atomicAdd(&a.heavy[0], 1u)] = (uint32_t)tile;
+        return;
     }
-    for (int k = threadIdx.x; k < 3 * TCELLS * 3; k += C_THREADS) (&L.med2[0][0][0])[k] = 0;
+    const bool extra = a.extra != nullptr;
+    stats_init(L.S, C_THREADS);
     __syncthreads();
 
-    // ---- pass 1: per (cell,set) statistics with LDS atomics ----
-    // If the tile's records fit the LDS colour buffer (the normal case) every thread keeps its <= RPT records'
-    // (key, rank, colour) in registers -- the rank comes back from the counting atomic -- and pass 2 is a pure
-    // LDS scatter without touching memory again.
+    // ---- pass 1: per (cell,set) statistics with LDS atomics; every thread keeps its <= RPT records' (key, rank,
+    // colour) in registers -- the rank comes back from the counting atomic -- so that pass 2 is a pure LDS scatter
     constexpr int RPT = RGB_CAP / C_THREADS;
-    const bool fits = (r_hi - r_lo) <= RGB_CAP;
+    constexpr int HALF = RPT / 2;                           // two rounds of loads: bounds the registers in flight
     uint32_t kr[RPT], cc[RPT];
 #pragma unroll
-    for (int u = 0; u < RPT; ++u) { kr[u] = 0xffffffffu; cc[u] = 0; }
-    auto account = [&](uint32_t k, uint32_t c, double z, double iv, bool want_rank) -> uint32_t {
-        uint32_t rank = 0;
-        if (want_rank) rank = atomicAdd(&L.cnt[k], 1u); else atomicAdd(&L.cnt[k], 1u);
-        atomicMin(&L.zk[k], (unsigned long long)f64_order_key(z));
-        if (c & FLAG_DYNOBJ) atomicAdd(&L.dyn[k], 1u);
-        if (c & FLAG_ROAD) {
-            const double sc = iv * FX_HI, fl = floor(sc);
-            atomicAdd(&L.road[k], 1u);
-            atomicAdd(&L.ihi[k], (unsigned long long)(long long)fl);
-            atomicAdd(&L.ilo[k], (unsigned long long)(long long)rint((sc - fl) * FX_LO));
-        }
-        return rank;
-    };
-    auto load = [&](uint32_t r, uint32_t &k, uint32_t &c, double &z, double &iv) {
-        if (I64) {
-            const RecD rec = reinterpret_cast<const RecD *>(a.recs)[r];
-            k = rec.fk; c = rec.c; z = rec.z; iv = rec.inten;
-        } else {
-            const RecF rec = reinterpret_cast<const RecF *>(a.recs)[r];
-            k = rec.fk; c = rec.c; z = rec.z;
-            iv = q.intensity_div255 ? (double)rec.inten / 255.0 : (double)rec.inten;
-        }
-    };
-    if (fits) {
-        constexpr int HALF = RPT / 2;                       // two rounds of loads: bounds the registers in flight
+    for (int h = 0; h < 2; ++h) {
+        uint32_t k[HALF], c[HALF];
+        double z[HALF], iv[HALF];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            uint32_t k[HALF], c[HALF];
-            double z[HALF], iv[HALF];
-#pragma unroll
-            for (int u = 0; u < HALF; ++u) {
-                const uint32_t r = r_lo + (h * HALF + u) * C_THREADS + threadIdx.x;
-                k[u] = 0xffffffffu; c[u] = 0; z[u] = 0; iv[u] = 0;
-                if (r < r_hi) load(r, k[u], c[u], z[u], iv[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < HALF; ++u) {
-                if (k[u] == 0xffffffffu) continue;
-                const uint32_t rank = account(k[u], c[u], z[u], iv[u], true);
-                kr[h * HALF + u] = k[u] | (rank << 8);
-                cc[h * HALF + u] = c[u] & 0xffffffu;
-            }
+        for (int u = 0; u < HALF; ++u) {
+            const uint32_t r = r_lo + (h * HALF + u) * C_THREADS + threadIdx.x;
+            k[u] = 0xffffffffu; c[u] = 0; z[u] = 0; iv[u] = 0;
+            if (r < r_hi) load_rec<I64>(a, r, k[u], c[u], z[u], iv[u]);
         }
-    } else {
-        for (uint32_t r = r_lo + threadIdx.x; r < r_hi; r += C_THREADS) {
-            uint32_t k, c;
-            double z, iv;
-            load(r, k, c, z, iv);
-            account(k, c, z, iv, false);
+#pragma unroll
+        for (int u = 0; u < HALF; ++u) {
+            const bool valid = k[u] != 0xffffffffu;
+            const uint32_t rank = stats_account_wave(L.S, extra, valid, k[u], c[u], z[u], iv[u]);
+            kr[h * HALF + u] = valid ? (k[u] | (rank << 8)) : 0xffffffffu;
+            cc[h * HALF + u] = c[u] & 0xffffffu;
         }
     }
     __syncthreads();
     // ---- offsets of the (cell,set) segments inside the tile ----
     if (wave == 0) {
-        const uint32_t c0 = L.cnt[2 * lane], c1 = L.cnt[2 * lane + 1];
-        uint32_t inc = c0 + c1;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
+        const uint32_t c0 = L.S.cnt[2 * lane], c1 = L.S.cnt[2 * lane + 1];
+        const uint32_t inc = wave_incl_scan_add(c0 + c1);
         const uint32_t excl = inc - (c0 + c1);
         L.off[2 * lane] = excl;
         L.off[2 * lane + 1] = excl + c0;
         if (lane == 63) L.off[NFK] = inc;
     }
     __syncthreads();
-
-    // ---- medians ----
-    if (fits) {
+    // ---- pass 2: colours sorted by (cell,set) in LDS, then the medians ----
 #pragma unroll
-        for (int u = 0; u < RPT; ++u)
-            if (kr[u] != 0xffffffffu) s_rgb[L.off[kr[u] & 127u] + (kr[u] >> 8)] = cc[u];
+    for (int u = 0; u < RPT; ++u)
+        if (kr[u] != 0xffffffffu) s_rgb[L.off[kr[u] & 127u] + (kr[u] >> 8)] = cc[u];
+    __syncthreads();
+    small_cells_bitplanes(L, s_rgb);
+    __syncthreads();
+    small_cells_select(L);
+    __syncthreads();                                        // the bit planes' LDS becomes the per-wave histograms
+    wave_cells_hist(L, s_rgb);
+    __syncthreads();
+    tile_finalize_write(a, L.S, reinterpret_cast<double(*)[TCELLS]>(s_buf), tile, C_THREADS);
+}
+
+// ---- heavy tiles: 1024 threads, 16-bit-packed 256-bin histograms per (cell, set, channel) for half of the
+// tile's cells at a time, filled straight from the record stream (two passes, no sort) ------------------------
+#define H_THREADS 1024
+#define H_CELLS 32                                          // cells per pass
+#define H_HIST_DWORDS (H_CELLS * 2 * 3 * 128)               // 96 KiB
+struct HeavyLds {
+    TileStats S;
+    uint32_t hist[3][256];                                  // 32-bit fallback for a (cell,set) of 65 536 values or more
+    uint32_t overflow;                                      // some (cell,set) of this tile needs it
+};
+#define HEAVY_LDS_BYTES (H_HIST_DWORDS * 4 + sizeof(HeavyLds))
+
+template <bool I64>
+__device__ __forceinline__ void heavy_hist32(HeavyLds &L, const BevArgs &a, uint32_t fk, uint32_t r_lo, uint32_t r_hi)
+{
+    const int lane = threadIdx.x & 63;
+    for (uint32_t r0 = r_lo; r0 < r_hi; r0 += H_THREADS) {
+        const uint32_t r = r0 + threadIdx.x;
+        bool act = r < r_hi;
+        uint32_t v = 0;
+        if (act) {
+            uint32_t k;
+            load_rec_key_colour<I64>(a, r, k, v);
+            act = k == fk;
+        }
+        const uint32_t tag = act ? v : 0xffffffffu;
+        const uint32_t first = __builtin_amdgcn_readfirstlane(tag);
+        const uint64_t actm = __ballot(act);
+        if (actm == 0) continue;
+        if (__ballot(tag == first) == actm && first != 0xffffffffu) {
+            if (lane == (int)__ffsll((unsigned long long)actm) - 1) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) atomicAdd(&L.hist[ch][(v >> (8 * ch)) & 255u], (uint32_t)__popcll(actm));
+            }
+        } else if (act) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) atomicAdd(&L.hist[ch][(v >> (8 * ch)) & 255u], 1u);
+        }
+    }
+}
+
+__device__ unsigned long long g_dbg_stamps[1024][8];
+template <bool I64>
+__global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs a)
+{
+    unsigned long long t_begin = wall_clock64();
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);                    // [H_CELLS][2][3][128]
+    HeavyLds &L = *reinterpret_cast<HeavyLds *>(smem + (size_t)H_HIST_DWORDS * 4);
+    __shared__ uint32_t s_next;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool extra = a.extra != nullptr;
+    const uint32_t n_heavy = a.heavy[0];
+    // the queued tiles are drawn one at a time: a 12 000-record tile takes several times longer than a 4 100-record one
+    for (;;) {
+    if (threadIdx.x == 0) s_next = atomicAdd(&a.heavy[1], 1u);
+    __syncthreads();
+    const uint32_t item = s_next;
+    if (item >= n_heavy) break;
+    const int tile = (int)a.heavy[2 + item];
+    if (item >= (uint32_t)gridDim.x) t_begin = wall_clock64();
+    const uint32_t r_lo = a.tile_off[tile], r_hi = a.tile_off[tile + 1];
+    stats_init(L.S, H_THREADS);
+    if (threadIdx.x == 0) L.overflow = 0;
+    for (int half = 0; half < TCELLS / H_CELLS; ++half) {
+        for (int k = threadIdx.x; k < H_HIST_DWORDS / 4; k += H_THREADS) reinterpret_cast<uint4 *>(hist)[k] = make_uint4(0, 0, 0, 0);
         __syncthreads();
-        small_cells_bitplanes(L, s_rgb, 0, 0, TCELLS);
+        constexpr int UNR = 4;
+        for (uint32_t r0 = r_lo; r0 < r_hi; r0 += UNR * H_THREADS) {
+            uint32_t k[UNR], c[UNR];
+            double z[UNR], iv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const uint32_t r = r0 + u * H_THREADS + threadIdx.x;
+                k[u] = 0xffffffffu; c[u] = 0; z[u] = 0; iv[u] = 0;
+                if (r < r_hi) load_rec<I64>(a, r, k[u], c[u], z[u], iv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const bool valid = k[u] != 0xffffffffu && (int)(k[u] >> 1) / H_CELLS == half;
+                stats_account_wave(L.S, extra, valid, k[u], c[u], z[u], iv[u]);
+                if (!valid) continue;
+                uint32_t *row = hist + ((((k[u] >> 1) % H_CELLS) * 2 + (k[u] & 1u)) * 3) * 128;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) hist16_add(row + ch * 128, (c[u] >> (8 * ch)) & 255u, 1u);
+            }
+        }
         __syncthreads();
-        small_cells_select(L, 0, TCELLS);
-        for (int cell = 0; cell < TCELLS; ++cell)
-            if (L.cnt[2 * cell] + L.cnt[2 * cell + 1] > 64) big_cell_medians<I64>(L, a, s_rgb, true, cell, 0, r_lo, r_hi);
+        if ((a.dbg & 8) && threadIdx.x == 0 && tile < 1024) g_dbg_stamps[tile][3 + 2 * half] = wall_clock64();
+        for (int job = wave; job < H_CELLS * 3; job += H_THREADS / 64) {
+            const int cl = job / 3, ch = job % 3, cell = half * H_CELLS + cl;
+            const uint32_t n_p = L.S.cnt[2 * cell], n_f = L.S.cnt[2 * cell + 1];
+            if (n_p > 0xffffu || n_f > 0xffffu) { if (lane == 0) L.overflow = 1; continue; }
+            if (n_p + n_f == 0) continue;
+            hist16_medians(L.S, hist + ((cl * 2 + 0) * 3 + ch) * 128, hist + ((cl * 2 + 1) * 3 + ch) * 128, cell, ch, n_p, n_f);
+        }
         __syncthreads();
-    } else {
-        // tiles too large for the LDS buffer: batches of cells whose colours fit, re-reading the tile's records
-        int c_begin = 0;
-        while (c_begin < TCELLS) {
-            const uint32_t base = L.off[2 * c_begin];
-            int c_end = c_begin + 1;
-            const bool huge = L.off[2 * c_begin + 2] - base > RGB_CAP;
-            if (!huge)
-                while (c_end < TCELLS && L.off[2 * c_end + 2] - base <= RGB_CAP) ++c_end;
-            if (huge) {
-                big_cell_medians<I64>(L, a, s_rgb, false, c_begin, base, r_lo, r_hi);
-            } else {
-                const uint32_t n_batch = L.off[2 * c_end] - base;
-                if (n_batch) {
-                    for (int k = 2 * c_begin + threadIdx.x; k < 2 * c_end; k += C_THREADS) L.cur[k] = L.off[k] - base;
-                    __syncthreads();
-                    for (uint32_t r = r_lo + threadIdx.x; r < r_hi; r += C_THREADS) {
-                        const uint32_t *w = rec_words<I64>(a, r);
-                        const uint32_t k = w[REC_FK<I64>()];
-                        if ((int)(k >> 1) >= c_begin && (int)(k >> 1) < c_end)
-                            s_rgb[atomicAdd(&L.cur[k], 1u)] = w[REC_C<I64>()] & 0xffffffu;
-                    }
-                    __syncthreads();
-                    small_cells_bitplanes(L, s_rgb, base, c_begin, c_end);
-                    __syncthreads();
-                    small_cells_select(L, c_begin, c_end);
-                    for (int cell = c_begin; cell < c_end; ++cell)
-                        if (L.cnt[2 * cell] + L.cnt[2 * cell + 1] > 64)
-                            big_cell_medians<I64>(L, a, s_rgb, true, cell, base, r_lo, r_hi);
-                }
+        if ((a.dbg & 8) && threadIdx.x == 0 && tile < 1024) g_dbg_stamps[tile][4 + 2 * half] = wall_clock64();
+    }
+    // (cell,set)s too large for 16-bit counters: 32-bit histograms, whole workgroup, re-reading the tile
+    for (int cell = 0; L.overflow && cell < TCELLS; ++cell) {
+        const uint32_t n_p = L.S.cnt[2 * cell], n_f = L.S.cnt[2 * cell + 1];
+        if (n_p <= 0xffffu && n_f <= 0xffffu) continue;
+        for (int round = 0; round < 2; ++round) {           // round 0: present, then + future = full; round 1: future
+            for (int i = threadIdx.x; i < 3 * 256; i += H_THREADS) (&L.hist[0][0])[i] = 0;
+            __syncthreads();
+            if (round == 0) {
+                heavy_hist32<I64>(L, a, 2 * cell, r_lo, r_hi);
+                __syncthreads();
+                if (wave < 3) { const uint32_t m = hist_med2(L.hist[wave], n_p); if (lane == 0) L.S.med2[0][cell][wave] = m; }
+                __syncthreads();
+            }
+            heavy_hist32<I64>(L, a, 2 * cell + 1, r_lo, r_hi);
+            __syncthreads();
+            if (wave < 3) {
+                const uint32_t m = hist_med2(L.hist[wave], round == 0 ? n_p + n_f : n_f);
+                if (lane == 0) L.S.med2[round == 0 ? 2 : 1][cell][wave] = m;
             }
             __syncthreads();
-            c_begin = c_end;
         }
-    }
-
-    // ---- closed-form maps: thread -> (set, cell) ----
-    if (threadIdx.x < 3 * TCELLS) {
-        const int s = threadIdx.x / TCELLS, cell = threadIdx.x % TCELLS;
-        const int kp = 2 * cell, kf = 2 * cell + 1;
-        uint32_t n, n_r, n_d;
-        long long ihi, ilo;
-        double zmin = 0.0;
-        if (s < 2) {
-            const int k = s ? kf : kp;
-            n = L.cnt[k]; n_r = L.road[k]; n_d = L.dyn[k]; ihi = (long long)L.ihi[k]; ilo = (long long)L.ilo[k];
-            if (n) zmin = f64_from_order_key(L.zk[k]);
-        } else {
-            n = L.cnt[kp] + L.cnt[kf]; n_r = L.road[kp] + L.road[kf]; n_d = L.dyn[kp] + L.dyn[kf];
-            ihi = (long long)L.ihi[kp] + (long long)L.ihi[kf];
-            ilo = (long long)L.ilo[kp] + (long long)L.ilo[kf];
-            const unsigned long long zk = L.zk[kp] < L.zk[kf] ? L.zk[kp] : L.zk[kf];
-            if (n) zmin = f64_from_order_key(zk);
-        }
-        double o[7];
-        finalize_cell(q, n, n_r, n_d, ihi, ilo, zmin, L.med2[s][cell], o);
-#pragma unroll
-        for (int k = 0; k < 7; ++k) s_out[7 * s + k][cell] = o[k];
     }
     __syncthreads();
-    const int row0 = (tile / a.tx) * TS, col0 = (tile % a.tx) * TS;
-    const int64_t ncell = (int64_t)q.px * q.px;
-    for (int idx = threadIdx.x; idx < 21 * TCELLS; idx += C_THREADS) {
-        const int plane = idx / TCELLS, lc = idx % TCELLS;
-        const int row = row0 + lc / TS, col = col0 + lc % TS;
-        if (row >= q.px || col >= q.px) continue;
-        const double v = s_out[plane][lc];
-        const int64_t o = (int64_t)plane * ncell + (int64_t)row * q.px + col;
-        if (a.planes) a.planes[o] = v;
-        if (a.planes_f16) a.planes_f16[o] = f64_to_f16_bits(v);
+    tile_finalize_write(a, L.S, reinterpret_cast<double(*)[TCELLS]>(smem), tile, H_THREADS);
+    __syncthreads();                                        // the staging area is the next tile's histogram
+    if ((a.dbg & 8) && threadIdx.x == 0 && tile < 1024) {
+        g_dbg_stamps[tile][0] = t_begin; g_dbg_stamps[tile][1] = wall_clock64(); g_dbg_stamps[tile][2] = r_hi - r_lo;
+        g_dbg_stamps[tile][7] = __smid();
+    }
     }
 }
 
@@ -607,13 +795,23 @@ int64_t pca_bev_workspace_bytes(int64_t max_points, int px)
 {
     if (max_points < 1) max_points = 1;
     const int64_t T = (int64_t)tiles_x(px) * tiles_x(px), G = n_groups(max_points);
-    return align256(max_points * 4) + 2 * align256(G * T * 4) + align256((T + 1) * 4) + align256(max_points * 24) + 512;
+    return align256(max_points * 4) + 2 * align256(G * T * 4) + align256((T + 1) * 4) + align256((T + 2) * 4) +
+           align256(max_points * 24) + 512;
 }
 
 int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensity64, const int64_t *frame_off,
                      int slot_begin, int slot_split, int slot_end, int64_t max_points, const pca_bev_params *prm,
                      const double *pending_T, int pending_slot_end, void *workspace, int64_t workspace_bytes,
                      double *planes, uint16_t *planes_f16, void *stream)
+{
+    return pca_bev_generate_ex(ctx, store, intensity64, frame_off, slot_begin, slot_split, slot_end, max_points, prm,
+                               pending_T, pending_slot_end, workspace, workspace_bytes, planes, planes_f16, nullptr, stream);
+}
+
+int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *intensity64, const int64_t *frame_off,
+                        int slot_begin, int slot_split, int slot_end, int64_t max_points, const pca_bev_params *prm,
+                        const double *pending_T, int pending_slot_end, void *workspace, int64_t workspace_bytes,
+                        double *planes, uint16_t *planes_f16, double *extra_planes, void *stream)
 {
     if (!ctx) return -1;
     if (!store || !frame_off || !prm || !workspace || (!planes && !planes_f16)) { ctx->err = "bev: bad arguments"; return -1; }
@@ -646,9 +844,20 @@ int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensi
     a.bh = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)a.G * a.T * 4);
     a.boff = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)a.G * a.T * 4);
     a.tile_off = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.T + 1) * 4);
+    a.heavy = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.T + 2) * 4);
     a.recs = w;
     a.planes = planes;
     a.planes_f16 = planes_f16;
+    a.extra = extra_planes;
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("PCA_BEV_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
+    static bool heavy_lds_set = false;                      // > 64 KiB of dynamic LDS has to be asked for once
+    if (!heavy_lds_set) {
+        PCA_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&bev_tile_cells_heavy<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAVY_LDS_BYTES));
+        PCA_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&bev_tile_cells_heavy<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAVY_LDS_BYTES));
+        heavy_lds_set = true;
+    }
     const int64_t n_scan = (int64_t)a.T * a.G;
     a.scan_tiles = (int)((n_scan + SCAN_TILE - 1) / SCAN_TILE);
     if (pca_ctx_reserve_tiles(ctx, a.scan_tiles, s)) return -1;
@@ -656,17 +865,25 @@ int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensi
     a.ticket = ctx->ticket;
     a.epoch = pca_ctx_next_epoch(ctx, s);
     const size_t lds = (size_t)a.T * 4;
+    const int heavy_grid = a.T < ctx->n_cu ? a.T : ctx->n_cu;          // one resident workgroup per CU draws from the queue
     PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_hist, dim3(a.G), dim3(AB_THREADS), lds, s, a);
     PCA_LAUNCH(ctx, PCA_K_BEV_SCAN, bev_tile_scan, dim3(a.scan_tiles), dim3(SCAN_THREADS), s, a);
     if (intensity64) {
         PCA_LAUNCH_SHM(ctx, PCA_K_BEV_SCATTER, bev_tile_scatter<true>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
         PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_tile_cells<true>, dim3(a.T), dim3(C_THREADS), s, a);
+        PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, bev_tile_cells_heavy<true>, dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a);
     } else {
         PCA_LAUNCH_SHM(ctx, PCA_K_BEV_SCATTER, bev_tile_scatter<false>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
         PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_tile_cells<false>, dim3(a.T), dim3(C_THREADS), s, a);
+        PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, bev_tile_cells_heavy<false>, dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a);
     }
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
+}
+
+int pca_debug_bev_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_stamps), sizeof(unsigned long long) * 8192);
 }
 
 }  // extern "C"

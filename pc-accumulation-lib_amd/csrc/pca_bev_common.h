@@ -37,21 +37,18 @@ __device__ __forceinline__ uint32_t hist_rank(const uint4 h, uint32_t excl, uint
     return __builtin_amdgcn_readlane(val, src);
 }
 
-// 2*median (lower + upper middle value) of a 256-bin histogram with n entries, called by one whole wave
-__device__ __forceinline__ uint32_t hist_med2(const uint32_t *hist256, uint32_t n)
+// 2*median (lower + upper middle value) of a 256-bin histogram with n entries, 4 bins per lane, one whole wave
+__device__ __forceinline__ uint32_t hist_med2_regs(const uint4 h, uint32_t n)
 {
     if (n == 0) return 0;
-    const int lane = threadIdx.x & 63;
-    const uint4 h = *reinterpret_cast<const uint4 *>(hist256 + 4 * lane);
     const uint32_t s = h.x + h.y + h.z + h.w;
-    uint32_t inc = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-    }
+    const uint32_t inc = wave_incl_scan_add(s);
     const uint32_t excl = inc - s;
     return hist_rank(h, excl, s, (n - 1) >> 1) + hist_rank(h, excl, s, n >> 1);
+}
+__device__ __forceinline__ uint32_t hist_med2(const uint32_t *hist256, uint32_t n)
+{
+    return hist_med2_regs(*reinterpret_cast<const uint4 *>(hist256 + 4 * (threadIdx.x & 63)), n);
 }
 
 // closed-form maps of one (cell, set): writes 7 values {road, intensity, r, g, b, dynamic, elevation}

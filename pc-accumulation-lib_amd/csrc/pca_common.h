@@ -9,11 +9,13 @@
 #include <vector>
 
 #include "../../include/pca.h"
+#include "pca_wave.h"
 
 #define PCA_WAVE 64
 
 struct pca_ctx {
     int device = 0;
+    int n_cu = 256;                   // compute units of the device (MI355X: 256)
     std::string err;
     // decoupled look-back workspace (stable compaction / scans)
     uint64_t *tile_state = nullptr;   // dev [tile_cap]
@@ -175,8 +177,8 @@ __device__ __forceinline__ uint64_t lb_walk(uint64_t *state, int tile, uint64_t 
                 break;
             }
             uint64_t v = (idx >= 0 && lane <= first_pfx) ? (w[j] & LB_VAL_MASK) : 0;
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            excl += v;
+            // values are below 2^40: two 20-bit halves, each summed over the wave on the VALU
+            excl += ((uint64_t)wave_reduce_add((uint32_t)(v >> 20)) << 20) + wave_reduce_add((uint32_t)v & 0xfffffu);
             if (first_pfx < 64 || hi - 64 < 0) done = true;
             else hi -= 64;
         }

@@ -78,6 +78,8 @@ class DeviceStore:
             raise AssertionError('pts_uv must be all inside image')
         if st & _lib.STATUS_STORE_OVERFLOW:
             raise RuntimeError('pca: device point store overflow (points were dropped)')
+        if st & _lib.STATUS_NEGATIVE_INTENSITY:
+            raise ValueError('pca: negative lidar intensity on the f32 path (pass intensity64 to bev())')
 
     def reserve(self, n_new, n_slots=1):
         """Make room for n_slots more frames holding at most n_new points in total."""
@@ -211,9 +213,11 @@ class DeviceStore:
                                            ctx.stream()))
 
     # ---- BEV ------------------------------------------------------------------------------
-    def bev(self, split_frame, prm, want_f64=False, intensity64=None, first_frame=0, last_frame=None, out16=None):
+    def bev(self, split_frame, prm, want_f64=False, intensity64=None, first_frame=0, last_frame=None, out16=None,
+            extra=None):
         """Rasterises live frames [first_frame, last_frame) with 'present' = frames before split_frame.
-        Returns (planes_f16 [21,px,px] cuda float16, planes_f64 or None)."""
+        Returns (planes_f16 [21,px,px] cuda float16, planes_f64 or None).
+        extra: optional cuda f64 [3, len(_lib.BEV_EXTRA_PLANES), px, px] receiving the opt-in extra reducers."""
         ctx, lib = self.ctx, self.ctx.lib
         last_frame = self.n_frames if last_frame is None else last_frame
         px = int(prm.px)
@@ -233,12 +237,15 @@ class DeviceStore:
                 self._pending = None
             else:
                 self.flush_pending()
-        ctx.check(lib.pca_bev_generate(ctx.h, C.byref(st), None if intensity64 is None else intensity64.data_ptr(),
-                                       self.frame_off.data_ptr(), self.head + first_frame, self.head + split_frame,
-                                       self.head + last_frame, max_points, C.byref(prm), pend_T, pend_end,
-                                       self._ws.data_ptr(),
-                                       self._ws.numel(), None if p64 is None else p64.data_ptr(), p16.data_ptr(),
-                                       ctx.stream()))
+        if extra is not None:
+            assert extra.dtype == torch.float64 and extra.is_contiguous() \
+                and tuple(extra.shape) == (3, len(_lib.BEV_EXTRA_PLANES), px, px)
+        ctx.check(lib.pca_bev_generate_ex(ctx.h, C.byref(st), None if intensity64 is None else intensity64.data_ptr(),
+                                          self.frame_off.data_ptr(), self.head + first_frame, self.head + split_frame,
+                                          self.head + last_frame, max_points, C.byref(prm), pend_T, pend_end,
+                                          self._ws.data_ptr(), self._ws.numel(),
+                                          None if p64 is None else p64.data_ptr(), p16.data_ptr(),
+                                          None if extra is None else extra.data_ptr(), ctx.stream()))
         return p16, p64
 
     # ---- host views (synchronise) -----------------------------------------------------------
@@ -290,7 +297,7 @@ class DeviceStore:
         raw32 = raw.astype(np.float32)
         back = raw32.astype(np.float64) / 255. if self.intensity_div255 else raw32.astype(np.float64)
         i64 = None
-        if not np.array_equal(back, inten):
+        if not np.array_equal(back, inten) or (inten.size and (inten.min() < 0 or np.signbit(inten).any())):
             i64 = torch.from_numpy(np.ascontiguousarray(inten)).to(d)
         self.intensity[:total] = torch.from_numpy(raw32).to(d)
         cu = c.astype(np.uint32)

@@ -409,3 +409,104 @@ def test_bev_dense_tile_goes_through_batches(T, orc):
     p16, p64, _ = run_dev_bev(T, rows[:12000], rows[12000:], 32, 64, None, (1., 30., 0.12), True, 0.0)
     ref = run_orc_bev(orc, rows[:12000], rows[12000:], 32, 64, None, (1., 30., 0.12), True, 0.0)
     assert_planes_match(p16, p64, ref, 'dense tile')
+
+
+def _skewed_rows(rng, n, sigma, colour_spread):
+    """Points clustered around a driven path (density falling off away from it), narrow colour distribution."""
+    rows = np.zeros((n, 10))
+    rows[:, 0] = rng.uniform(-15.9, 15.9, n)
+    rows[:, 1] = rng.normal(0, sigma, n)
+    rows[:, 2] = rng.uniform(-1, 2, n)
+    rows[:, 3] = rng.integers(0, 256, n) / 255.
+    base = rng.integers(0, 256, 3)
+    rows[:, 4:7] = np.clip(base + rng.integers(-colour_spread, colour_spread + 1, (n, 3)), 0, 255)
+    rows[:, 7] = rng.choice([0, 1, 2, 13], n, p=[0.6, 0.2, 0.15, 0.05])
+    rows[:, 9] = rng.random(n) < 0.02
+    return rows
+
+
+@pytest.mark.parametrize('n,sigma,spread', [(60000, 1.5, 8), (400000, 0.8, 3), (150000, 4.0, 0)])
+def test_bev_ring_like_skew_heavy_and_light_tiles(T, orc, n, sigma, spread):
+    """Real accumulations are skewed: cells next to the path hold hundreds to thousands of points.  Covers the
+    per-wave histogram path (cells > 64 values in tiles that fit LDS), the heavy-tile kernel (tiles beyond the LDS
+    colour buffer), identical colours (spread 0) and the mix of both tile kinds in one raster."""
+    rng = np.random.default_rng(n)
+    rows = _skewed_rows(rng, n, sigma, spread)
+    cut = int(0.4 * n)
+    p16, p64, _ = run_dev_bev(T, rows[:cut], rows[cut:], 32, 64, None, (1., 30., 0.12), True, 0.2)
+    ref = run_orc_bev(orc, rows[:cut], rows[cut:], 32, 64, None, (1., 30., 0.12), True, 0.2)
+    assert_planes_match(p16, p64, ref, f'skew n={n}')
+
+
+def test_bev_cell_beyond_16bit_counters(T, orc):
+    """One (cell, set) with more than 65 535 values: the heavy kernel's packed 16-bit histograms overflow there and the
+    32-bit whole-workgroup path must take over for that cell only."""
+    rng = np.random.default_rng(77)
+    n = 180000
+    rows = _skewed_rows(rng, n, 3.0, 5)
+    rows[:70000, 0] = rng.uniform(2.01, 2.49, 70000)          # cell [2.0, 2.5) x [1.0, 1.5): 70k present points
+    rows[:70000, 1] = rng.uniform(1.01, 1.49, 70000)
+    rows[70000:100000, 0] = rng.uniform(2.51, 2.99, 30000)    # neighbour cell: 30k
+    rows[70000:100000, 1] = rng.uniform(1.01, 1.49, 30000)
+    rows[100000:140000, 0] = rng.uniform(2.01, 2.49, 40000)   # and 40k future points in the first cell
+    rows[100000:140000, 1] = rng.uniform(1.01, 1.49, 40000)
+    p16, p64, used_i64 = run_dev_bev(T, rows[:100000], rows[100000:], 32, 64, None, (1., 30., 0.12), True, 0.0)
+    assert not used_i64
+    ref = run_orc_bev(orc, rows[:100000], rows[100000:], 32, 64, None, (1., 30., 0.12), True, 0.0)
+    assert_planes_match(p16, p64, ref, '16-bit overflow')
+    # the same raster through the f64-intensity variant of the kernels (column 3 not f32-representable)
+    rows[:, 3] = rng.uniform(0, 1, n)
+    p16, p64, used_i64 = run_dev_bev(T, rows[:100000], rows[100000:], 32, 64, None, (20., 20., 0.5), False, 0.0)
+    assert used_i64
+    from pca_amd import host_logic as hl
+    prm = orc.make_bev_params([0, 0, 0], hl.rotation_matrix_3d(0.0), 0, 0, 32, 64, None, 20., 20., 0.5, 0, DYNOBJ, False)
+    ref = orc.bev(orc.Store.from_rows(rows), 100000, prm, intensity64=rows[:, 3])
+    assert_planes_match(p16, p64, ref, '16-bit overflow, f64 intensity')
+
+
+def test_bev_extra_reducers_max_mean(T):
+    """Opt-in extra reducers (no reference counterpart): max z / mean z over a cell's static points, mean raw
+    intensity over its road points; checked against numpy on an axis-aligned raster (R = I, no shift), light and
+    heavy tiles."""
+    from pca_amd import _lib, host_logic as hl
+    from pca_amd.device_store import make_bev_params
+    rng = np.random.default_rng(31)
+    n, view, px = 120000, 32.0, 64
+    rows = _skewed_rows(rng, n, 2.0, 6)
+    rows[:, 3] = rng.uniform(0, 1, n).astype(np.float32)
+    cut = 50000
+    st = dev_store(capacity=n, max_frames=4)
+    assert st.load_rows([rows[:cut], rows[cut:]]) is None
+    prm = make_bev_params((0., 0., 0.), hl.rotation_matrix_3d(0.0), 0., 0., view, px, None, 20., 20., 0.5, 0, DYNOBJ, False)
+    extra = T.zeros((3, len(_lib.BEV_EXTRA_PLANES), px, px), dtype=T.float64, device='cuda')
+    p16, p64 = st.bev(1, prm, want_f64=True, extra=extra)
+    st.check_status()
+    ex = extra.cpu().numpy()
+    elev = p64.cpu().numpy()
+    x, y, z, inten, sem, dyn = rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3], rows[:, 7], rows[:, 9]
+    keep = (x > -view / 2) & (x < view / 2) & (y > -view / 2) & (y < view / 2) & (dyn != 1)
+    i = np.floor(x / view * px + 0.5 * px).astype(int)
+    j = np.floor(y / view * px + 0.5 * px).astype(int)
+    cell = (px - 1 - j) * px + i
+    is_future = np.arange(n) >= cut
+    for s, sel in enumerate((~is_future, is_future, np.ones(n, bool))):
+        m = keep & sel
+        cnt = np.bincount(cell[m], minlength=px * px).astype(float)
+        zmax = np.full(px * px, -np.inf)
+        np.maximum.at(zmax, cell[m], z[m])
+        zmax[cnt == 0] = 0.0
+        zsum = np.bincount(cell[m], weights=z[m], minlength=px * px)
+        zmean = np.where(cnt > 0, zsum / np.maximum(cnt, 1), 0.0)
+        mr = m & (sem == 0)
+        cr = np.bincount(cell[mr], minlength=px * px).astype(float)
+        isum = np.bincount(cell[mr], weights=inten[mr], minlength=px * px)
+        imean = np.where(cr > 0, isum / np.maximum(cr, 1), 0.0)
+        assert np.array_equal(ex[s, 0].ravel(), zmax), f'max z set {s}'
+        np.testing.assert_allclose(ex[s, 1].ravel(), zmean, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(ex[s, 2].ravel(), imean, rtol=0, atol=1e-11)
+        # the ordinary planes are untouched by the option, and max >= mean >= min where observed
+        obs = cnt > 0
+        assert np.all(ex[s, 0].ravel()[obs] >= ex[s, 1].ravel()[obs] - 1e-12)
+        assert np.all(ex[s, 1].ravel()[obs] >= elev[7 * s + 6].ravel()[obs] - 1e-12)
+    p16b, p64b = st.bev(1, prm, want_f64=True)
+    assert T.equal(p64, p64b) and T.equal(p16, p16b)
