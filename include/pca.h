@@ -129,6 +129,18 @@ int pca_mark_dynamic(pca_ctx *ctx, const pca_store *store, const int64_t *frame_
                      const int32_t *inst_idx, int n_pairs, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Voxel de-duplication of the accumulation buffer (opt-in; no reference counterpart -- the reference only
+ *     evicts whole frames by horizon, sem_pc_accum.py:185-209).  Over the stored points of frames
+ *     [slot_begin, slot_end): of all points in one voxel floor(xyz / voxel_size) the first in store order (the
+ *     oldest observation) stays.  Segments are compacted in place, order-preserving; frame_off[slot_begin+1 ..
+ *     slot_end] is rewritten.  slot_end must be the last used slot (later segments are not moved).
+ * ------------------------------------------------------------------------------------------------ */
+int64_t pca_voxel_dedup_workspace_bytes(int64_t max_points, int n_slots);
+int pca_voxel_dedup(pca_ctx *ctx, const pca_store *store, int64_t *frame_off /*dev*/, int slot_begin, int slot_end,
+                    double voxel_size, int64_t max_points, void *workspace /*dev*/, int64_t workspace_bytes,
+                    void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K4-K7  BEV rasteriser: window [slot_begin, slot_end), 'present' = [slot_begin, slot_split),
  *     'future' = [slot_split, slot_end), 'full' = both.  Replaces
  *       kitti360_sem_pc_accum.py:189-213 / nuscenes_oracle_sem_pc_accum.py:535-581 (window assembly, origin),
@@ -187,7 +199,7 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
  * ------------------------------------------------------------------------------------------------ */
 enum {
     PCA_K_KITTI = 0, PCA_K_NUSC, PCA_K_PROJECT_CAMS, PCA_K_RETRANSFORM, PCA_K_MARK_DYNAMIC,
-    PCA_K_BEV_BIN, PCA_K_BEV_SCAN, PCA_K_BEV_SCATTER, PCA_K_BEV_CELLS, PCA_K_BEV_CELLS_HEAVY, PCA_K_COUNT
+    PCA_K_BEV_BIN, PCA_K_BEV_SCAN, PCA_K_BEV_SCATTER, PCA_K_BEV_CELLS, PCA_K_BEV_CELLS_HEAVY, PCA_K_DEDUP, PCA_K_COUNT
 };
 int pca_profile_enable(pca_ctx *ctx, int on);
 int pca_profile_read(pca_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);

@@ -596,6 +596,154 @@ __global__ __launch_bounds__(SBLK) void k3_mark_dynamic(const K3Args a)
 }
 
 // =============================================================================================
+// Voxel de-duplication of the running accumulation buffer (opt-in; the reference only evicts whole
+// frames, sem_pc_accum.py:185-209).  Of all stored points of the window that fall into one voxel
+// floor(xyz / size) the first in store order (the oldest observation) stays; the segments are
+// compacted in place, stably, and frame_off follows.
+//   dedup_insert   open-addressing table keyed by the packed voxel index: value = min point index
+//   dedup_compact  keep = (table value == own index); single-pass stable compaction (decoupled
+//                  look-back).  In place is safe: a tile's destination range ends before its own
+//                  source range ends, and it is written only after every earlier tile has published
+//                  its aggregate -- which each workgroup does after its own loads have completed.
+//   dedup_offsets  frame_off <- new segment boundaries
+// =============================================================================================
+struct DedupArgs {
+    pca_store st;
+    int64_t *frame_off;
+    int64_t *new_off;         // [slot_end - slot_begin + 2]; last entry = kept total
+    int slot_begin, slot_end;
+    int64_t max_points;
+    double size;
+    unsigned long long *keys; // [cap] 0 = empty
+    uint32_t *vals;           // [cap] min window-relative index
+    uint64_t cap_mask;
+    uint64_t *state;
+    uint32_t *ticket;
+    uint32_t epoch;
+    int total_tiles;
+};
+
+__device__ __forceinline__ unsigned long long voxel_key(double x, double y, double z, double size)
+{
+    auto q = [&](double v) -> unsigned long long {
+        double f = floor(v / size) + 1048576.0;
+        f = f < 0.0 ? 0.0 : (f > 2097151.0 ? 2097151.0 : f);
+        return (unsigned long long)f;
+    };
+    return (1ull << 63) | (q(x) << 42) | (q(y) << 21) | q(z);
+}
+__device__ __forceinline__ uint64_t voxel_hash(unsigned long long k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+__device__ __forceinline__ void dedup_window(const DedupArgs &a, int64_t &lo, int64_t &hi)
+{
+    lo = a.frame_off[a.slot_begin];
+    hi = a.frame_off[a.slot_end];
+    if (hi - lo > a.max_points) hi = lo + a.max_points;
+}
+
+__global__ __launch_bounds__(SBLK) void dedup_insert(const DedupArgs a)
+{
+    int64_t lo, hi;
+    dedup_window(a, lo, hi);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.frame_off[a.slot_end] - lo > a.max_points)
+        atomicOr(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
+    for (int64_t p = lo + (int64_t)blockIdx.x * SBLK + threadIdx.x; p < hi; p += (int64_t)gridDim.x * SBLK) {
+        const unsigned long long key = voxel_key(a.st.x[p], a.st.y[p], a.st.z[p], a.size);
+        uint64_t h = voxel_hash(key) & a.cap_mask;
+        for (uint64_t probe = 0; probe <= a.cap_mask; ++probe) {             // load factor <= 1/2: ends early
+            const unsigned long long prev = atomicCAS(&a.keys[h], 0ull, key);
+            if (prev == 0ull || prev == key) { atomicMin(&a.vals[h], (uint32_t)(p - lo)); break; }
+            h = (h + 1) & a.cap_mask;
+        }
+    }
+}
+
+template <int BLK>
+__global__ __launch_bounds__(BLK) void dedup_compact(const DedupArgs a)
+{
+    constexpr int TILE = PPT * BLK;
+    __shared__ uint32_t s_rank[TILE];
+    const int tile = draw_tile(a.ticket, a.total_tiles);
+    int64_t lo, hi;
+    dedup_window(a, lo, hi);
+    const int64_t t_lo = lo + (int64_t)tile * TILE;
+    bool keep[PPT];
+    double X[PPT], Y[PPT], Z[PPT];
+    float I[PPT];
+    uint32_t C[PPT];
+    int32_t N[PPT];
+    uint8_t D[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int64_t p = t_lo + k * BLK + threadIdx.x;
+        keep[k] = false;
+        X[k] = Y[k] = Z[k] = 0.0; I[k] = 0.f; C[k] = 0; N[k] = 0; D[k] = 0;
+        if (p < hi) {
+            X[k] = a.st.x[p]; Y[k] = a.st.y[p]; Z[k] = a.st.z[p];
+            I[k] = a.st.intensity[p]; C[k] = a.st.rgbs[p]; N[k] = a.st.inst[p]; D[k] = a.st.dyn[p];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int64_t p = t_lo + k * BLK + threadIdx.x;
+        if (p >= hi) continue;
+        const unsigned long long key = voxel_key(X[k], Y[k], Z[k], a.size);
+        uint64_t h = voxel_hash(key) & a.cap_mask;
+        for (uint64_t probe = 0; probe <= a.cap_mask; ++probe) {
+            const unsigned long long kk = a.keys[h];
+            if (kk == key) { keep[k] = a.vals[h] == (uint32_t)(p - lo); break; }
+            if (kk == 0ull) break;                                             // cannot happen after dedup_insert
+            h = (h + 1) & a.cap_mask;
+        }
+    }
+    // every load of this workgroup has returned before its aggregate becomes visible (see the header)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const TileScan sc = tile_compact<BLK>(keep, a.state, tile, a.epoch);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        s_rank[k * BLK + threadIdx.x] = sc.local[k];
+        if (!keep[k]) continue;
+        const int64_t d = lo + (int64_t)sc.excl + sc.local[k];
+        a.st.x[d] = X[k]; a.st.y[d] = Y[k]; a.st.z[d] = Z[k];
+        a.st.intensity[d] = I[k]; a.st.rgbs[d] = C[k]; a.st.inst[d] = N[k]; a.st.dyn[d] = D[k];
+    }
+    __syncthreads();
+    // segment boundaries that fall into this tile: first frame f > slot_begin with frame_off[f] >= t_lo
+    const int64_t t_hi = t_lo + TILE < hi ? t_lo + TILE : hi;
+    int f0 = a.slot_begin + 1, f1 = a.slot_end + 1;
+    while (f0 < f1) {
+        const int m = (f0 + f1) >> 1;
+        if (a.frame_off[m] < t_lo) f0 = m + 1; else f1 = m;
+    }
+    for (int f = f0 + threadIdx.x; f <= a.slot_end; f += BLK) {
+        const int64_t b = a.frame_off[f];
+        if (b >= t_hi) break;
+        a.new_off[f - a.slot_begin] = lo + (int64_t)sc.excl + s_rank[b - t_lo];
+    }
+    if (tile == a.total_tiles - 1 && threadIdx.x == 0) a.new_off[a.slot_end - a.slot_begin + 1] = lo + (int64_t)sc.excl + sc.total;
+}
+
+__global__ __launch_bounds__(SBLK) void dedup_offsets(const DedupArgs a)
+{
+    int64_t lo, hi;
+    dedup_window(a, lo, hi);
+    const int64_t end = a.new_off[a.slot_end - a.slot_begin + 1];
+    __shared__ int64_t s_old_hi;
+    if (threadIdx.x == 0) s_old_hi = hi;
+    __syncthreads();
+    // boundaries at or beyond the old window end (the end itself, empty trailing frames) move to the new end
+    for (int f = a.slot_begin + 1 + threadIdx.x; f <= a.slot_end; f += SBLK) {
+        const int64_t b = a.frame_off[f];
+        a.new_off[f - a.slot_begin] = b >= s_old_hi ? end : a.new_off[f - a.slot_begin];
+    }
+    __syncthreads();
+    for (int f = a.slot_begin + 1 + threadIdx.x; f <= a.slot_end; f += SBLK) a.frame_off[f] = a.new_off[f - a.slot_begin];
+}
+
+// =============================================================================================
 // C ABI
 // =============================================================================================
 extern "C" {
@@ -783,6 +931,62 @@ int pca_mark_dynamic(pca_ctx *ctx, const pca_store *store, const int64_t *frame_
         PCA_LAUNCH(ctx, PCA_K_MARK_DYNAMIC, k3_mark_dynamic, dim3(64, a.n_pairs), dim3(SBLK), s, a);
         PCA_CHECK(ctx, hipGetLastError());
     }
+    return 0;
+}
+
+
+static inline int64_t dd_align(int64_t v) { return (v + 255) & ~255ll; }
+static inline int64_t dedup_capacity(int64_t max_points)
+{
+    int64_t cap = 1024;
+    while (cap < 2 * max_points) cap <<= 1;
+    return cap;
+}
+
+int64_t pca_voxel_dedup_workspace_bytes(int64_t max_points, int n_slots)
+{
+    if (max_points < 1) max_points = 1;
+    const int64_t cap = dedup_capacity(max_points);
+    return dd_align(cap * 8) + dd_align(cap * 4) + dd_align((int64_t)(n_slots + 2) * 8) + 512;
+}
+
+int pca_voxel_dedup(pca_ctx *ctx, const pca_store *store, int64_t *frame_off, int slot_begin, int slot_end,
+                    double voxel_size, int64_t max_points, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (!ctx) return -1;
+    if (!store || !frame_off || !workspace || slot_end < slot_begin) { ctx->err = "dedup: bad arguments"; return -1; }
+    if (!(voxel_size > 0.0)) { ctx->err = "dedup: voxel_size must be positive"; return -1; }
+    if (slot_end == slot_begin) return 0;
+    if (max_points < 1) max_points = 1;
+    if (max_points >= (1ll << 31)) { ctx->err = "dedup: window too large"; return -1; }
+    if (workspace_bytes < pca_voxel_dedup_workspace_bytes(max_points, slot_end - slot_begin)) { ctx->err = "dedup: workspace too small"; return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    DedupArgs a;
+    a.st = *store;
+    a.frame_off = frame_off;
+    a.slot_begin = slot_begin; a.slot_end = slot_end;
+    a.max_points = max_points;
+    a.size = voxel_size;
+    const int64_t cap = dedup_capacity(max_points);
+    char *w = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    a.keys = reinterpret_cast<unsigned long long *>(w); w += dd_align(cap * 8);
+    a.vals = reinterpret_cast<uint32_t *>(w); w += dd_align(cap * 4);
+    a.new_off = reinterpret_cast<int64_t *>(w);
+    a.cap_mask = (uint64_t)cap - 1;
+    constexpr int BLK = 256;
+    a.total_tiles = (int)((max_points + PPT * BLK - 1) / (PPT * BLK));
+    if (pca_ctx_reserve_tiles(ctx, a.total_tiles, s)) return -1;
+    a.state = ctx->tile_state;
+    a.ticket = ctx->ticket;
+    a.epoch = pca_ctx_next_epoch(ctx, s);
+    PCA_CHECK(ctx, hipMemsetAsync(a.keys, 0, (size_t)cap * 8, s));
+    PCA_CHECK(ctx, hipMemsetAsync(a.vals, 0xff, (size_t)cap * 4, s));
+    const int64_t g = (max_points + SBLK - 1) / SBLK;
+    PCA_LAUNCH(ctx, PCA_K_DEDUP, dedup_insert, dim3((unsigned)(g < 4096 ? g : 4096)), dim3(SBLK), s, a);
+    PCA_LAUNCH(ctx, PCA_K_DEDUP, dedup_compact<BLK>, dim3(a.total_tiles), dim3(BLK), s, a);
+    PCA_LAUNCH(ctx, PCA_K_DEDUP, dedup_offsets, dim3(1), dim3(SBLK), s, a);
+    PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }
 

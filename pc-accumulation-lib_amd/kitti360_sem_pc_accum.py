@@ -104,6 +104,7 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         if len(self._track) > 1:
             idx, path_length = self.remove_observations()
             print(f'    #pc {self.store.n_frames} |', f'path length {path_length:.2f}')
+        self._after_integrate()
         return idx
 
     def obs2sem_vec_space(self, rgb, pc, sem_gt=None) -> tuple:

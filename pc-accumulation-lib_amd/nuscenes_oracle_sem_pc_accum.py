@@ -89,6 +89,7 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
             path_length = 0
         print(f'    ts {self.ts} | #pc {self.store.n_frames} |', f'path length {path_length:.2f}')
         self.ts += 1
+        self._after_integrate()
 
     def _ego_world(self, T_ego_global, ego_pose_z):
         T_ego_world = self.T_global_world @ T_ego_global

@@ -34,6 +34,7 @@ class DeviceStore:
         self._pending = None     # (T 4x4, end slot): a re-transform owed to slots [head, end slot)
         self._k1_cache = None
         self._ws = None
+        self._dedup_ws = None
 
     # ---- memory ----------------------------------------------------------------------------
     def _alloc(self, cap):
@@ -211,6 +212,22 @@ class DeviceStore:
         ctx = self.ctx
         ctx.check(ctx.lib.pca_mark_dynamic(ctx.h, C.byref(st), self.frame_off.data_ptr(), slots, insts, len(pairs),
                                            ctx.stream()))
+
+    def voxel_dedup(self, voxel_size):
+        """Opt-in (no reference counterpart): of all live points in one voxel floor(xyz / voxel_size) only the first
+        in store order (the oldest observation) stays; frames are compacted in place, order-preserving."""
+        if self.n_frames == 0:
+            return
+        self.flush_pending()
+        ctx, lib = self.ctx, self.ctx.lib
+        max_points = self.max_window_points()
+        need = lib.pca_voxel_dedup_workspace_bytes(max_points, self.n_frames)
+        if self._dedup_ws is None or self._dedup_ws.numel() < need:
+            self._dedup_ws = torch.empty(int(need) + 256, dtype=torch.uint8, device=self.device)
+        st = self.c_store()
+        ctx.check(lib.pca_voxel_dedup(ctx.h, C.byref(st), self.frame_off.data_ptr(), self.head, self.tail,
+                                      float(voxel_size), max_points, self._dedup_ws.data_ptr(),
+                                      self._dedup_ws.numel(), ctx.stream()))
 
     # ---- BEV ------------------------------------------------------------------------------
     def bev(self, split_frame, prm, want_f64=False, intensity64=None, first_frame=0, last_frame=None, out16=None,

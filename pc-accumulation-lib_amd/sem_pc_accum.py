@@ -40,6 +40,12 @@ class SemanticPointCloudAccumulator:
         self.semsegs = []
         self._store = None               # created on first use (needs the GPU)
         self._store_args = {}
+        # opt-in voxel de-duplication of the accumulation buffer (extension, off by default: the reference only
+        # evicts whole frames).  Set the attribute, or PCA_VOXEL_DEDUP=<voxel size in m> [PCA_VOXEL_DEDUP_EVERY=<k>].
+        env = os.environ.get('PCA_VOXEL_DEDUP')
+        self.voxel_dedup = float(env) if env else None
+        self.voxel_dedup_every = int(os.environ.get('PCA_VOXEL_DEDUP_EVERY', '1'))
+        self._integrated = 0
 
         self.sem_bev_generator = None
         if bev_params['type'] == 'sem':
@@ -88,6 +94,11 @@ class SemanticPointCloudAccumulator:
 
     def obs2sem_vec_space(self, rgb, pc, sem_gt=None) -> tuple:
         raise NotImplementedError()
+
+    def _after_integrate(self):
+        self._integrated += 1
+        if self.voxel_dedup and self._integrated % max(self.voxel_dedup_every, 1) == 0:
+            self.store.voxel_dedup(self.voxel_dedup)
 
     def update_poses(self, T_new_prev):
         self._track.apply_transform(T_new_prev)

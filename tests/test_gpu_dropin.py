@@ -393,3 +393,52 @@ def test_prefetching_loader_and_async_writer(tmp_path, monkeypatch):
     table, lo = compose_label_lut(base.idx2idx)
     ids = np.arange(-1, 46, dtype=np.int16)[:, None]
     assert np.array_equal(table[:47], conv_semantic_ids(ids.copy(), base.idx2idx)[:, 0])
+
+
+def test_kitti_accumulator_voxel_dedup_option(golden):
+    """Opt-in extension: acc.voxel_dedup = size de-duplicates the buffer after every integrate().  Model: the same
+    sequence WITHOUT the option gives every point's coordinates (transforms are per point, so survivors are bitwise
+    identical); a numpy survivor mask (first point per voxel in store order) is carried from step to step."""
+    from PIL import Image
+
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    g = golden('kitti_accum')
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': g['P']}
+    size = 0.4
+
+    def make():
+        a = Kitti360SemanticPointCloudAccumulator(1e9, calib, 1e3, 'fake.onnx', KITTI_FILTERS, SEM_IDXS, False,
+                                                  dict(BEV_KITTI))
+        q = list(g['Ts'])
+        a.pose_provider = lambda pc: q.pop(0)
+        return a
+    plain, dd = make(), make()
+    assert dd.voxel_dedup is None                       # off by default
+    dd.voxel_dedup = size
+    alive = []                                           # per frame: survivor mask over the plain frame's rows
+    n_steps = min(int(g['F']), 8)
+    for k in range(n_steps):
+        obs = [(Image.fromarray(g[f'img_{k}']), g[f'pc_{k}'], None)]
+        plain.integrate(obs)
+        dd.integrate(obs)
+        frames = plain.sem_pcs
+        alive.append(np.ones(frames[-1].shape[0], bool))
+        cand = np.concatenate([f[m] for f, m in zip(frames, alive)])
+        vox = np.floor(cand[:, :3] / size).astype(np.int64)
+        _, first = np.unique(vox, axis=0, return_index=True)
+        keep = np.zeros(len(cand), bool)
+        keep[first] = True
+        pos = 0
+        for j, m in enumerate(alive):
+            cnt = int(m.sum())
+            idx = np.flatnonzero(m)
+            m[idx[~keep[pos:pos + cnt]]] = False
+            pos += cnt
+        got = dd.sem_pcs
+        assert len(got) == len(frames)
+        for j, (f, m) in enumerate(zip(frames, alive)):
+            assert np.array_equal(got[j], f[m]), (k, j)
+    assert sum(int(m.sum()) for m in alive) < sum(len(m) for m in alive)
+    bevs = dd.generate_bev(n_steps // 2, 1, gen_future=True)     # the rasteriser runs on the thinned buffer
+    assert bevs[0]['road_full'].shape == (32, 32)
+    dd.store.check_status()

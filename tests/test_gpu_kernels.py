@@ -510,3 +510,45 @@ def test_bev_extra_reducers_max_mean(T):
         assert np.all(ex[s, 1].ravel()[obs] >= elev[7 * s + 6].ravel()[obs] - 1e-12)
     p16b, p64b = st.bev(1, prm, want_f64=True)
     assert T.equal(p64, p64b) and T.equal(p16, p16b)
+
+
+@pytest.mark.parametrize('n_frames,size', [(1, 0.5), (7, 0.2), (40, 1.0)])
+def test_voxel_dedup_first_point_per_voxel_stays(T, n_frames, size):
+    """Opt-in voxel de-duplication (no reference counterpart): numpy model = first occurrence per voxel in store
+    order; frames stay contiguous and ordered; a second call changes nothing; BEV still runs on the result."""
+    rng = np.random.default_rng(n_frames)
+    frames = []
+    for f in range(n_frames):
+        m = int(rng.integers(0, 9000)) if f % 5 else 0           # includes empty frames
+        rows = np.zeros((m, 10))
+        rows[:, :3] = rng.normal(0, 3.0, (m, 3)) + [0.1 * f, 0, 0]
+        rows[:, 3] = rng.integers(0, 256, m)
+        rows[:, 4:7] = rng.integers(0, 256, (m, 3))
+        rows[:, 7] = rng.integers(0, 19, m)
+        rows[:, 8] = rng.integers(-1, 5, m)
+        rows[:, 9] = rng.random(m) < 0.1
+        frames.append(rows)
+    if n_frames == 1:
+        dense = np.zeros((5000, 10))
+        dense[:, :3] = rng.normal(0, 1.0, (5000, 3))
+        frames = [np.concatenate([frames[0], dense])]
+    st = dev_store(capacity=max(sum(r.shape[0] for r in frames), 1), max_frames=n_frames + 1)
+    assert st.load_rows(frames) is None
+    st.voxel_dedup(size)
+    st.check_status()
+    allrows = np.concatenate(frames)
+    vox = np.floor(allrows[:, :3] / size).astype(np.int64)
+    _, first = np.unique(vox, axis=0, return_index=True)
+    keep = np.zeros(len(allrows), bool)
+    keep[first] = True
+    bounds = np.concatenate([[0], np.cumsum([r.shape[0] for r in frames])])
+    got = st.frame_rows()
+    assert len(got) == n_frames
+    for f in range(n_frames):
+        want = allrows[bounds[f]:bounds[f + 1]][keep[bounds[f]:bounds[f + 1]]]
+        assert np.array_equal(got[f], want), f'frame {f}'
+    sizes_before = st.sizes().copy()
+    st.voxel_dedup(size)                                      # idempotent
+    assert np.array_equal(st.sizes(), sizes_before)
+    assert all(np.array_equal(a, b) for a, b in zip(st.frame_rows(), got))
+    assert 0 < keep.sum() < len(allrows) or len(allrows) == 0
