@@ -193,13 +193,14 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
                         uint16_t *planes_f16 /*dev*/, double *extra_planes /*dev, may be NULL*/, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Optional per-kernel timing: while enabled every kernel launch is bracketed by HIP events recorded on
- * the call's stream.  pca_profile_read synchronises, returns the accumulated time / launch count of one
+ * Optional timing with HIP events recorded on the call's stream.  on = 1: every kernel launch is bracketed
+ * (ids PCA_K_KITTI .. PCA_K_DEDUP); on = 2: only whole multi-kernel units are (PCA_K_BEV_UNIT = one
+ * pca_bev_generate call, launch gaps included, without the per-kernel events in between); 0: off.  pca_profile_read synchronises, returns the accumulated time / launch count of one
  * kernel id since the last pca_profile_enable(ctx, 1) and keeps recording.  (No reference counterpart.)
  * ------------------------------------------------------------------------------------------------ */
 enum {
     PCA_K_KITTI = 0, PCA_K_NUSC, PCA_K_PROJECT_CAMS, PCA_K_RETRANSFORM, PCA_K_MARK_DYNAMIC,
-    PCA_K_BEV_BIN, PCA_K_BEV_SCAN, PCA_K_BEV_SCATTER, PCA_K_BEV_CELLS, PCA_K_BEV_CELLS_HEAVY, PCA_K_DEDUP, PCA_K_COUNT
+    PCA_K_BEV_BIN, PCA_K_BEV_SCAN, PCA_K_BEV_SCATTER, PCA_K_BEV_CELLS, PCA_K_BEV_CELLS_HEAVY, PCA_K_DEDUP, PCA_K_BEV_UNIT, PCA_K_COUNT
 };
 int pca_profile_enable(pca_ctx *ctx, int on);
 int pca_profile_read(pca_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);

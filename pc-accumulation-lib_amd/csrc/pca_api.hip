@@ -55,7 +55,7 @@ int pca_profile_enable(pca_ctx *ctx, int on)
 {
     if (!ctx) return -1;
     prof_fold(ctx);
-    ctx->profiling = on != 0;
+    ctx->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
     if (on) for (int k = 0; k < PCA_K_COUNT; ++k) { ctx->prof_ms[k] = 0; ctx->prof_n[k] = 0; }
     return 0;
 }

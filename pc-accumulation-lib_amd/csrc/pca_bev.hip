@@ -866,6 +866,7 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
     a.epoch = pca_ctx_next_epoch(ctx, s);
     const size_t lds = (size_t)a.T * 4;
     const int heavy_grid = a.T < ctx->n_cu ? a.T : ctx->n_cu;          // one resident workgroup per CU draws from the queue
+    if (ctx->profiling == 2) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
     PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_hist, dim3(a.G), dim3(AB_THREADS), lds, s, a);
     PCA_LAUNCH(ctx, PCA_K_BEV_SCAN, bev_tile_scan, dim3(a.scan_tiles), dim3(SCAN_THREADS), s, a);
     if (intensity64) {
@@ -877,6 +878,7 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
         PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_tile_cells<false>, dim3(a.T), dim3(C_THREADS), s, a);
         PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, bev_tile_cells_heavy<false>, dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a);
     }
+    if (ctx->profiling == 2) pca_prof_end(ctx, s);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }

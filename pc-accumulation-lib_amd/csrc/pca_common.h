@@ -31,7 +31,7 @@ struct pca_ctx {
     int dbg_blocks = 0;
     // optional per-kernel event timing
     struct Ev { hipEvent_t a, b; int kid; };
-    bool profiling = false;
+    int profiling = 0;                // 0 off, 1 every kernel launch, 2 whole units only (pca_profile_enable)
     std::vector<Ev> evs;              // recorded pairs not yet folded into the totals
     std::vector<Ev> free_evs;         // recycled events
     double prof_ms[PCA_K_COUNT] = {0};
@@ -43,9 +43,9 @@ void pca_prof_begin(pca_ctx *ctx, int kid, hipStream_t s);
 void pca_prof_end(pca_ctx *ctx, hipStream_t s);
 #define PCA_LAUNCH_SHM(ctx, kid, kernel, grid, block, shm, stream, ...)        \
     do {                                                                        \
-        if ((ctx)->profiling) pca_prof_begin((ctx), (kid), (stream));           \
+        if ((ctx)->profiling == 1) pca_prof_begin((ctx), (kid), (stream));      \
         hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);      \
-        if ((ctx)->profiling) pca_prof_end((ctx), (stream));                    \
+        if ((ctx)->profiling == 1) pca_prof_end((ctx), (stream));               \
     } while (0)
 #define PCA_LAUNCH(ctx, kid, kernel, grid, block, stream, ...) \
     PCA_LAUNCH_SHM(ctx, kid, kernel, grid, block, 0, stream, __VA_ARGS__)

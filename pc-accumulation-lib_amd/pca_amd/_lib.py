@@ -21,7 +21,7 @@ EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error',
            'pca_profile_enable', 'pca_profile_read')
 
 KERNEL_IDS = ('kitti_project_sample_filter', 'nusc_sample_filter_transform', 'nusc_project_cams', 'retransform',
-              'mark_dynamic', 'bev_bin', 'bev_scan', 'bev_scatter', 'bev_cells', 'bev_cells_heavy', 'voxel_dedup')
+              'mark_dynamic', 'bev_bin', 'bev_scan', 'bev_scatter', 'bev_cells', 'bev_cells_heavy', 'voxel_dedup', 'bev_unit')
 BEV_EXTRA_PLANES = ('elevation_max', 'elevation_mean', 'intensity_mean')
 
 
@@ -151,7 +151,8 @@ class Context:
             raise RuntimeError('pca: ' + self.lib.pca_last_error(self.h).decode())
 
     def profile(self, on):
-        self.check(self.lib.pca_profile_enable(self.h, int(bool(on))))
+        """0/False off, 1/True per kernel launch, 2 whole units only (pca.h: pca_profile_enable)."""
+        self.check(self.lib.pca_profile_enable(self.h, int(on)))
 
     def profile_read(self):
         """{kernel name: (total_ms, launches)} since profiling was enabled (synchronises)."""

@@ -1,5 +1,6 @@
 """Full integrate()/generate_bev() sequences of the reference (golden fixtures) reproduced with the
 oracle kernels + the product's host logic (pose track, eviction, tracker, trajectories).  CPU only."""
+import pytest
 import numpy as np
 
 from oracle import oracle as orc
@@ -181,3 +182,14 @@ def test_ego_split_transform_equals_three_separate_transforms():
         want = [hl.transform_traj(t.copy(), R, dx, dy, view, px) for t in (pts[:split], pts[split:], pts)]
         for got, w in zip((p, f, a), want):
             assert got.shape == w.shape and np.array_equal(got, w), (trial, n, split)
+
+
+def test_pts_feat_from_img_nearest_and_optin_bilinear(golden):
+    """datasets/nuscenes_utils.py:181-214: 'nearest' is what every caller uses (and what K1n fuses); 'bilinear' is
+    the reference's unused branch (2-D maps only), kept as an opt-in and pinned on its own output."""
+    from datasets.nuscenes_utils import pts_feat_from_img
+    g = golden('utils')
+    assert np.array_equal(pts_feat_from_img(g['pf_uv'], g['pf_img'], 'nearest'), g['pf_nearest'])
+    assert np.array_equal(pts_feat_from_img(g['pf_uv_bil'], g['pf_img'][..., 0], 'bilinear'), g['pf_bilinear'])
+    with pytest.raises(AssertionError):
+        pts_feat_from_img(np.array([[0.5, 5.0]]), g['pf_img'], 'nearest')
