@@ -25,7 +25,8 @@
 #define AB_THREADS 1024           // workgroup size of the hist / scatter kernels
 #define MAX_G 512                 // workgroups of the hist / scatter kernels
 #define C_THREADS 256             // workgroup size of the tile kernel
-#define RGB_CAP 4096              // colour records resident in LDS per batch of cells
+#define RGB_CAP 4096              // colour records resident in LDS: larger tiles go to bev_tile_cells_heavy
+#define CONTIG_MIN 2560           // tiles above this many records are read thread-contiguously (runs form)
 #define FLAG_ROAD (1u << 24)
 #define FLAG_DYNOBJ (1u << 25)
 
@@ -47,11 +48,13 @@ struct BevArgs {
     Mat34 pend_T;         // owed re-transform of slots [slot_begin, pend_slot_end), fused into the hist kernel
     int pend_slot_end;    // <= slot_begin: none
     int tx, T, G;
+    int tile_mult;        // bev_tile_cells: workgroup -> tile permutation (coprime to T)
     uint32_t *key;        // [max_points]
     uint32_t *bh;         // [T][G] kept records per (tile, workgroup)
     uint32_t *boff;       // [T][G] exclusive scan of bh in that order
     uint32_t *tile_off;   // [T+1]
-    uint32_t *heavy;      // [2+T]: count, cursor, ids of the tiles bev_tile_cells leaves to bev_tile_cells_heavy
+    uint32_t *heavy;      // [3+T]: heavy count, heavy cursor, tile ticket of bev_tile_cells, ids of the tiles it
+                          //        leaves to bev_tile_cells_heavy
     void *recs;           // RecF / RecD [max_points], tile-ordered; c = r | g<<8 | b<<16 | FLAG_*
     double *planes;
     uint16_t *planes_f16;
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void bev_tile_scan(const BevArgs a)
     __shared__ uint32_t s_w[SCAN_THREADS / 64];
     __shared__ uint64_t s_excl;
     const int n = a.T * a.G;
-    if (threadIdx.x == 0 && blockIdx.x == 0) { a.heavy[0] = 0; a.heavy[1] = 0; }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { a.heavy[0] = 0; a.heavy[1] = 0; a.heavy[2] = 0; }
     if (threadIdx.x == 0) {
         const uint32_t t = atomicAdd(a.ticket, 1u);
         if ((int)t == a.scan_tiles - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -210,6 +213,10 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_scatter(const BevArgs a)
 {
     extern __shared__ uint32_t s_cur[];                     // [T]
     const Window w = chunk_of(a);
+    // queue of the tiles whose records exceed the LDS colour buffer of bev_tile_cells: they are bev_tile_cells_heavy's
+    if (blockIdx.x == 0)
+        for (int t = threadIdx.x; t < a.T; t += AB_THREADS)
+            if (a.tile_off[t + 1] - a.tile_off[t] > RGB_CAP) a.heavy[3 + atomicAdd(&a.heavy[0], 1u)] = (uint32_t)t;
     for (int t = threadIdx.x; t < a.T; t += AB_THREADS) s_cur[t] = a.boff[(int64_t)t * a.G + blockIdx.x];
     __syncthreads();
     const pca_bev_params &q = a.prm;
@@ -277,85 +284,57 @@ __device__ __forceinline__ void stats_init(TileStats &S, int nthreads)
     for (int k = threadIdx.x; k < 3 * TCELLS * 3; k += nthreads) (&S.med2[0][0][0])[k] = 0;
 }
 
-// Per (cell,set) statistics of the records a wave holds one per lane; returns each record's rank inside its
-// (cell,set).  Records that arrive together are neighbours in space (consecutive lidar returns), so in a real
-// accumulation most of a wave shares one (cell,set) -- and 64 LDS atomics on one address cost 2 cycles per lane on
-// the CU's only LDS pipe (tools/experiments/lds_atomics.hip).  Groups of at least AGG_MIN lanes holding the leading
-// lane's key are therefore reduced on the VALU (DPP) and accounted by one lane; what is left takes per-lane atomics.
-// Must be called by the whole wave (valid = this lane holds a record).
-#define AGG_MIN 12
-__device__ __forceinline__ uint32_t stats_account_wave(TileStats &S, bool extra, bool valid, uint32_t k, uint32_t c, double z,
-                                                       double iv)
+// Per (cell,set) statistics are accumulated by every THREAD over a run of consecutive records with the same key and
+// reach LDS once per run.  Records that arrive together are neighbours in space (consecutive lidar returns), so in a
+// real accumulation a thread's contiguous chunk of a dense tile lies in one or two cells; LDS atomics on one address
+// cost 2 cycles per lane on the CU's only LDS pipe (tools/experiments/lds_atomics.hip), a register add costs nothing.
+// (With random keys every run has length one and this degenerates to one set of atomics per record.)
+struct Run {
+    uint32_t key, cnt, road, dyn;
+    unsigned long long zmin, zmax;
+    long long ihi, ilo, zhi, zlo;
+};
+#define RUN_NONE 0xffffffffu
+__device__ __forceinline__ void run_reset(Run &r, uint32_t key)
 {
-    const int lane = threadIdx.x & 63;
+    r.key = key; r.cnt = 0; r.road = 0; r.dyn = 0; r.zmin = ~0ull; r.zmax = 0; r.ihi = 0; r.ilo = 0; r.zhi = 0; r.zlo = 0;
+}
+__device__ __forceinline__ void run_add(Run &r, bool extra, uint32_t c, double z, double iv)
+{
     const unsigned long long zkey = f64_order_key(z);
-    const bool road = valid && (c & FLAG_ROAD), dynobj = valid && (c & FLAG_DYNOBJ);
-    long long ihi = 0, ilo = 0;
-    if (road) {
+    r.cnt++;
+    r.zmin = zkey < r.zmin ? zkey : r.zmin;
+    if (extra) {
+        const double sc = z * FX_HI, fl = floor(sc);
+        r.zmax = zkey > r.zmax ? zkey : r.zmax;
+        r.zhi += (long long)fl;
+        r.zlo += (long long)rint((sc - fl) * FX_LO);
+    }
+    if (c & FLAG_DYNOBJ) r.dyn++;
+    if (c & FLAG_ROAD) {
         const double sc = iv * FX_HI, fl = floor(sc);
-        ihi = (long long)fl;
-        ilo = (long long)rint((sc - fl) * FX_LO);
+        r.road++;
+        r.ihi += (long long)fl;
+        r.ilo += (long long)rint((sc - fl) * FX_LO);
     }
-    uint32_t rank = 0;
-    uint64_t todo = __ballot(valid);
-    for (int round = 0; round < 4 && todo; ++round) {
-        const int lead = (int)__ffsll((unsigned long long)todo) - 1;
-        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)k, lead);
-        const bool in = ((todo >> lane) & 1ull) && k == k0;
-        const uint64_t m = __ballot(in);
-        const uint32_t g = (uint32_t)__popcll(m);
-        const uint64_t rm = __ballot(in && road);
-        // sums are formed in 32-bit pieces: ihi below 2^25 per record (intensity < 32), ilo <= 2^40 in two 20-bit halves
-        if (g < AGG_MIN || __ballot(in && road && ((unsigned long long)ihi >> 25) != 0)) break;
-        const uint32_t zh = (uint32_t)(zkey >> 32), zl = (uint32_t)zkey;
-        const uint32_t mh = wave_reduce_min(in ? zh : 0xffffffffu);
-        const uint32_t ml = wave_reduce_min(in && zh == mh ? zl : 0xffffffffu);
-        uint32_t s_ihi = 0, s_il0 = 0, s_il1 = 0;
-        if (rm) {
-            const bool r = in && road;
-            s_ihi = wave_reduce_add(r ? (uint32_t)ihi : 0u);
-            s_il0 = wave_reduce_add(r ? (uint32_t)ilo & 0xfffffu : 0u);
-            s_il1 = wave_reduce_add(r ? (uint32_t)((unsigned long long)ilo >> 20) : 0u);
-        }
-        const uint32_t n_dyn = (uint32_t)__popcll(__ballot(in && dynobj));
-        uint32_t base = 0;
-        if (lane == lead) {
-            base = atomicAdd(&S.cnt[k0], g);
-            atomicMin(&S.zk[k0], ((unsigned long long)mh << 32) | ml);
-            if (n_dyn) atomicAdd(&S.dyn[k0], n_dyn);
-            if (rm) {
-                atomicAdd(&S.road[k0], (uint32_t)__popcll(rm));
-                atomicAdd(&S.ihi[k0], (unsigned long long)s_ihi);
-                atomicAdd(&S.ilo[k0], ((unsigned long long)s_il1 << 20) + s_il0);
-            }
-        }
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, lead);
-        if (in) rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (extra && in) {
-            const double sc = z * FX_HI, fl = floor(sc);
-            atomicMax(&S.zmaxk[k], zkey);
-            atomicAdd(&S.zhi[k], (unsigned long long)(long long)fl);
-            atomicAdd(&S.zlo[k], (unsigned long long)(long long)rint((sc - fl) * FX_LO));
-        }
-        todo &= ~m;
+}
+// returns the rank of the run's first record inside its (cell,set)
+__device__ __forceinline__ uint32_t run_flush(TileStats &S, bool extra, const Run &r)
+{
+    const uint32_t base = atomicAdd(&S.cnt[r.key], r.cnt);
+    atomicMin(&S.zk[r.key], r.zmin);
+    if (extra) {
+        atomicMax(&S.zmaxk[r.key], r.zmax);
+        atomicAdd(&S.zhi[r.key], (unsigned long long)r.zhi);
+        atomicAdd(&S.zlo[r.key], (unsigned long long)r.zlo);
     }
-    if ((todo >> lane) & 1ull) {
-        rank = atomicAdd(&S.cnt[k], 1u);
-        atomicMin(&S.zk[k], zkey);
-        if (extra) {
-            const double sc = z * FX_HI, fl = floor(sc);
-            atomicMax(&S.zmaxk[k], zkey);
-            atomicAdd(&S.zhi[k], (unsigned long long)(long long)fl);
-            atomicAdd(&S.zlo[k], (unsigned long long)(long long)rint((sc - fl) * FX_LO));
-        }
-        if (dynobj) atomicAdd(&S.dyn[k], 1u);
-        if (road) {
-            atomicAdd(&S.road[k], 1u);
-            atomicAdd(&S.ihi[k], (unsigned long long)ihi);
-            atomicAdd(&S.ilo[k], (unsigned long long)ilo);
-        }
+    if (r.dyn) atomicAdd(&S.dyn[r.key], r.dyn);
+    if (r.road) {
+        atomicAdd(&S.road[r.key], r.road);
+        atomicAdd(&S.ihi[r.key], (unsigned long long)r.ihi);
+        atomicAdd(&S.ilo[r.key], (unsigned long long)r.ilo);
     }
-    return rank;
+    return base;
 }
 
 template <bool I64>
@@ -574,6 +553,8 @@ __device__ __forceinline__ void wave_cells_hist(TileLds &L, const uint32_t *s_rg
     }
 }
 
+__device__ unsigned long long g_dbg_stamps[1024][8];   // PCA_BEV_DBG=8|16: per-tile phase stamps (diagnostics)
+#define DBG_STAMP(bit, slot) do { if ((a.dbg & (bit)) && threadIdx.x == 0 && tile < 1024) g_dbg_stamps[tile][slot] = wall_clock64(); } while (0)
 template <bool I64>
 __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
 {
@@ -581,40 +562,61 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
     __shared__ __align__(16) unsigned char s_buf[RGB_CAP * 4 > OUT_STAGE_BYTES ? RGB_CAP * 4 : OUT_STAGE_BYTES];
     uint32_t *s_rgb = reinterpret_cast<uint32_t *>(s_buf);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x;
-    const uint32_t r_lo = a.tile_off[tile], r_hi = a.tile_off[tile + 1];
-    if (r_hi - r_lo > RGB_CAP) {                            // bev_tile_cells_heavy's: queue it
-        if (threadIdx.x == 0) a.heavy[2 + atomicAdd(&a.heavy[0], 1u)] = (uint32_t)tile;
-        return;
-    }
     const bool extra = a.extra != nullptr;
+    // Dense tiles are neighbours in the grid (they follow the driven path).  Workgroup b takes tile b * tile_mult mod T
+    // (tile_mult coprime to T), which interleaves them with the empty ones in dispatch order.
+    const int tile = (int)(((int64_t)blockIdx.x * a.tile_mult) % a.T);
+    const uint32_t r_lo = a.tile_off[tile], r_hi = a.tile_off[tile + 1];
+    if (r_hi - r_lo > RGB_CAP) return;                      // bev_tile_cells_heavy's (queued by bev_tile_scatter)
+    const unsigned long long t_begin = wall_clock64();
     stats_init(L.S, C_THREADS);
     __syncthreads();
 
-    // ---- pass 1: per (cell,set) statistics with LDS atomics; every thread keeps its <= RPT records' (key, rank,
-    // colour) in registers -- the rank comes back from the counting atomic -- so that pass 2 is a pure LDS scatter
+    // ---- pass 1: per (cell,set) statistics; every thread keeps its <= RPT records' (key, rank, colour) in registers
+    // -- the rank is the run's base (returned by the counting atomic) + the position in the run -- so that pass 2 is
+    // a pure LDS scatter.  Sparse tiles are read coalesced (record u*C_THREADS + t); dense ones give every thread a
+    // contiguous chunk so that runs form (16 records = two cache lines per lane).
     constexpr int RPT = RGB_CAP / C_THREADS;
     constexpr int HALF = RPT / 2;                           // two rounds of loads: bounds the registers in flight
-    uint32_t kr[RPT], cc[RPT];
+    const bool contig = (r_hi - r_lo) > CONTIG_MIN;
+    uint32_t kr[RPT], cc[RPT], end_base[RPT];
+    uint32_t is_end = 0;
+    Run run;
+    run_reset(run, RUN_NONE);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         uint32_t k[HALF], c[HALF];
         double z[HALF], iv[HALF];
 #pragma unroll
         for (int u = 0; u < HALF; ++u) {
-            const uint32_t r = r_lo + (h * HALF + u) * C_THREADS + threadIdx.x;
-            k[u] = 0xffffffffu; c[u] = 0; z[u] = 0; iv[u] = 0;
+            const int uu = h * HALF + u;
+            const uint32_t r = r_lo + (contig ? threadIdx.x * RPT + uu : uu * C_THREADS + threadIdx.x);
+            k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
             if (r < r_hi) load_rec<I64>(a, r, k[u], c[u], z[u], iv[u]);
         }
 #pragma unroll
         for (int u = 0; u < HALF; ++u) {
-            const bool valid = k[u] != 0xffffffffu;
-            const uint32_t rank = stats_account_wave(L.S, extra, valid, k[u], c[u], z[u], iv[u]);
-            kr[h * HALF + u] = valid ? (k[u] | (rank << 8)) : 0xffffffffu;
-            cc[h * HALF + u] = c[u] & 0xffffffu;
+            const int uu = h * HALF + u;
+            kr[uu] = RUN_NONE; cc[uu] = c[u] & 0xffffffu; end_base[uu] = 0;
+            if (k[u] == RUN_NONE) continue;
+            if (k[u] != run.key) {
+                if (run.key != RUN_NONE && uu > 0) { end_base[uu - 1] = run_flush(L.S, extra, run); is_end |= 1u << (uu - 1); }
+                run_reset(run, k[u]);
+            }
+            kr[uu] = k[u] | (run.cnt << 8);                 // position in the run, for now
+            run_add(run, extra, c[u], z[u], iv[u]);
+        }
+    }
+    {
+        uint32_t b = run.key != RUN_NONE ? run_flush(L.S, extra, run) : 0u;
+#pragma unroll
+        for (int uu = RPT - 1; uu >= 0; --uu) {
+            if ((is_end >> uu) & 1u) b = end_base[uu];
+            if (kr[uu] != RUN_NONE) kr[uu] += b << 8;
         }
     }
     __syncthreads();
+    DBG_STAMP(16, 3);
     // ---- offsets of the (cell,set) segments inside the tile ----
     if (wave == 0) {
         const uint32_t c0 = L.S.cnt[2 * lane], c1 = L.S.cnt[2 * lane + 1];
@@ -630,13 +632,22 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
     for (int u = 0; u < RPT; ++u)
         if (kr[u] != 0xffffffffu) s_rgb[L.off[kr[u] & 127u] + (kr[u] >> 8)] = cc[u];
     __syncthreads();
+    DBG_STAMP(16, 4);
     small_cells_bitplanes(L, s_rgb);
     __syncthreads();
     small_cells_select(L);
     __syncthreads();                                        // the bit planes' LDS becomes the per-wave histograms
+    DBG_STAMP(16, 5);
     wave_cells_hist(L, s_rgb);
     __syncthreads();
+    DBG_STAMP(16, 6);
     tile_finalize_write(a, L.S, reinterpret_cast<double(*)[TCELLS]>(s_buf), tile, C_THREADS);
+    if ((a.dbg & 16) && threadIdx.x == 0 && tile < 1024) {
+        g_dbg_stamps[tile][0] = t_begin; g_dbg_stamps[tile][1] = wall_clock64(); g_dbg_stamps[tile][2] = r_hi - r_lo;
+        uint32_t big = 0;
+        for (int c = 0; c < TCELLS; ++c) big += (L.S.cnt[2 * c] + L.S.cnt[2 * c + 1]) > 64;
+        g_dbg_stamps[tile][7] = __smid() | ((unsigned long long)big << 32);
+    }
 }
 
 // ---- heavy tiles: 1024 threads, 16-bit-packed 256-bin histograms per (cell, set, channel) for half of the
@@ -680,7 +691,6 @@ __device__ __forceinline__ void heavy_hist32(HeavyLds &L, const BevArgs &a, uint
     }
 }
 
-__device__ unsigned long long g_dbg_stamps[1024][8];
 template <bool I64>
 __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs a)
 {
@@ -698,7 +708,7 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs 
     __syncthreads();
     const uint32_t item = s_next;
     if (item >= n_heavy) break;
-    const int tile = (int)a.heavy[2 + item];
+    const int tile = (int)a.heavy[3 + item];
     if (item >= (uint32_t)gridDim.x) t_begin = wall_clock64();
     const uint32_t r_lo = a.tile_off[tile], r_hi = a.tile_off[tile + 1];
     stats_init(L.S, H_THREADS);
@@ -706,26 +716,35 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs 
     for (int half = 0; half < TCELLS / H_CELLS; ++half) {
         for (int k = threadIdx.x; k < H_HIST_DWORDS / 4; k += H_THREADS) reinterpret_cast<uint4 *>(hist)[k] = make_uint4(0, 0, 0, 0);
         __syncthreads();
+        // every thread walks a contiguous chunk of the tile's records (runs form: see Run)
         constexpr int UNR = 4;
-        for (uint32_t r0 = r_lo; r0 < r_hi; r0 += UNR * H_THREADS) {
+        const uint32_t per_thread = (r_hi - r_lo + H_THREADS - 1) / H_THREADS;
+        const uint32_t t_lo = r_lo + threadIdx.x * per_thread;
+        const uint32_t t_hi = t_lo + per_thread < r_hi ? t_lo + per_thread : r_hi;
+        Run run;
+        run_reset(run, RUN_NONE);
+        for (uint32_t r0 = t_lo; r0 < t_hi; r0 += UNR) {
             uint32_t k[UNR], c[UNR];
             double z[UNR], iv[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const uint32_t r = r0 + u * H_THREADS + threadIdx.x;
-                k[u] = 0xffffffffu; c[u] = 0; z[u] = 0; iv[u] = 0;
-                if (r < r_hi) load_rec<I64>(a, r, k[u], c[u], z[u], iv[u]);
+                k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
+                if (r0 + u < t_hi) load_rec<I64>(a, r0 + u, k[u], c[u], z[u], iv[u]);
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const bool valid = k[u] != 0xffffffffu && (int)(k[u] >> 1) / H_CELLS == half;
-                stats_account_wave(L.S, extra, valid, k[u], c[u], z[u], iv[u]);
-                if (!valid) continue;
+                if (k[u] == RUN_NONE || (int)(k[u] >> 1) / H_CELLS != half) continue;
+                if (k[u] != run.key) {
+                    if (run.key != RUN_NONE) run_flush(L.S, extra, run);
+                    run_reset(run, k[u]);
+                }
+                run_add(run, extra, c[u], z[u], iv[u]);
                 uint32_t *row = hist + ((((k[u] >> 1) % H_CELLS) * 2 + (k[u] & 1u)) * 3) * 128;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) hist16_add(row + ch * 128, (c[u] >> (8 * ch)) & 255u, 1u);
             }
         }
+        if (run.key != RUN_NONE) run_flush(L.S, extra, run);
         __syncthreads();
         if ((a.dbg & 8) && threadIdx.x == 0 && tile < 1024) g_dbg_stamps[tile][3 + 2 * half] = wall_clock64();
         for (int job = wave; job < H_CELLS * 3; job += H_THREADS / 64) {
@@ -795,7 +814,7 @@ int64_t pca_bev_workspace_bytes(int64_t max_points, int px)
 {
     if (max_points < 1) max_points = 1;
     const int64_t T = (int64_t)tiles_x(px) * tiles_x(px), G = n_groups(max_points);
-    return align256(max_points * 4) + 2 * align256(G * T * 4) + align256((T + 1) * 4) + align256((T + 2) * 4) +
+    return align256(max_points * 4) + 2 * align256(G * T * 4) + align256((T + 1) * 4) + align256((T + 3) * 4) +
            align256(max_points * 24) + 512;
 }
 
@@ -844,7 +863,7 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
     a.bh = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)a.G * a.T * 4);
     a.boff = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)a.G * a.T * 4);
     a.tile_off = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.T + 1) * 4);
-    a.heavy = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.T + 2) * 4);
+    a.heavy = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.T + 3) * 4);
     a.recs = w;
     a.planes = planes;
     a.planes_f16 = planes_f16;
@@ -865,10 +884,18 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
     a.ticket = ctx->ticket;
     a.epoch = pca_ctx_next_epoch(ctx, s);
     const size_t lds = (size_t)a.T * 4;
+    {
+        auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
+        int m = (int)(a.T * 0.6180339887) | 1;
+        while (m > 1 && gcd(m, a.T) != 1) m -= 2;
+        a.tile_mult = m < 1 ? 1 : m;
+    }
     const int heavy_grid = a.T < ctx->n_cu ? a.T : ctx->n_cu;          // one resident workgroup per CU draws from the queue
     if (ctx->profiling == 2) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
     PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_hist, dim3(a.G), dim3(AB_THREADS), lds, s, a);
     PCA_LAUNCH(ctx, PCA_K_BEV_SCAN, bev_tile_scan, dim3(a.scan_tiles), dim3(SCAN_THREADS), s, a);
+    // (Running the two tile kernels side by side was tried: a second stream with fork / join events costs ~20 us per
+    // call, and hipExtAnyOrderLaunch is not honoured on gfx9 -- see DESIGN.md.)
     if (intensity64) {
         PCA_LAUNCH_SHM(ctx, PCA_K_BEV_SCATTER, bev_tile_scatter<true>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
         PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_tile_cells<true>, dim3(a.T), dim3(C_THREADS), s, a);
