@@ -161,12 +161,12 @@ def make_accumulator(frame_fn, seq):
     return acc, pool, model
 
 
-def ring_model_pass(steps):
+def ring_model_pass(steps, frame_fn=None):
     """The same step on ring-model frames (rank 0 only, after the headline measurement): steady-state time per
     step and per-kernel HIP-event times.  Reported beside the headline number, never as `value`."""
     import torch
     from pca_amd import _lib
-    acc, pool, _ = make_accumulator(ring_frame, 0)
+    acc, pool, _ = make_accumulator(frame_fn or ring_frame, 0)
     n = [0]
 
     def step(out=None):

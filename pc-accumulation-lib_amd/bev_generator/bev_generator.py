@@ -89,13 +89,27 @@ class BEVGenerator(ABC):
 
     # ------------------------------------------------------------------ raster (device) ----
     def _raster_params(self, origin, rot_mat, dx, dy, aug_view_size, intensity_div255):
+        """pca_bev_params of one sample.  The constant part (grid, intensity transform, class sets) is built once per
+        generator; origin / rotation / shift / view -- the first 15 doubles of the struct -- are copied in per call."""
+        import ctypes
+
         from pca_amd.device_store import make_bev_params
-        sem_idxs = getattr(self, 'sem_idxs', None) or {}
-        dyn_cls = [sem_idxs[k] for k in ('car', 'truck', 'bus', 'motorcycle') if k in sem_idxs]
-        return make_bev_params(origin, rot_mat, dx, dy, aug_view_size, self.pixel_size, self.height_filter,
-                               self.int_scaler, self.int_sep_scaler, self.int_mid_threshold,
-                               sem_idxs.get('road', -1), dyn_cls, intensity_div255,
-                               getattr(self, 'rgb_fill', 0))
+        key = ('prm', bool(intensity_div255), self.pixel_size, self.height_filter, self.int_scaler,
+               self.int_sep_scaler, self.int_mid_threshold, getattr(self, 'rgb_fill', 0))
+        prm = self._tmp.get(key)
+        if prm is None:
+            sem_idxs = getattr(self, 'sem_idxs', None) or {}
+            dyn_cls = [sem_idxs[k] for k in ('car', 'truck', 'bus', 'motorcycle') if k in sem_idxs]
+            prm = self._tmp[key] = make_bev_params(np.zeros(3), np.eye(3), 0., 0., 1., self.pixel_size,
+                                                   self.height_filter, self.int_scaler, self.int_sep_scaler,
+                                                   self.int_mid_threshold, sem_idxs.get('road', -1), dyn_cls,
+                                                   intensity_div255, getattr(self, 'rgb_fill', 0))
+        head = np.empty(15)
+        head[0:3] = origin
+        head[3:12] = np.asarray(rot_mat, dtype=np.float64).reshape(9)
+        head[12], head[13], head[14] = dx, dy, aug_view_size
+        ctypes.memmove(ctypes.addressof(prm), head.ctypes.data, 120)
+        return prm
 
     def _tmp_store(self, key):
         from pca_amd.device_store import DeviceStore

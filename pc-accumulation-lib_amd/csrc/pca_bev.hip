@@ -453,8 +453,8 @@ struct TileLds {
 };
 
 // ---- medians of cells with at most 64 values: bit-sliced radix select -------------------------------------
-// Phase 1 (per cell, whole wave): the cell's values sit one per lane (present lanes first); 24 ballots give
-// the 64-bit membership mask of every colour bit, parked in LDS.
+// Phase 1 (per cell, whole wave): the cell's values sit one per lane (present lanes first); a cross-lane bit
+// transpose gives the 64-bit membership mask of every colour bit, parked in LDS.
 // Phase 2 (per wave): one LANE per (cell, set, channel, lower|upper middle) target -- 18 per cell -- walks the 8
 // bit planes from the top: zeros = cand & ~plane; rank < popcount(zeros) ? keep zeros : (rank -= ..., keep ones,
 // set the bit).  That is ~12 VALU per plane for 64 targets at once instead of a 21-stage sort per channel.
@@ -466,13 +466,10 @@ __device__ __forceinline__ void small_cells_bitplanes(TileLds &L, const uint32_t
         const uint32_t n = L.S.cnt[2 * cell] + L.S.cnt[2 * cell + 1];
         if (n == 0 || n > 64) continue;
         const uint32_t v = (uint32_t)lane < n ? s_rgb[L.off[2 * cell] + lane] : 0u;
-        unsigned long long mine = 0;
-#pragma unroll
-        for (int b = 0; b < 24; ++b) {
-            const unsigned long long m = __ballot((v >> b) & 1u);
-            mine = (lane == b) ? m : mine;
-        }
-        if (lane < 24) L.bits[cell][lane] = mine;
+        // 64 values x 24 bits -> 24 masks of 64 lanes: a bit-matrix transpose across lanes (30 VALU; 24 ballots with
+        // their select chains were 130)
+        const uint32_t t = wave_bit_transpose32(v);
+        if ((lane & 31) < 24) reinterpret_cast<uint32_t *>(&L.bits[cell][lane & 31])[lane >> 5] = t;
     }
 }
 

@@ -50,3 +50,37 @@ __device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v)
 PCA_WAVE_REDUCE(wave_reduce_add, 0u, PCA_OP_ADD)
 PCA_WAVE_REDUCE(wave_reduce_min, 0xffffffffu, PCA_OP_MIN)
 PCA_WAVE_REDUCE(wave_reduce_max, 0u, PCA_OP_MAX)
+
+// ---------------------------------------------------------------------------------------------
+// 32 x 32 bit-matrix transpose across lanes, done at once in both halves of the wave: on entry lane l holds row
+// (l & 31) of its half; on return bit j of lane l is bit (l & 31) of the entry value of lane (l & 32) + j.
+// Five butterfly stages; partners come over DPP / v_permlane16_swap, nothing goes through LDS.
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__device__ __forceinline__ uint32_t lane_xor_fetch(uint32_t x)
+{
+    if (S == 1) return dpp_or<0xb1>(0u, x);                                   // quad_perm [1,0,3,2]
+    if (S == 2) return dpp_or<0x4e>(0u, x);                                   // quad_perm [2,3,0,1]
+    if (S == 4) return dpp_or<0x1b>(0u, dpp_or<0x141>(0u, x));                // row_half_mirror (^7) then [3,2,1,0] (^3)
+    if (S == 8) return dpp_or<0x128>(0u, x);                                  // row_ror:8
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);      // r[0] = rows x0 x0 x2 x2, r[1] = x1 x1 x3 x3
+    return (threadIdx.x & 16) ? r[0] : r[1];
+}
+template <int S, uint32_t M>
+__device__ __forceinline__ uint32_t transpose_stage(uint32_t x)
+{
+    const bool lo = !(threadIdx.x & S);
+    const uint32_t p = lane_xor_fetch<S>(x);
+    const uint32_t moved = lo ? (p << S) : (p >> S);
+    const uint32_t keep = lo ? M : ~M;                      // M = bit positions with bit S clear
+    return (x & keep) | (moved & ~keep);
+}
+__device__ __forceinline__ uint32_t wave_bit_transpose32(uint32_t x)
+{
+    x = transpose_stage<16, 0x0000ffffu>(x);
+    x = transpose_stage<8, 0x00ff00ffu>(x);
+    x = transpose_stage<4, 0x0f0f0f0fu>(x);
+    x = transpose_stage<2, 0x33333333u>(x);
+    x = transpose_stage<1, 0x55555555u>(x);
+    return x;
+}

@@ -140,7 +140,7 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
     def get_dyn_obj_trajs(self, ts_start: int = 0, ts_end: int = None, skip_ego_traj: bool = True):
         out = self._tracker.trajectories(ts_start, ts_end)
         if not skip_ego_traj:
-            out.append(self.poses)
+            out.append(self._track.as_array().tolist())
         return out
 
     # ---- BEV -----------------------------------------------------------------------------------

@@ -143,7 +143,11 @@ class Context:
         return cls._by_device[idx]
 
     def stream(self):
+        """Raw handle of torch's current stream on this device (every call targets it)."""
         import torch
+        raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)      # ~10x cheaper than current_stream()
+        if raw is not None:
+            return C.c_void_p(raw(self.device_index))
         return C.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream)
 
     def check(self, rc):

@@ -31,9 +31,11 @@ class DeviceStore:
         self.ub_tail = 0         # upper bound of frame_off[tail]
         self.lb_head = 0         # lower bound of frame_off[head] (exact after a sync)
         self._ub = []            # per live frame: upper bound of its size (its input point count)
+        self._ub_sum = 0         # sum(self._ub), kept incrementally
         self._pending = None     # (T 4x4, end slot): a re-transform owed to slots [head, end slot)
         self._k1_cache = None
         self._ws = None
+        self._ws_points, self._ws_px = 0, 0
         self._dedup_ws = None
 
     # ---- memory ----------------------------------------------------------------------------
@@ -68,6 +70,7 @@ class DeviceStore:
         self.lb_head = int(off[0])
         self.ub_tail = int(off[-1])
         self._ub = [int(v) for v in np.diff(off)]
+        self._ub_sum = sum(self._ub)
         return off
 
     def sizes(self):
@@ -113,15 +116,17 @@ class DeviceStore:
 
     def evict(self, k):
         self.head += int(k)
+        self._ub_sum -= sum(self._ub[:int(k)])
         del self._ub[:int(k)]
 
     def max_window_points(self):
-        return max(int(sum(self._ub)), 1)
+        return max(self._ub_sum, 1)
 
     def clear(self):
         self.head = self.tail = 0
         self.ub_tail = self.lb_head = 0
         self._ub = []
+        self._ub_sum = 0
         self._pending = None
         self.frame_off.zero_()
 
@@ -156,6 +161,7 @@ class DeviceStore:
         self.tail += len(frames)
         self.ub_tail += n_in
         self._ub += [int(f['pts'].shape[0]) for f in frames]
+        self._ub_sum += n_in
 
     # ---- K1n: NuScenes --------------------------------------------------------------------
     def append_nusc(self, pc, cam_idx, imgs, sems, T, filters):
@@ -172,6 +178,7 @@ class DeviceStore:
         self.tail += 1
         self.ub_tail += n
         self._ub.append(n)
+        self._ub_sum += n
 
     # ---- K2 / K3 --------------------------------------------------------------------------
     def retransform(self, Ts, defer=False):
@@ -239,9 +246,12 @@ class DeviceStore:
         last_frame = self.n_frames if last_frame is None else last_frame
         px = int(prm.px)
         max_points = self.max_window_points()
-        need = lib.pca_bev_workspace_bytes(max_points, px)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        if self._ws is None or max_points > self._ws_points or px != self._ws_px:
+            # sized with headroom so that a window growing frame by frame does not reallocate every call
+            self._ws_points, self._ws_px = int(max_points * 1.25) + 1, px
+            need = lib.pca_bev_workspace_bytes(self._ws_points, px)
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(int(need) + 256, dtype=torch.uint8, device=self.device)
         if out16 is not None:
             assert out16.dtype == torch.float16 and out16.is_contiguous() and tuple(out16.shape) == (21, px, px)
         p16 = out16 if out16 is not None else torch.empty((21, px, px), dtype=torch.float16, device=self.device)
@@ -327,6 +337,7 @@ class DeviceStore:
         self.head, self.tail = 0, len(rows_list)
         self.lb_head, self.ub_tail = 0, total
         self._ub = [int(r.shape[0]) for r in rows_list]
+        self._ub_sum = sum(self._ub)
         return i64
 
 

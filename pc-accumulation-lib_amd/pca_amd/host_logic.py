@@ -18,6 +18,7 @@ Reference behaviour restated (file:line relative to the reference root):
 """
 import math
 import random
+from collections.abc import Sequence
 
 import numpy as np
 
@@ -45,6 +46,36 @@ def incremental_path_dists(seg_dists):
     return np.matmul(tri, d)
 
 
+class ArrayList(Sequence):
+    """Read-only list view of an array snapshot: behaves like the reference's list (of lists) for len / index /
+    iteration / comparison / np.array(), but costs nothing until an element is actually looked at (the drivers ask
+    for len(acc.poses) once per frame)."""
+
+    def __init__(self, arr):
+        self._a = arr
+
+    def __len__(self):
+        return self._a.shape[0]
+
+    def __getitem__(self, i):
+        return self._a[i].tolist()
+
+    def __iter__(self):
+        return iter(self._a.tolist())
+
+    def __array__(self, dtype=None, copy=None):
+        return np.array(self._a, dtype=dtype)
+
+    def tolist(self):
+        return self._a.tolist()
+
+    def __eq__(self, other):
+        return self._a.tolist() == (other.tolist() if isinstance(other, (ArrayList, np.ndarray)) else other)
+
+    def __repr__(self):
+        return repr(self._a.tolist())
+
+
 class PoseTrack:
     """Ego poses of the live frames and the segment distances between them.
 
@@ -53,12 +84,16 @@ class PoseTrack:
     gemv, whose rounding differs from a (4,4)@(4,F) gemm) -- but issues them as one stacked matmul."""
 
     def __init__(self):
-        self._P = np.zeros((0, 3))
+        self._H = np.zeros((0, 4, 1))    # homogeneous column vectors [x, y, z, 1]: the matmul operand, kept as is
         self._D = np.zeros(0)            # segment distances between consecutive poses
 
     @property
+    def _P(self):
+        return self._H[:, :3, 0]
+
+    @property
     def seg_dists(self):
-        return self._D.tolist()
+        return ArrayList(self._D.copy())
 
     @seg_dists.setter
     def seg_dists(self, value):
@@ -69,14 +104,16 @@ class PoseTrack:
 
     @property
     def poses(self):
-        return self._P.tolist()
+        return ArrayList(self._P.copy())
 
     @poses.setter
     def poses(self, value):
-        self._P = np.array(value, dtype=np.float64).reshape(-1, 3)
+        P = np.array(value, dtype=np.float64).reshape(-1, 3)
+        self._H = np.ones((P.shape[0], 4, 1))
+        self._H[:, :3, 0] = P
 
     def __len__(self):
-        return self._P.shape[0]
+        return self._H.shape[0]
 
     def pose(self, idx):
         return self._P[idx].copy()
@@ -86,17 +123,20 @@ class PoseTrack:
 
     def apply_transform(self, T):
         """Every stored pose p <- (T @ [p,1])[:3]."""
-        if self._P.shape[0] == 0:
+        if self._H.shape[0] == 0:
             return
-        homo = np.concatenate([self._P, np.ones((self._P.shape[0], 1))], axis=1)[:, :, None]   # (F,4,1)
-        self._P = np.ascontiguousarray(np.matmul(T, homo)[:, :3, 0])
+        H = np.matmul(T, self._H)        # (F,4,1): one gemv per pose, as the reference issues them
+        H[:, 3, 0] = 1.0
+        self._H = H
 
     def append(self, pose):
-        self._P = np.concatenate([self._P, np.asarray(pose, dtype=np.float64).reshape(1, 3)])
+        h = np.ones((1, 4, 1))
+        h[0, :3, 0] = np.asarray(pose, dtype=np.float64).reshape(3)
+        self._H = np.concatenate([self._H, h])
 
     def push_segment(self):
         """Appends the distance between the two newest poses; returns the total path length."""
-        self._D = np.append(self._D, pose_dist(self._P[-1], self._P[-2]))
+        self._D = np.append(self._D, pose_dist(self._H[-1, :3, 0], self._H[-2, :3, 0]))
         return np.sum(self._D)
 
     def evict_beyond(self, horizon_dist, path_length):
@@ -106,7 +146,7 @@ class PoseTrack:
         incr = incremental_path_dists(self._D)
         incr -= path_length - horizon_dist
         k = int((incr > 0.).argmax())
-        self._P = self._P[k:]
+        self._H = self._H[k:]
         self._D = self._D[k:]
         return k
 

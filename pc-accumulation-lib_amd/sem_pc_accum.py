@@ -124,7 +124,7 @@ class SemanticPointCloudAccumulator:
         return hl.incremental_path_dists(seg_dists)
 
     def get_segment_dists(self) -> list:
-        return self.seg_dists
+        return self._track.seg_array().tolist()
 
     def get_incremental_path_dists(self) -> np.array:
         return hl.incremental_path_dists(self._track.seg_array())

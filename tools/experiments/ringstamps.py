@@ -5,7 +5,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'pc-accumulation-lib_amd')
 import numpy as np, builtins, bench
 rp = builtins.print
 builtins.print = lambda *a, **k: None
-r = bench.ring_model_pass(5)
+r = bench.ring_model_pass(5, bench.synth_frame if os.environ.get('SCENE') == 'uniform' else None)
 builtins.print = rp
 from pca_amd import _lib
 lib = _lib.Context.get().lib
