@@ -141,6 +141,23 @@ int pca_voxel_dedup(pca_ctx *ctx, const pca_store *store, int64_t *frame_off /*d
                     void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Point-to-plane ICP between two lidar sweeps.  Replaces the Open3D calls
+ *       sem_pc_accum.py:310-315 (estimate_normals, default 30 nearest neighbours) and
+ *       kitti360_sem_pc_accum.py:115-127 (registration_icp(source = previous sweep, target = new sweep, threshold,
+ *       init, PointToPlane), defaults: <= 30 iterations, relative fitness / rmse 1e-6).
+ *     Open3D is a third-party, unpinned dependency of the reference: parity is UNPINNED; the tests check known
+ *     motions and a k-d-tree CPU model of this algorithm.  Neighbour searches are exact inside a cap (normals 3 m,
+ *     correspondences min(max_corr_dist, 4 m)); sweeps must lie within +-128 m (x, y), -16..16 m (z) of the sensor.
+ *     src_pts / tgt_pts: dev [n,4] f32 rows x,y,z,(ignored).  init / T_out: host 4x4 row-major; T_out maps source
+ *     coordinates into the target frame (T_new_prev).  Synchronises `stream` before returning.
+ * ------------------------------------------------------------------------------------------------ */
+int64_t pca_icp_workspace_bytes(int32_t max_points);
+int pca_icp_register(pca_ctx *ctx, const float *src_pts /*dev*/, int32_t n_src, const float *tgt_pts /*dev*/,
+                     int32_t n_tgt, double max_corr_dist, const double init[16], int max_iter, double rel_fitness,
+                     double rel_rmse, void *workspace /*dev*/, int64_t workspace_bytes, double T_out[16],
+                     double *fitness, double *rmse, int *iterations, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K4-K7  BEV rasteriser: window [slot_begin, slot_end), 'present' = [slot_begin, slot_split),
  *     'future' = [slot_split, slot_end), 'full' = both.  Replaces
  *       kitti360_sem_pc_accum.py:189-213 / nuscenes_oracle_sem_pc_accum.py:535-581 (window assembly, origin),
@@ -200,7 +217,7 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
  * ------------------------------------------------------------------------------------------------ */
 enum {
     PCA_K_KITTI = 0, PCA_K_NUSC, PCA_K_PROJECT_CAMS, PCA_K_RETRANSFORM, PCA_K_MARK_DYNAMIC,
-    PCA_K_BEV_BIN, PCA_K_BEV_SCAN, PCA_K_BEV_SCATTER, PCA_K_BEV_CELLS, PCA_K_BEV_CELLS_HEAVY, PCA_K_DEDUP, PCA_K_BEV_UNIT, PCA_K_COUNT
+    PCA_K_BEV_BIN, PCA_K_BEV_SCAN, PCA_K_BEV_SCATTER, PCA_K_BEV_CELLS, PCA_K_BEV_CELLS_HEAVY, PCA_K_DEDUP, PCA_K_BEV_UNIT, PCA_K_ICP, PCA_K_COUNT
 };
 int pca_profile_enable(pca_ctx *ctx, int on);
 int pca_profile_read(pca_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);

@@ -81,12 +81,14 @@ int pca_ctx_create(int device, pca_ctx **out)
         hipMemset(ctx->ticket, 0, 2 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&ctx->ticket64, sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(ctx->ticket64, 0, sizeof(unsigned long long)) != hipSuccess ||
-        hipHostMalloc(&ctx->status_host, sizeof(uint32_t)) != hipSuccess) {
+        hipHostMalloc(&ctx->status_host, sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc(&ctx->heavy_hint, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) {
         delete ctx;
         return -1;
     }
     int n_cu = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) ctx->n_cu = n_cu;
+    *ctx->heavy_hint = 1;            // first call: assume heavy tiles exist
     *out = ctx;
     return 0;
 }
@@ -100,6 +102,7 @@ void pca_ctx_destroy(pca_ctx *ctx)
     if (ctx->ticket64) (void)hipFree(ctx->ticket64);
     if (ctx->frames_dev) (void)hipFree(ctx->frames_dev);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
+    if (ctx->heavy_hint) (void)hipHostFree(ctx->heavy_hint);
     prof_fold(ctx);
     for (auto &e : ctx->free_evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete ctx;

@@ -53,6 +53,7 @@ struct BevArgs {
     uint32_t *bh;         // [T][G] kept records per (tile, workgroup)
     uint32_t *boff;       // [T][G] exclusive scan of bh in that order
     uint32_t *tile_off;   // [T+1]
+    uint32_t *heavy_hint; // host-visible word: the heavy count of this call, read by the host before the next one
     uint32_t *heavy;      // [3+T]: heavy count, heavy cursor, tile ticket of bev_tile_cells, ids of the tiles it
                           //        leaves to bev_tile_cells_heavy
     void *recs;           // RecF / RecD [max_points], tile-ordered; c = r | g<<8 | b<<16 | FLAG_*
@@ -699,6 +700,7 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool extra = a.extra != nullptr;
     const uint32_t n_heavy = a.heavy[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.heavy_hint = n_heavy;
     // the queued tiles are drawn one at a time: a 12 000-record tile takes several times longer than a 4 100-record one
     for (;;) {
     if (threadIdx.x == 0) s_next = atomicAdd(&a.heavy[1], 1u);
@@ -887,7 +889,13 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
         while (m > 1 && gcd(m, a.T) != 1) m -= 2;
         a.tile_mult = m < 1 ? 1 : m;
     }
-    const int heavy_grid = a.T < ctx->n_cu ? a.T : ctx->n_cu;          // one resident workgroup per CU draws from the queue
+    // one resident workgroup per CU draws from the queue -- when the previous call had no heavy tile (uniform data)
+    // only a few are launched: any number of them drains the queue, and 256 idle 110-KiB workgroups cost ~5 us
+    int heavy_grid = a.T < ctx->n_cu ? a.T : ctx->n_cu;
+    if (*ctx->heavy_hint == 0 && heavy_grid > 16) heavy_grid = 16;
+    void *hint_dev = nullptr;
+    PCA_CHECK(ctx, hipHostGetDevicePointer(&hint_dev, ctx->heavy_hint, 0));
+    a.heavy_hint = reinterpret_cast<uint32_t *>(hint_dev);
     if (ctx->profiling == 2) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
     PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_hist, dim3(a.G), dim3(AB_THREADS), lds, s, a);
     PCA_LAUNCH(ctx, PCA_K_BEV_SCAN, bev_tile_scan, dim3(a.scan_tiles), dim3(SCAN_THREADS), s, a);

@@ -27,6 +27,7 @@ struct pca_ctx {
     pca_kitti_frame *frames_dev = nullptr;
     int frames_cap = 0;
     uint32_t *status_host = nullptr;  // pinned
+    uint32_t *heavy_hint = nullptr;   // pinned, device-visible: heavy-tile count of the latest rasteriser call
     unsigned long long *dbg = nullptr; // diagnostic stamps of the last K1 launch (PCA_K1_STAMPS)
     int dbg_blocks = 0;
     // optional per-kernel event timing

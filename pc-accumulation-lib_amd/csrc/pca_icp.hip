@@ -1,0 +1,353 @@
+// pca_icp.hip -- point-to-plane ICP between two lidar sweeps on the device.
+//
+// Replaces the reference's only remaining native dependency on the KITTI-360 flow:
+//     sem_pc_accum.py:310-315        pc2pcd: Open3D PointCloud + estimate_normals()   (default: 30 nearest neighbours)
+//     kitti360_sem_pc_accum.py:115-127  registration_icp(source = previous sweep, target = new sweep, threshold, init,
+//                                       TransformationEstimationPointToPlane())        (defaults: <= 30 iterations,
+//                                       relative fitness / rmse 1e-6)
+// Open3D is third-party and unpinned (README.md:14): PARITY IS UNPINNED.  The tests check known motions and a CPU model
+// of this same algorithm (exact k-d tree neighbours), not Open3D.
+//
+//   icp_grid_insert   uniform grid (0.5 m cells, 256 m x 256 m x 32 m around the sensor) as per-cell linked lists
+//   icp_normals       per target point: the K = 30 nearest neighbours (shell-by-shell grid search, exact within the
+//                     search cap), covariance, eigenvector of the smallest eigenvalue (cyclic Jacobi, f64)
+//   icp_accumulate    per source point: q = T p, nearest target point (exact within the cap), r = (q - t).n,
+//                     J = [q x n, n]; per-workgroup partial sums of J^T J, J^T r, |q - t|^2, inlier count
+//   icp_solve         one workgroup: fixed-order reduction of the partials (deterministic), 6x6 Cholesky solve,
+//                     T <- exp(x) T, fitness / rmse, convergence flag -- the iteration loop never leaves the device
+#include "pca_common.h"
+
+#define ICP_CELL 0.5
+#define ICP_NX 512
+#define ICP_NY 512
+#define ICP_NZ 64
+#define ICP_OX (-128.0)
+#define ICP_OY (-128.0)
+#define ICP_OZ (-16.0)
+#define ICP_K 30                 // neighbours of a normal (Open3D's default KDTreeSearchParamKNN)
+#define ICP_NORMAL_RINGS 6       // search cap of the normals: 3 m
+#define ICP_MATCH_RINGS 8        // search cap of a correspondence: 4 m (the reference passes 1e3 m = everything)
+#define ICP_THREADS 256
+#define ICP_NACC 30              // 21 (J^T J upper) + 6 (J^T r) + sum d^2 + inliers + sum r^2
+
+struct IcpArgs {
+    const float *src;            // [n_src,4]
+    const float *tgt;            // [n_tgt,4]
+    int n_src, n_tgt;
+    int32_t *head;               // [NX*NY*NZ] first target point of the cell, -1 = empty
+    int32_t *next;               // [n_tgt]
+    float *normal;               // [n_tgt,4]  nx, ny, nz, valid
+    double *partial;             // [grid][ICP_NACC]
+    double *state;               // [0..15] T (row-major), [16] fitness, [17] rmse, [18] prev fitness, [19] prev rmse,
+                                 // [20] converged flag, [21] iterations done
+    double max_dist2;
+    double rel_fitness, rel_rmse;
+    int grid;
+};
+
+__device__ __forceinline__ bool icp_cell_of(double x, double y, double z, int &cx, int &cy, int &cz)
+{
+    const double fx = floor((x - ICP_OX) / ICP_CELL), fy = floor((y - ICP_OY) / ICP_CELL), fz = floor((z - ICP_OZ) / ICP_CELL);
+    if (!(fx >= 0 && fx < ICP_NX && fy >= 0 && fy < ICP_NY && fz >= 0 && fz < ICP_NZ)) return false;
+    cx = (int)fx; cy = (int)fy; cz = (int)fz;
+    return true;
+}
+__device__ __forceinline__ int icp_cell_index(int cx, int cy, int cz) { return (cz * ICP_NY + cy) * ICP_NX + cx; }
+
+__global__ __launch_bounds__(ICP_THREADS) void icp_grid_insert(const IcpArgs a)
+{
+    const int p = blockIdx.x * ICP_THREADS + threadIdx.x;
+    if (p >= a.n_tgt) return;
+    const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
+    int cx, cy, cz;
+    if (!icp_cell_of(v.x, v.y, v.z, cx, cy, cz)) { a.next[p] = -2; return; }     // outside the grid: never matched
+    a.next[p] = atomicExch(&a.head[icp_cell_index(cx, cy, cz)], p);
+}
+
+// visits every target point of the shell of Chebyshev radius r around cell (cx,cy,cz)
+template <typename F>
+__device__ __forceinline__ void icp_visit_shell(const IcpArgs &a, int cx, int cy, int cz, int r, F &&f)
+{
+    for (int dz = -r; dz <= r; ++dz) {
+        const int z = cz + dz;
+        if (z < 0 || z >= ICP_NZ) continue;
+        for (int dy = -r; dy <= r; ++dy) {
+            const int y = cy + dy;
+            if (y < 0 || y >= ICP_NY) continue;
+            const bool face = (dz == -r || dz == r || dy == -r || dy == r);
+            for (int dx = -r; dx <= r; dx += (face || r == 0) ? 1 : 2 * r) {     // interior rows: only the two end cells
+                const int x = cx + dx;
+                if (x < 0 || x >= ICP_NX) continue;
+                for (int q = a.head[icp_cell_index(x, y, z)]; q >= 0; q = a.next[q]) f(q);
+            }
+        }
+    }
+}
+
+// symmetric 3x3 eigen decomposition by cyclic Jacobi rotations; returns the eigenvector of the smallest eigenvalue
+__device__ __forceinline__ void icp_smallest_eigvec(double A[3][3], double n[3])
+{
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300) break;
+#pragma unroll
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+            if (fabs(A[p][q]) < 1e-300) continue;
+            const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double akp = A[k][p], akq = A[k][q];
+                A[k][p] = c * akp - s * akq;
+                A[k][q] = s * akp + c * akq;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double apk = A[p][k], aqk = A[q][k];
+                A[p][k] = c * apk - s * aqk;
+                A[q][k] = s * apk + c * aqk;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double vkp = V[k][p], vkq = V[k][q];
+                V[k][p] = c * vkp - s * vkq;
+                V[k][q] = s * vkp + c * vkq;
+            }
+        }
+    }
+    int m = 0;
+    if (A[1][1] < A[m][m]) m = 1;
+    if (A[2][2] < A[m][m]) m = 2;
+    n[0] = V[0][m]; n[1] = V[1][m]; n[2] = V[2][m];
+}
+
+__global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
+{
+    __shared__ float s_d[ICP_K][ICP_THREADS];               // per thread: the K smallest squared distances, ascending
+    const int p = blockIdx.x * ICP_THREADS + threadIdx.x;
+    if (p >= a.n_tgt) return;
+    const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
+    float4 out = make_float4(0.f, 0.f, 1.f, 0.f);
+    int cx, cy, cz;
+    if (icp_cell_of(v.x, v.y, v.z, cx, cy, cz)) {
+        const int t = threadIdx.x;
+        int found = 0;
+        for (int r = 0; r <= ICP_NORMAL_RINGS; ++r) {
+            icp_visit_shell(a, cx, cy, cz, r, [&](int q) {
+                const float4 w = reinterpret_cast<const float4 *>(a.tgt)[q];
+                const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                if (found == ICP_K && d2 >= s_d[ICP_K - 1][t]) return;
+                int i = found < ICP_K ? found : ICP_K - 1;                      // insertion into the sorted list
+                while (i > 0 && s_d[i - 1][t] > d2) { s_d[i][t] = s_d[i - 1][t]; --i; }
+                s_d[i][t] = d2;
+                if (found < ICP_K) ++found;
+            });
+            // every unvisited point is farther than r cells: the list is final once its last entry is inside that
+            if (found == ICP_K && s_d[ICP_K - 1][t] <= (float)(r * ICP_CELL) * (float)(r * ICP_CELL)) break;
+        }
+        if (found >= 3) {
+            const float lim = s_d[found - 1][t];
+            const int rmax = (int)ceil(sqrt((double)lim) / ICP_CELL);
+            double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+            int cnt = 0;
+            for (int r = 0; r <= rmax && r <= ICP_NORMAL_RINGS; ++r)
+                icp_visit_shell(a, cx, cy, cz, r, [&](int q) {
+                    const float4 w = reinterpret_cast<const float4 *>(a.tgt)[q];
+                    const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z;
+                    if (dx * dx + dy * dy + dz * dz > lim) return;
+                    const double x = dx, y = dy, z = dz;                        // relative to the query: well conditioned
+                    sx += x; sy += y; sz += z;
+                    sxx += x * x; sxy += x * y; sxz += x * z; syy += y * y; syz += y * z; szz += z * z;
+                    ++cnt;
+                });
+            const double inv = 1.0 / cnt;
+            const double mx = sx * inv, my = sy * inv, mz = sz * inv;
+            double A[3][3];
+            A[0][0] = sxx * inv - mx * mx; A[0][1] = sxy * inv - mx * my; A[0][2] = sxz * inv - mx * mz;
+            A[1][1] = syy * inv - my * my; A[1][2] = syz * inv - my * mz; A[2][2] = szz * inv - mz * mz;
+            A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
+            double n[3];
+            icp_smallest_eigvec(A, n);
+            const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            if (len > 0) out = make_float4((float)(n[0] / len), (float)(n[1] / len), (float)(n[2] / len), 1.f);
+        }
+    }
+    reinterpret_cast<float4 *>(a.normal)[p] = out;
+}
+
+__global__ __launch_bounds__(ICP_THREADS) void icp_accumulate(const IcpArgs a)
+{
+    __shared__ double s_red[ICP_THREADS / 64][ICP_NACC];
+    double acc[ICP_NACC];
+#pragma unroll
+    for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
+    const bool done = a.state[20] != 0.0;
+    const double *T = a.state;
+    for (int p = blockIdx.x * ICP_THREADS + threadIdx.x; p < a.n_src && !done; p += a.grid * ICP_THREADS) {
+        const float4 v = reinterpret_cast<const float4 *>(a.src)[p];
+        const double qx = T[0] * v.x + T[1] * v.y + T[2] * v.z + T[3];
+        const double qy = T[4] * v.x + T[5] * v.y + T[6] * v.z + T[7];
+        const double qz = T[8] * v.x + T[9] * v.y + T[10] * v.z + T[11];
+        int cx, cy, cz;
+        if (!icp_cell_of(qx, qy, qz, cx, cy, cz)) continue;
+        double best = a.max_dist2;
+        int bi = -1;
+        for (int r = 0; r <= ICP_MATCH_RINGS; ++r) {
+            icp_visit_shell(a, cx, cy, cz, r, [&](int q) {
+                const float4 w = reinterpret_cast<const float4 *>(a.tgt)[q];
+                const double dx = w.x - qx, dy = w.y - qy, dz = w.z - qz;
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 < best || (d2 == best && q < bi)) { best = d2; bi = q; }   // ties: lowest index (list order varies)
+            });
+            if (bi >= 0 && best <= (r * ICP_CELL) * (r * ICP_CELL)) break;
+        }
+        if (bi < 0) continue;
+        const float4 w = reinterpret_cast<const float4 *>(a.tgt)[bi];
+        const float4 nn = reinterpret_cast<const float4 *>(a.normal)[bi];
+        acc[27] += best;                                    // Open3D: fitness / rmse over all correspondences
+        acc[28] += 1.0;
+        if (nn.w == 0.f) continue;                          // no normal: the pair carries no point-to-plane row
+        const double nx = nn.x, ny = nn.y, nz = nn.z;
+        const double r = (qx - w.x) * nx + (qy - w.y) * ny + (qz - w.z) * nz;
+        const double J[6] = {qy * nz - qz * ny, qz * nx - qx * nz, qx * ny - qy * nx, nx, ny, nz};
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) acc[k++] += J[i] * J[j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[21 + i] += J[i] * r;
+        acc[29] += r * r;
+    }
+    // fixed-order reduction: lanes (butterfly), waves (serial), workgroups (icp_solve, serial) -> deterministic
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < ICP_NACC; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) s_red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < ICP_NACC) {
+        double v = 0.0;
+        for (int w = 0; w < ICP_THREADS / 64; ++w) v += s_red[w][threadIdx.x];
+        a.partial[(size_t)blockIdx.x * ICP_NACC + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void icp_solve(const IcpArgs a)
+{
+    __shared__ double s_sum[ICP_NACC];
+    if (a.state[20] != 0.0) return;
+    if (threadIdx.x < ICP_NACC) {
+        double v = 0.0;
+        for (int b = 0; b < a.grid; ++b) v += a.partial[(size_t)b * ICP_NACC + threadIdx.x];
+        s_sum[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double *S = a.state;
+    const double inl = s_sum[28];
+    const double fitness = a.n_src > 0 ? inl / a.n_src : 0.0;
+    const double rmse = inl > 0 ? sqrt(s_sum[27] / inl) : 0.0;
+    // Open3D evaluates fitness / rmse of the CURRENT transform, then updates; convergence compares successive evaluations
+    const bool first = S[21] == 0.0;
+    S[16] = fitness; S[17] = rmse;
+    if (!first && fabs(S[18] - fitness) < a.rel_fitness && fabs(S[19] - rmse) < a.rel_rmse) { S[20] = 1.0; return; }
+    S[18] = fitness; S[19] = rmse;
+    if (inl < 6) { S[20] = 1.0; return; }
+    // solve (J^T J) x = -J^T r  (Cholesky, upper triangle stored row-wise in s_sum[0..20])
+    double A[6][6], b[6], x[6];
+    int k = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) { A[i][j] = A[j][i] = s_sum[k++]; }
+    for (int i = 0; i < 6; ++i) b[i] = -s_sum[21 + i];
+    bool ok = true;
+    for (int i = 0; i < 6 && ok; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i][j];
+            for (int m = 0; m < j; ++m) s -= A[i][m] * A[j][m];
+            if (i == j) { if (!(s > 1e-12)) { ok = false; break; } A[i][i] = sqrt(s); }
+            else A[i][j] = s / A[j][j];
+        }
+    }
+    if (!ok) { S[20] = 1.0; return; }
+    for (int i = 0; i < 6; ++i) { double s = b[i]; for (int m = 0; m < i; ++m) s -= A[i][m] * x[m]; x[i] = s / A[i][i]; }
+    for (int i = 5; i >= 0; --i) { double s = x[i]; for (int m = i + 1; m < 6; ++m) s -= A[m][i] * x[m]; x[i] = s / A[i][i]; }
+    // x = (alpha, beta, gamma, tx, ty, tz): R = Rz(gamma) Ry(beta) Rx(alpha)
+    const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+    const double U[12] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa, x[3],
+                          sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa, x[4],
+                          -sb, cb * sa, cb * ca, x[5]};
+    double N[12];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j)
+            N[4 * i + j] = U[4 * i] * S[j] + U[4 * i + 1] * S[4 + j] + U[4 * i + 2] * S[8 + j] + (j == 3 ? U[4 * i + 3] : 0.0);
+    for (int i = 0; i < 12; ++i) S[i] = N[i];
+    S[21] += 1.0;
+}
+
+extern "C" {
+
+static inline int64_t icp_align(int64_t v) { return (v + 255) & ~255ll; }
+static inline int icp_grid(int n) { const int g = (n + ICP_THREADS - 1) / ICP_THREADS; return g < 1 ? 1 : (g > 1024 ? 1024 : g); }
+
+int64_t pca_icp_workspace_bytes(int32_t max_points)
+{
+    if (max_points < 1) max_points = 1;
+    return icp_align((int64_t)ICP_NX * ICP_NY * ICP_NZ * 4) + icp_align((int64_t)max_points * 4) + icp_align((int64_t)max_points * 16) +
+           icp_align((int64_t)1024 * ICP_NACC * 8) + icp_align(32 * 8) + 512;
+}
+
+int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const float *tgt_pts, int32_t n_tgt,
+                     double max_corr_dist, const double init[16], int max_iter, double rel_fitness, double rel_rmse,
+                     void *workspace, int64_t workspace_bytes, double T_out[16], double *fitness, double *rmse,
+                     int *iterations, void *stream)
+{
+    if (!ctx) return -1;
+    if (!src_pts || !tgt_pts || n_src < 1 || n_tgt < 1 || !workspace || !T_out) { ctx->err = "icp: bad arguments"; return -1; }
+    if (workspace_bytes < pca_icp_workspace_bytes(n_tgt)) { ctx->err = "icp: workspace too small"; return -1; }
+    if (max_iter < 1) max_iter = 30;
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    IcpArgs a;
+    a.src = src_pts; a.tgt = tgt_pts; a.n_src = n_src; a.n_tgt = n_tgt;
+    char *w = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int64_t cells = (int64_t)ICP_NX * ICP_NY * ICP_NZ;
+    a.head = reinterpret_cast<int32_t *>(w); w += icp_align(cells * 4);
+    a.next = reinterpret_cast<int32_t *>(w); w += icp_align((int64_t)n_tgt * 4);
+    a.normal = reinterpret_cast<float *>(w); w += icp_align((int64_t)n_tgt * 16);
+    a.partial = reinterpret_cast<double *>(w); w += icp_align((int64_t)1024 * ICP_NACC * 8);
+    a.state = reinterpret_cast<double *>(w);
+    a.max_dist2 = max_corr_dist * max_corr_dist;
+    a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse;
+    a.grid = icp_grid(n_src);
+    double st[32] = {0};
+    static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int i = 0; i < 16; ++i) st[i] = init ? init[i] : eye[i];
+    PCA_CHECK(ctx, hipMemsetAsync(a.head, 0xff, (size_t)cells * 4, s));
+    PCA_CHECK(ctx, hipMemcpyAsync(a.state, st, sizeof st, hipMemcpyHostToDevice, s));
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_insert, dim3((n_tgt + ICP_THREADS - 1) / ICP_THREADS), dim3(ICP_THREADS), s, a);
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_normals, dim3((n_tgt + ICP_THREADS - 1) / ICP_THREADS), dim3(ICP_THREADS), s, a);
+    // one more evaluation than updates: Open3D reports fitness / rmse of the final transform
+    for (int it = 0; it <= max_iter; ++it) {
+        PCA_LAUNCH(ctx, PCA_K_ICP, icp_accumulate, dim3(a.grid), dim3(ICP_THREADS), s, a);
+        if (it == max_iter) a.rel_fitness = a.rel_rmse = 1e300;              // last pass only evaluates
+        PCA_LAUNCH(ctx, PCA_K_ICP, icp_solve, dim3(1), dim3(64), s, a);
+    }
+    PCA_CHECK(ctx, hipMemcpyAsync(st, a.state, sizeof st, hipMemcpyDeviceToHost, s));
+    PCA_CHECK(ctx, hipStreamSynchronize(s));
+    for (int i = 0; i < 12; ++i) T_out[i] = st[i];
+    T_out[12] = T_out[13] = T_out[14] = 0.0; T_out[15] = 1.0;
+    if (fitness) *fitness = st[16];
+    if (rmse) *rmse = st[17];
+    if (iterations) *iterations = (int)st[21];
+    PCA_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

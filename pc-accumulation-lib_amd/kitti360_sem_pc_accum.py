@@ -23,30 +23,50 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         self.H_velo_cam = calib_params['h_velo_cam']
         self.P_cam_frame = calib_params['p_cam_frame']
         self.P_velo_frame = calib_params['p_velo_frame']
+        self._gpu_icp = None
+        self._prev_sweep = None
         self.pose_provider = self._default_pose_provider()
 
     # ---- pose input ----------------------------------------------------------------------------
     def _default_pose_provider(self):
-        """Pose source without touching the driver: PCA_KITTI_T_FILE=<.npy of (F,4,4) T_new_prev, one per frame>
-        or PCA_POSE_PROVIDER=<module>:<callable(pc) -> 4x4>; otherwise the reference's Open3D ICP call."""
+        """Pose source without touching the driver: PCA_KITTI_T_FILE=<.npy of (F,4,4) T_new_prev, one per frame>,
+        PCA_POSE_PROVIDER=<module>:<callable(pc) -> 4x4>, or PCA_POSE_PROVIDER=gpu_icp / open3d; by default the
+        reference's Open3D ICP call when open3d imports, else the device ICP (pca_amd/icp.py; parity with Open3D
+        unpinned)."""
         import os
         path = os.environ.get('PCA_KITTI_T_FILE')
         if path:
             Ts = iter(np.load(path))
             return lambda pc: next(Ts)
         spec = os.environ.get('PCA_POSE_PROVIDER')
+        if spec == 'gpu_icp':
+            return self._gpu_icp_pose
+        if spec == 'open3d':
+            return self._icp_pose
         if spec:
             import importlib
             mod, _, fn = spec.partition(':')
             return getattr(importlib.import_module(mod), fn)
+        try:
+            import open3d  # noqa: F401
+        except ImportError:
+            return self._gpu_icp_pose
         return self._icp_pose
 
+    def _gpu_icp_pose(self, pc):
+        """kitti360_sem_pc_accum.py:115-127 on the device: previous sweep -> new sweep, point-to-plane."""
+        from pca_amd.icp import GpuIcp
+        if self._gpu_icp is None:
+            self._gpu_icp = GpuIcp()
+        new = GpuIcp.to_device(pc)
+        if self._prev_sweep is None:
+            self._prev_sweep = new
+        reg = self._gpu_icp.register(self._prev_sweep, new, self.icp_threshold, self.icp_trans_init)
+        self._prev_sweep = new
+        return reg.transformation
+
     def _icp_pose(self, pc):
-        try:
-            import open3d as o3d
-        except ImportError as e:
-            raise RuntimeError('no pose source: open3d is not installed; set '
-                               '`accumulator.pose_provider = fn(pc) -> 4x4 T_new_prev` (e.g. from GT poses)') from e
+        import open3d as o3d
         pcd_new = self.pc2pcd(pc)
         if self.pcd_prev is None:
             self.pcd_prev = pcd_new

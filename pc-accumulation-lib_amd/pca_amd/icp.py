@@ -1,0 +1,68 @@
+"""Point-to-plane ICP on the device: the pose source of the KITTI-360 flow without Open3D.
+
+The reference calls (kitti360_sem_pc_accum.py:115-127, sem_pc_accum.py:310-315)
+
+    pcd.estimate_normals()                                   # 30 nearest neighbours
+    registration_icp(pcd_prev, pcd_new, threshold, init, TransformationEstimationPointToPlane())
+
+and uses ``.transformation`` as T_new_prev.  `GpuIcp.register` runs the same algorithm (defaults of Open3D:
+at most 30 iterations, relative fitness / rmse 1e-6) in HIP kernels (csrc/pca_icp.hip).  Open3D is a third-party,
+unpinned dependency of the reference, so there is no golden vector: parity is UNPINNED and the tests check known
+motions and a k-d-tree CPU model instead.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class IcpResult:
+    """Mirrors the fields the reference reads from Open3D's RegistrationResult."""
+
+    def __init__(self, T, fitness, rmse, iterations):
+        self.transformation = T
+        self.fitness = fitness
+        self.inlier_rmse = rmse
+        self.iterations = iterations
+
+
+class GpuIcp:
+    def __init__(self, max_iteration=30, relative_fitness=1e-6, relative_rmse=1e-6):
+        self.max_iteration = int(max_iteration)
+        self.relative_fitness = float(relative_fitness)
+        self.relative_rmse = float(relative_rmse)
+        self._ws = None
+
+    @staticmethod
+    def to_device(pc):
+        """(N,>=3) host array or cuda tensor -> contiguous cuda float32 [N,4] (x, y, z, anything)."""
+        import torch
+        ctx = _lib.Context.get()
+        dev = torch.device('cuda', ctx.device_index)
+        if isinstance(pc, torch.Tensor):
+            t = pc.to(device=dev, dtype=torch.float32)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(pc, dtype=np.float32)).to(dev)
+        if t.shape[1] != 4:
+            t4 = torch.zeros((t.shape[0], 4), dtype=torch.float32, device=dev)
+            t4[:, :3] = t[:, :3]
+            t = t4
+        return t.contiguous()
+
+    def register(self, source, target, threshold, init=None):
+        """T (4,4) with target ~= T source.  source / target: cuda float32 [N,4] (see to_device)."""
+        import torch
+        ctx = _lib.Context.get()
+        lib = ctx.lib
+        need = lib.pca_icp_workspace_bytes(int(target.shape[0]))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need) + 256, dtype=torch.uint8, device=target.device)
+        T = (C.c_double * 16)()
+        fit, rmse, it = C.c_double(0), C.c_double(0), C.c_int(0)
+        init_c = None if init is None else _lib.f64_array(np.asarray(init, dtype=np.float64), 16)
+        ctx.check(lib.pca_icp_register(ctx.h, source.data_ptr(), int(source.shape[0]), target.data_ptr(),
+                                       int(target.shape[0]), float(threshold), init_c, self.max_iteration,
+                                       self.relative_fitness, self.relative_rmse, self._ws.data_ptr(),
+                                       self._ws.numel(), T, C.byref(fit), C.byref(rmse), C.byref(it), ctx.stream()))
+        return IcpResult(np.array(T[:]).reshape(4, 4), fit.value, rmse.value, it.value)

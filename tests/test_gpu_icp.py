@@ -1,0 +1,160 @@
+"""Device point-to-plane ICP (replaces the reference's Open3D calls).  Parity with Open3D is
+unpinned (third-party, unpinned version, absent here): the tests check (1) known ego motions on a ray-cast street
+scene, (2) agreement with a k-d-tree numpy model of the same algorithm, (3) the accumulator's pose hook."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SENSOR_H = 1.73
+BOXES = []
+for j in range(-3, 8):
+    BOXES += [(12.0 * j, 9.0, 4.0, 2.5, 6.0), (12.0 * j + 6.0, -9.0, 4.0, 2.5, 6.0)]           # facades
+    BOXES += [(12.0 * j + 3.0, 4.2, 2.1, 0.9, 1.5), (12.0 * j + 9.0, -4.2, 2.1, 0.9, 1.5)]       # parked cars
+BOXES += [(20.0, 0.5, 0.3, 0.3, 3.0), (33.0, -1.5, 0.25, 0.25, 3.5), (8.0, -6.5, 0.2, 0.2, 4.0)]  # poles
+
+
+def sweep(x, y, yaw, seed, n_beams=32, n_az=900, max_range=45.0):
+    """Ray-casts a 32-beam lidar at world pose (x, y, yaw) over a ground plane and axis-aligned boxes fixed in the
+    WORLD; returns points in the SENSOR frame (N,4)."""
+    rng = np.random.default_rng(seed)
+    az = np.repeat(np.linspace(-np.pi, np.pi, n_az, endpoint=False)[None], n_beams, 0).ravel()
+    el = np.repeat(np.deg2rad(np.linspace(3.0, -24.0, n_beams))[:, None], n_az, 1).ravel()
+    az = az + rng.normal(0, 2e-4, az.shape)
+    d_s = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], 1)
+    c, s = np.cos(yaw), np.sin(yaw)
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.]])
+    d_w = d_s @ R.T
+    o_w = np.array([x, y, 0.0])
+    with np.errstate(divide='ignore', invalid='ignore'):
+        t = np.where(d_w[:, 2] < 0, -SENSOR_H / d_w[:, 2], np.inf)
+        for cx, cy, hx, hy, h in BOXES:
+            lo = (np.array([cx - hx, cy - hy, -SENSOR_H]) - o_w) / d_w
+            hi = (np.array([cx + hx, cy + hy, -SENSOR_H + h]) - o_w) / d_w
+            tn = np.nanmax(np.minimum(lo, hi), 1)
+            tf = np.nanmin(np.maximum(lo, hi), 1)
+            hit = (tn <= tf) & (tn > 0) & (tn < t)
+            t = np.where(hit, tn, t)
+    ok = np.isfinite(t) & (t < max_range)
+    t = t[ok] + rng.normal(0, 0.01, ok.sum())
+    pts = d_s[ok] * t[:, None]
+    return np.concatenate([pts, np.zeros((len(pts), 1))], 1).astype(np.float32)
+
+
+def pose_T(x, y, yaw):
+    c, s = np.cos(yaw), np.sin(yaw)
+    T = np.eye(4)
+    T[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]
+    T[:2, 3] = [x, y]
+    return T
+
+
+def rot_err_deg(R):
+    return np.degrees(np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1)))
+
+
+def icp_model(src, tgt, max_iter=30, rel=1e-6):
+    """The algorithm of csrc/pca_icp.hip with exact k-d-tree neighbours (scipy)."""
+    from scipy.spatial import cKDTree
+    src = src[:, :3].astype(np.float64)
+    tgt = tgt[:, :3].astype(np.float64)
+    tree = cKDTree(tgt)
+    _, nb = tree.query(tgt, k=30)
+    P = tgt[nb] - tgt[:, None, :]
+    m = P.mean(1, keepdims=True)
+    cov = np.einsum('nki,nkj->nij', P - m, P - m) / 30
+    _, vec = np.linalg.eigh(cov)
+    normals = vec[:, :, 0]
+    T = np.eye(4)
+    prev = None
+    for it in range(max_iter + 1):
+        q = src @ T[:3, :3].T + T[:3, 3]
+        d, j = tree.query(q)
+        fit, rmse = 1.0, np.sqrt(np.mean(d**2))
+        if prev is not None and abs(prev[0] - fit) < rel and abs(prev[1] - rmse) < rel:
+            break
+        prev = (fit, rmse)
+        if it == max_iter:
+            break
+        n = normals[j]
+        r = np.einsum('ij,ij->i', q - tgt[j], n)
+        J = np.concatenate([np.cross(q, n), n], 1)
+        x = np.linalg.solve(J.T @ J, -J.T @ r)
+        ca, sa, cb, sb, cg, sg = np.cos(x[0]), np.sin(x[0]), np.cos(x[1]), np.sin(x[1]), np.cos(x[2]), np.sin(x[2])
+        U = np.eye(4)
+        U[:3, :3] = [[cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa],
+                     [sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa], [-sb, cb * sa, cb * ca]]
+        U[:3, 3] = x[3:]
+        T = U @ T
+    return T, rmse, it
+
+
+@pytest.mark.parametrize('dx,dy,dyaw', [(1.0, 0.0, 0.0), (0.8, 0.05, 0.01), (1.5, -0.1, -0.02), (0.0, 0.0, 0.0)])
+def test_icp_recovers_known_ego_motion(dx, dy, dyaw):
+    from pca_amd.icp import GpuIcp
+    prev = sweep(0.0, 0.0, 0.0, 1)
+    new = sweep(dx, dy, dyaw, 2)
+    icp = GpuIcp()
+    res = icp.register(GpuIcp.to_device(prev), GpuIcp.to_device(new), 1e3, np.eye(4))
+    T_true = np.linalg.inv(pose_T(dx, dy, dyaw))          # previous-sweep coordinates -> new-sweep coordinates
+    assert np.linalg.norm(res.transformation[:3, 3] - T_true[:3, 3]) < 0.03, (res.transformation, T_true)
+    assert rot_err_deg(res.transformation[:3, :3] @ T_true[:3, :3].T) < 0.1
+    assert res.fitness > 0.95 and res.inlier_rmse < 0.5 and 1 <= res.iterations <= 30
+    assert np.array_equal(res.transformation[3], [0, 0, 0, 1])
+    again = icp.register(GpuIcp.to_device(prev), GpuIcp.to_device(new), 1e3, np.eye(4))
+    np.testing.assert_allclose(again.transformation, res.transformation, rtol=0, atol=1e-9)   # sums: fixed order
+
+
+@pytest.mark.parametrize('n_beams,n_az,max_range,tol', [(64, 700, 18.0, 1e-6), (96, 500, 14.0, 1e-6), (32, 900, 30.0, 1e-2)])
+def test_icp_matches_kdtree_model(n_beams, n_az, max_range, tol):
+    """Same algorithm with exact k-d-tree neighbours (scipy).  Where every 30-neighbourhood and every correspondence
+    lies inside the device search caps (3 m / 4 m) the two agree to rounding; on the sparse far rings of the third
+    scene the caps change a few (ill-conditioned, collinear) normals and the poses differ by millimetres."""
+    from pca_amd.icp import GpuIcp
+    prev = sweep(0.0, 0.0, 0.0, 5, n_beams=n_beams, n_az=n_az, max_range=max_range)
+    new = sweep(0.9, 0.03, 0.008, 6, n_beams=n_beams, n_az=n_az, max_range=max_range)
+    res = GpuIcp().register(GpuIcp.to_device(prev), GpuIcp.to_device(new), 1e3, np.eye(4))
+    T_ref, rmse_ref, it_ref = icp_model(prev, new)
+    assert np.linalg.norm(res.transformation[:3, 3] - T_ref[:3, 3]) < tol
+    assert rot_err_deg(res.transformation[:3, :3] @ T_ref[:3, :3].T) < 60 * tol
+    assert abs(res.inlier_rmse - rmse_ref) < tol
+    if tol < 1e-3:
+        assert res.iterations == it_ref
+
+
+def test_icp_threshold_and_init_are_honoured():
+    from pca_amd.icp import GpuIcp
+    prev = sweep(0.0, 0.0, 0.0, 7)
+    new = sweep(1.0, 0.0, 0.0, 8)
+    icp = GpuIcp()
+    tight = icp.register(GpuIcp.to_device(prev), GpuIcp.to_device(new), 0.05, np.eye(4))
+    loose = icp.register(GpuIcp.to_device(prev), GpuIcp.to_device(new), 1e3, np.eye(4))
+    assert tight.fitness < loose.fitness                  # 5 cm gate at 1 m offset: few correspondences
+    good = np.linalg.inv(pose_T(1.0, 0.0, 0.0))
+    warm = icp.register(GpuIcp.to_device(prev), GpuIcp.to_device(new), 1e3, good)
+    assert warm.iterations <= loose.iterations
+    assert np.linalg.norm(warm.transformation[:3, 3] - good[:3, 3]) < 0.03
+
+
+def test_kitti_accumulator_uses_device_icp_when_asked(monkeypatch):
+    """PCA_POSE_PROVIDER=gpu_icp: the unchanged integrate() path gets its T_new_prev from the device ICP."""
+    import sem_pc_accum
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    monkeypatch.setenv('PCA_POSE_PROVIDER', 'gpu_icp')
+    monkeypatch.setattr(sem_pc_accum, 'SemSegONNX', lambda path: None)
+    P = np.array([[552.554261, 0, 682.049453, 0], [0, 552.554261, 238.769549, 0], [0, 0, 1, 0.]]) @ np.linalg.inv(
+        np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418],
+                  [-0.999004371, 0.007784614041, 0.04392796942, 0.2993489574],
+                  [-0.01162548558, -0.9960641394, -0.08786966659, -0.1770225824], [0, 0, 0, 1]]))
+    bev = dict(type='sem', view_size=40, pixel_size=32, max_trans_radius=0., zoom_thresh=0., do_warp=False,
+               int_scaler=20., int_sep_scaler=20., int_mid_threshold=0.5, height_filter=None)
+    acc = Kitti360SemanticPointCloudAccumulator(200., {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': P}, 1e3,
+                                                'none', [255], {'road': 0, 'car': 13}, True, bev)
+    for k in range(5):
+        pc = sweep(1.0 * k, 0.0, 0.004 * k, 20 + k)
+        acc.integrate([(None, pc, np.zeros((len(pc), 1), dtype=np.int64))])
+    poses = np.array(acc.poses)
+    # the newest pose is the origin; the oldest lies ~4 m behind along -x of the current frame
+    assert np.allclose(poses[-1], 0.0)
+    assert abs(np.linalg.norm(poses[0]) - 4.0) < 0.1 and poses[0][0] < -3.8
+    assert np.all(np.abs(np.diff(np.linalg.norm(poses, axis=1))) > 0.9)
