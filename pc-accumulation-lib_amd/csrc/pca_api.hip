@@ -89,6 +89,10 @@ int pca_ctx_create(int device, pca_ctx **out)
     int n_cu = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) ctx->n_cu = n_cu;
     *ctx->heavy_hint = 1;            // first call: assume heavy tiles exist
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->heavy_hint_dev), ctx->heavy_hint, 0) != hipSuccess) {
+        delete ctx;
+        return -1;
+    }
     *out = ctx;
     return 0;
 }

@@ -893,9 +893,7 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
     // only a few are launched: any number of them drains the queue, and 256 idle 110-KiB workgroups cost ~5 us
     int heavy_grid = a.T < ctx->n_cu ? a.T : ctx->n_cu;
     if (*ctx->heavy_hint == 0 && heavy_grid > 16) heavy_grid = 16;
-    void *hint_dev = nullptr;
-    PCA_CHECK(ctx, hipHostGetDevicePointer(&hint_dev, ctx->heavy_hint, 0));
-    a.heavy_hint = reinterpret_cast<uint32_t *>(hint_dev);
+    a.heavy_hint = ctx->heavy_hint_dev;
     if (ctx->profiling == 2) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
     PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_hist, dim3(a.G), dim3(AB_THREADS), lds, s, a);
     PCA_LAUNCH(ctx, PCA_K_BEV_SCAN, bev_tile_scan, dim3(a.scan_tiles), dim3(SCAN_THREADS), s, a);

@@ -28,6 +28,7 @@ struct pca_ctx {
     int frames_cap = 0;
     uint32_t *status_host = nullptr;  // pinned
     uint32_t *heavy_hint = nullptr;   // pinned, device-visible: heavy-tile count of the latest rasteriser call
+    uint32_t *heavy_hint_dev = nullptr;
     unsigned long long *dbg = nullptr; // diagnostic stamps of the last K1 launch (PCA_K1_STAMPS)
     int dbg_blocks = 0;
     // optional per-kernel event timing

@@ -64,20 +64,32 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_grid_insert(const IcpArgs a)
     a.next[p] = atomicExch(&a.head[icp_cell_index(cx, cy, cz)], p);
 }
 
-// visits every target point of the shell of Chebyshev radius r around cell (cx,cy,cz)
-template <typename F>
-__device__ __forceinline__ void icp_visit_shell(const IcpArgs &a, int cx, int cy, int cz, int r, F &&f)
+// visits every target point of the shell of Chebyshev radius r around cell (cx,cy,cz), skipping the cells whose box
+// lies farther from the query (qx,qy,qz) than bound() -- the caller's current search radius squared (after the own
+// cell has produced a candidate a few centimetres away, almost every neighbouring cell is culled)
+template <typename B, typename F>
+__device__ __forceinline__ void icp_visit_shell(const IcpArgs &a, int cx, int cy, int cz, int r, double qx, double qy,
+                                                double qz, B &&bound, F &&f)
 {
     for (int dz = -r; dz <= r; ++dz) {
         const int z = cz + dz;
         if (z < 0 || z >= ICP_NZ) continue;
+        const double z0 = ICP_OZ + z * ICP_CELL;
+        const double ez = qz < z0 ? z0 - qz : (qz > z0 + ICP_CELL ? qz - (z0 + ICP_CELL) : 0.0);
         for (int dy = -r; dy <= r; ++dy) {
             const int y = cy + dy;
             if (y < 0 || y >= ICP_NY) continue;
+            const double y0 = ICP_OY + y * ICP_CELL;
+            const double ey = qy < y0 ? y0 - qy : (qy > y0 + ICP_CELL ? qy - (y0 + ICP_CELL) : 0.0);
+            const double eyz = ey * ey + ez * ez;
+            if (eyz >= bound()) continue;
             const bool face = (dz == -r || dz == r || dy == -r || dy == r);
             for (int dx = -r; dx <= r; dx += (face || r == 0) ? 1 : 2 * r) {     // interior rows: only the two end cells
                 const int x = cx + dx;
                 if (x < 0 || x >= ICP_NX) continue;
+                const double x0 = ICP_OX + x * ICP_CELL;
+                const double ex = qx < x0 ? x0 - qx : (qx > x0 + ICP_CELL ? qx - (x0 + ICP_CELL) : 0.0);
+                if (ex * ex + eyz >= bound()) continue;
                 for (int q = a.head[icp_cell_index(x, y, z)]; q >= 0; q = a.next[q]) f(q);
             }
         }
@@ -136,7 +148,9 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
         const int t = threadIdx.x;
         int found = 0;
         for (int r = 0; r <= ICP_NORMAL_RINGS; ++r) {
-            icp_visit_shell(a, cx, cy, cz, r, [&](int q) {
+            icp_visit_shell(a, cx, cy, cz, r, v.x, v.y, v.z,
+                            [&]() { return found == ICP_K ? (double)s_d[ICP_K - 1][t] * (1.0 + 1e-6) + 1e-12 : 1e300; },
+                            [&](int q) {
                 const float4 w = reinterpret_cast<const float4 *>(a.tgt)[q];
                 const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z;
                 const float d2 = dx * dx + dy * dy + dz * dz;
@@ -155,7 +169,8 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
             double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
             int cnt = 0;
             for (int r = 0; r <= rmax && r <= ICP_NORMAL_RINGS; ++r)
-                icp_visit_shell(a, cx, cy, cz, r, [&](int q) {
+                icp_visit_shell(a, cx, cy, cz, r, v.x, v.y, v.z, [&]() { return (double)lim * (1.0 + 1e-6) + 1e-12; },
+                                [&](int q) {
                     const float4 w = reinterpret_cast<const float4 *>(a.tgt)[q];
                     const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z;
                     if (dx * dx + dy * dy + dz * dz > lim) return;
@@ -197,7 +212,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_accumulate(const IcpArgs a)
         double best = a.max_dist2;
         int bi = -1;
         for (int r = 0; r <= ICP_MATCH_RINGS; ++r) {
-            icp_visit_shell(a, cx, cy, cz, r, [&](int q) {
+            icp_visit_shell(a, cx, cy, cz, r, qx, qy, qz, [&]() { return best * (1.0 + 1e-12) + 1e-300; }, [&](int q) {
                 const float4 w = reinterpret_cast<const float4 *>(a.tgt)[q];
                 const double dx = w.x - qx, dy = w.y - qy, dz = w.z - qz;
                 const double d2 = dx * dx + dy * dy + dz * dz;

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'pc-accumulation-lib_amd')
+import os; R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'pc-accumulation-lib_amd'))
 import numpy as np, torch, bench
 from pca_amd.icp import GpuIcp
 from pca_amd import _lib
