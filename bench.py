@@ -8,7 +8,7 @@ frames, ~5 M stored points), one 256x256 x 21-plane BEV per integrated frame.
 One STEP = integrate one frame  (K2 re-transform of every stored point + K1 fused project / sample /
 filter / append + horizon eviction)  +  generate one BEV sample (bin, scan, scatter, per-cell reduce).
 Inputs (point clouds, images, semseg maps) are resident in HBM before the timed region; BEV tensors
-stay in HBM (multi-GPU: gathered to rank 0 over RCCL inside the timed region).
+stay in HBM (multi-GPU: gathered to rank 0 over RCCL inside the timed region, chunk by chunk, overlapped).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -33,6 +33,7 @@ HORIZON_M, BEV_HORIZON_M, VIEW_M, PX = 200.0, 80, 80, 256
 FILTERS = [10, 11, 12, 16, 18, 255]
 SEM_IDXS = {'road': 0, 'car': 13, 'truck': 14, 'bus': 15, 'motorcycle': 17}
 POOL = 8                                  # distinct synthetic frames cycled through
+GATHER_CHUNK = 16                         # multi-GPU: BEV samples per asynchronous gather to rank 0
 HBM_PEAK_GBS = 8000.0                     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 CAM_TO_VELO = np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418],
@@ -316,11 +317,14 @@ def main():
         step()
     acc.store.check_status()
     bev_buf = torch.empty((args.steps, 21, PX, PX), dtype=torch.float16, device='cuda')
-    gathered = None
+    # finished BEV tensors go to rank 0 in chunks of GATHER_CHUNK samples: the gather of one chunk (RCCL, its own
+    # stream) runs while the next chunk is being computed; only the last chunk's transfer is exposed
     coll_dev = 'cuda' if backend == 'nccl' else 'cpu'
-    if world > 1:
-        gathered = [torch.empty((args.steps, 21, PX, PX), dtype=torch.float16, device=coll_dev)
-                    for _ in range(world)] if rank == 0 else None
+    chunks = [(lo, min(lo + GATHER_CHUNK, args.steps)) for lo in range(0, args.steps, GATHER_CHUNK)]
+    gathered = None
+    if world > 1 and rank == 0:
+        gathered = [[torch.empty((hi - lo, 21, PX, PX), dtype=torch.float16, device=coll_dev) for _ in range(world)]
+                    for lo, hi in chunks]
 
     def barrier():
         if world > 1:
@@ -330,10 +334,17 @@ def main():
     # ---- timed region: exactly K steps ----
     barrier()
     t0 = time.perf_counter()
+    pending = []
+    ci = 0
     for k in range(args.steps):
         step(bev_buf, k)
-    if world > 1:                                     # finished BEV tensors -> rank 0 over RCCL / xGMI
-        dist.gather(bev_buf if backend == 'nccl' else bev_buf.cpu(), gathered, dst=0)
+        if world > 1 and k + 1 == chunks[ci][1]:
+            lo, hi = chunks[ci]
+            part = bev_buf[lo:hi] if backend == 'nccl' else bev_buf[lo:hi].cpu()
+            pending.append(dist.gather(part, gathered[ci] if rank == 0 else None, dst=0, async_op=True))
+            ci += 1
+    for h in pending:
+        h.wait()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -341,7 +352,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         if rank == 0:                                 # every rank's last BEV arrived and is a plausible probability map
-            for g in gathered:
+            for g in gathered[-1]:
                 assert float(g[-1, 0].float().min()) > 0.0 and float(g[-1, 0].float().max()) < 1.0
     acc.store.check_status()
     stored = int(acc.store.offsets()[-1] - acc.store.offsets()[0])
