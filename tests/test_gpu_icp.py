@@ -158,3 +158,25 @@ def test_kitti_accumulator_uses_device_icp_when_asked(monkeypatch):
     assert np.allclose(poses[-1], 0.0)
     assert abs(np.linalg.norm(poses[0]) - 4.0) < 0.1 and poses[0][0] < -3.8
     assert np.all(np.abs(np.diff(np.linalg.norm(poses, axis=1))) > 0.9)
+
+
+def test_icp_degenerate_inputs_leave_the_initial_pose():
+    """No correspondence inside the gate / sweeps outside the search grid / a handful of points: the initial transform
+    comes back unchanged with fitness 0 (Open3D returns the init pose when the correspondence set is empty)."""
+    from pca_amd.icp import GpuIcp
+    icp = GpuIcp()
+    a = sweep(0.0, 0.0, 0.0, 3)
+    far = a.copy()
+    far[:, 2] += 10.0
+    init = pose_T(0.3, -0.2, 0.05)
+    res = icp.register(GpuIcp.to_device(a), GpuIcp.to_device(far), 0.5, init)
+    assert res.fitness == 0.0 and np.array_equal(res.transformation, init)
+    outside = a.copy()
+    outside[:, 0] += 500.0                                  # beyond the +-128 m grid
+    res = icp.register(GpuIcp.to_device(outside), GpuIcp.to_device(outside), 1e3, np.eye(4))
+    assert res.fitness == 0.0 and np.array_equal(res.transformation, np.eye(4))
+    few = GpuIcp.to_device(a[:4])
+    res = icp.register(few, few, 1e3, np.eye(4))
+    assert np.array_equal(res.transformation, np.eye(4))
+    xyz_only = GpuIcp.to_device(a[:, :3])                   # (N,3) input is padded to the [N,4] layout
+    assert tuple(xyz_only.shape) == (len(a), 4)
