@@ -447,14 +447,14 @@ def main():
     # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate passes,
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); bench.py cannot run the profiler itself
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, 'profiles', 'r01_d_pmc_traffic.json')
+    pmc_path = os.path.join(ROOT, 'profiles', 'r01_e_pmc_traffic.json')
     if os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))['kernels']
         names = {'bev': ('bev_tile_hist', 'bev_tile_scan', 'bev_tile_scatter<false>', 'bev_tile_cells<false>',
                          'bev_tile_cells_heavy<false>')}
         if dominant in names and all(k in pmc for k in names[dominant]):
             traffic = sum(2.0 * pmc[k]['FETCH_SIZE_KB'] + pmc[k]['WRITE_SIZE_KB'] for k in names[dominant]) * 1024.0
-            traffic_src = 'profiles/r01_d_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, summed over the unit\'s kernels)'
+            traffic_src = 'profiles/r01_e_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, summed over the unit\'s kernels)'
     roofline = {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_bytes_per_launch': alg[dominant], 'avg_launch_us': units[dominant],
