@@ -87,27 +87,48 @@ def sample_frames(positions, accum_horizon, bev_horizon, min_spacing):
     return out
 
 
-def gather_to_rank0(local, group=None):
+class _PendingGather:
+    """Handle of an asynchronous gather_to_rank0: wait() returns what the blocking call returns."""
+
+    def __init__(self, work, bufs, sizes):
+        self._work, self._bufs, self._sizes = work, bufs, sizes
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+        if self._bufs is None:
+            return None
+        return [b[:k] for b, k in zip(self._bufs, self._sizes)]
+
+
+def gather_to_rank0(local, group=None, async_op=False, sizes=None):
     """local: tensor [n_local, ...] (same trailing shape and dtype on every rank, n_local may differ).
     Returns on rank 0 the list of per-rank tensors (rank order), elsewhere None.  One size exchange plus one
-    padded gather; with the nccl backend both run over RCCL / xGMI."""
+    padded gather; with the nccl backend both run over RCCL / xGMI.
+    async_op=True returns a handle at once (`.wait()` gives the result): the transfer of one batch of samples then
+    overlaps the computation of the next (keep `local` untouched until then).  `sizes` (per-rank counts, known to
+    every rank, e.g. a fixed batch size) skips the size exchange -- and with it the only synchronising step."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
-        return [local]
+        return _PendingGather(None, [local], [local.shape[0]]) if async_op else [local]
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    if sizes is None:
+        n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        szs = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(szs, n, group=group)
+        sizes = [int(s.item()) for s in szs]
+    assert len(sizes) == world and sizes[rank] == local.shape[0]
     n_max = max(max(sizes), 1)
     padded = local
     if local.shape[0] != n_max:
         padded = torch.zeros((n_max, ) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         padded[:local.shape[0]] = local
     bufs = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
-    dist.gather(padded.contiguous(), bufs, dst=0, group=group)
+    work = dist.gather(padded.contiguous(), bufs, dst=0, group=group, async_op=async_op)
+    if async_op:
+        return _PendingGather(work, bufs, sizes)
     if rank != 0:
         return None
     return [b[:k] for b, k in zip(bufs, sizes)]

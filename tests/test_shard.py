@@ -83,6 +83,16 @@ def _worker(rank, world, port, out):
     got2 = shard.gather_to_rank0(empty)
     if rank == 0:
         ok = ok and got2[0].shape[0] == 2 and got2[1].shape[0] == 0
+    # asynchronous batches with known sizes: two gathers in flight, results in order
+    b0 = torch.full((4, 21, 8, 8), float(10 + rank), dtype=torch.float16)
+    b1 = torch.full((4, 21, 8, 8), float(20 + rank), dtype=torch.float16)
+    h0 = shard.gather_to_rank0(b0, async_op=True, sizes=[4, 4])
+    h1 = shard.gather_to_rank0(b1, async_op=True, sizes=[4, 4])
+    r0, r1 = h0.wait(), h1.wait()
+    if rank == 0:
+        ok = ok and float(r0[1][0, 0, 0, 0]) == 11.0 and float(r1[1][3, 20, 7, 7]) == 21.0 and r1[0].shape[0] == 4
+    else:
+        ok = ok and r0 is None and r1 is None
     out[rank] = ok
     dist.destroy_process_group()
 
@@ -106,3 +116,4 @@ def test_gather_without_process_group_is_identity():
     import torch
     t = torch.zeros((2, 21, 4, 4), dtype=torch.float16)
     assert shard.gather_to_rank0(t)[0] is t
+    assert shard.gather_to_rank0(t, async_op=True).wait()[0] is t
