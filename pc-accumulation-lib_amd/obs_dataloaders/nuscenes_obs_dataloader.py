@@ -1,0 +1,122 @@
+"""NuScenes observation loader (reference: obs_dataloaders/nuscenes_obs_dataloader.py).
+
+Same class, constructor and observation dict as the reference, so that `run_nuscenes_bev_gen.py` imports and runs
+unchanged.  What runs where:
+
+  * lidar -> ego -> global -> 6 cameras, pinhole projection, "last camera wins" (reference :162-202): ONE device launch
+    (`datasets.nuscenes_utils.project_to_cameras`, kernel K0n) instead of 2 + 6 numpy transforms and 6 projections;
+  * walking the dataset, merging sweeps and labelling points with their GT boxes (`inst_centric_get_sweeps`, ~200
+    lines of nuscenes-devkit bookkeeping and disk I/O, SURVEY.md scope table: out of the hot path) is NOT restated
+    here.  It is obtained from, in this order: `NuScenesDataloader.sweep_provider` (any callable with the signature of
+    the reference's function that returns its dict after `load_data_to_tensor`), or the reference's own
+    `datasets/nuscenes_utils.py` loaded from the checkout named by PCA_REFERENCE_ROOT.
+
+nuscenes-devkit / pyquaternion are only imported when a real dataset is walked.
+"""
+import importlib.util
+import os
+
+import numpy as np
+
+from datasets.nuscenes_utils import NuScenesCamera, NuScenesLidar, project_to_cameras
+from obs_dataloaders.obs_dataloader import ObservationDataloader
+
+_REF = {}
+
+
+def _reference_utils():
+    """The reference's datasets/nuscenes_utils.py as a private module (dataset bookkeeping only)."""
+    if 'mod' not in _REF:
+        root = os.environ.get('PCA_REFERENCE_ROOT')
+        path = os.path.join(root, 'datasets', 'nuscenes_utils.py') if root else None
+        if not path or not os.path.isfile(path):
+            raise RuntimeError('NuScenesDataloader needs a sweep provider: set NuScenesDataloader.sweep_provider, or '
+                               'PCA_REFERENCE_ROOT=<checkout of the reference> (its inst_centric_get_sweeps is used)')
+        spec = importlib.util.spec_from_file_location('_pca_reference_nuscenes_utils', path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _REF['mod'] = mod
+    return _REF['mod']
+
+
+class NuScenesDataloader(ObservationDataloader):
+    sweep_provider = None       # callable(nusc, sample_token, **cfg) -> dict (points, instances_token, ...)
+
+    def __init__(self, nusc, scene_ids=None, batch_size=1, num_sweeps=5):
+        super().__init__(None, batch_size)
+        self.nusc = nusc
+        self.num_sweeps = num_sweeps
+        self.cam_channels = ['CAM_FRONT', 'CAM_FRONT_LEFT', 'CAM_FRONT_RIGHT', 'CAM_BACK', 'CAM_BACK_LEFT',
+                             'CAM_BACK_RIGHT']
+        if scene_ids is None:
+            scene_ids = range(self.nusc.scene)     # as the reference (:31-32): raises TypeError for a list of scenes
+        self.sample_tokens = []
+        for scene_idx in scene_ids:
+            token = self.nusc.scene[scene_idx]['first_sample_token']
+            while token != '':
+                self.sample_tokens.append(token)
+                token = self.nusc.get('sample', token)['next']
+        # columns of the sweep matrix
+        self.int_idx, self.sweep_idx, self.inst_idx, self.cls_idx = 3, 5, 6, 7
+        big = 1000
+        self.pc_range = [-big, -big, -big, big, big, big]
+
+    def __len__(self):
+        return len(self.sample_tokens)
+
+    # ---- pieces a test (or another dataset layout) can replace ------------------------------------------------
+    def _sweeps(self, sample_token, cfg):
+        if self.sweep_provider is not None:
+            return self.sweep_provider(self.nusc, sample_token, **cfg)
+        ref = _reference_utils()
+        out = ref.inst_centric_get_sweeps(self.nusc, sample_token, **cfg)
+        ref.load_data_to_tensor(out)
+        return out
+
+    def _lidar(self, sample):
+        return NuScenesLidar(self.nusc, self.nusc.get('sample_data', sample['data']['LIDAR_TOP']))
+
+    def _cameras(self, sample):
+        return [NuScenesCamera(self.nusc, self.nusc.get('sample_data', sample['data'][ch])) for ch in self.cam_channels]
+
+    # ---- one observation -------------------------------------------------------------------------------------
+    def read_obs(self, idx):
+        """dict with the reference's keys: images, pc (N,7) [x,y,z (ego), intensity, u, v, instance idx], pc_cam_idx
+        (N,), ego_at_lidar_ts (4,4), meta, inst_tokens, inst_cls, inst_center, ego_global_x, ego_global_y."""
+        sample_token = self.sample_tokens[idx]
+        sample = self.nusc.get('sample', sample_token)
+        obs = {'meta': {'sample_token': sample_token, 'scene_token': sample['scene_token'],
+                        'cam_channels': self.cam_channels}}
+        cfg = {
+            'n_sweeps': self.num_sweeps,
+            'center_radius': 2.0,
+            'in_box_tolerance': 5e-2,
+            'return_instances_last_box': True,
+            'point_cloud_range': self.pc_range,
+            'detection_classes': ('car', 'truck', 'construction_vehicle', 'bus', 'trailer', 'motorcycle', 'bicycle',
+                                  'pedestrian'),
+            'map_point_feat2idx': {'sweep_idx': self.sweep_idx, 'inst_idx': self.inst_idx, 'cls_idx': self.cls_idx},
+        }
+        out = self._sweeps(sample_token, cfg)
+        pc = np.asarray(out['points'])                      # lidar frame
+
+        lidar = self._lidar(sample)
+        cameras = self._cameras(sample)
+        obs['ego_at_lidar_ts'] = lidar.glob_from_ego
+        obs['images'] = [cam.img for cam in cameras]
+        pc_in_ego, pc_uv, pc_cam_idx = project_to_cameras(
+            pc[:, :3], lidar.ego_from_self, lidar.glob_from_ego, [cam.glob_from_self for cam in cameras],
+            [cam.cam_K for cam in cameras], [cam.img_wh for cam in cameras])
+        obs['pc_cam_idx'] = pc_cam_idx
+        obs['pc'] = np.concatenate([pc_in_ego, pc[:, self.int_idx:self.int_idx + 1], pc_uv,
+                                    pc[:, self.inst_idx:self.inst_idx + 1]], axis=1)
+
+        obs['inst_tokens'] = out['instances_token']
+        obs['inst_cls'] = [int(cls.item()) for cls in out['instances_name']]
+        obs['inst_center'] = out['instances_center']
+
+        sd = self.nusc.get('sample_data', sample['data']['LIDAR_TOP'])
+        x, y, _ = self.nusc.get('ego_pose', sd['ego_pose_token'])['translation']
+        obs['ego_global_x'] = x
+        obs['ego_global_y'] = y
+        return obs

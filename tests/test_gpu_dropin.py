@@ -442,3 +442,62 @@ def test_kitti_accumulator_voxel_dedup_option(golden):
     bevs = dd.generate_bev(n_steps // 2, 1, gen_future=True)     # the rasteriser runs on the thinned buffer
     assert bevs[0]['road_full'].shape == (32, 32)
     dd.store.check_status()
+
+
+def test_nuscenes_dataloader_projection_chain_on_device(golden):
+    """obs_dataloaders/nuscenes_obs_dataloader.py:162-202 through the drop-in loader: fake dataset tables and sweep
+    provider (dataset walking is out of scope), the reference's transform chain + 6-camera projection + last-camera-
+    wins from the golden vectors."""
+    from types import SimpleNamespace
+
+    from obs_dataloaders.nuscenes_obs_dataloader import NuScenesDataloader
+    g = golden('utils')
+    n = g['c6_pc'].shape[0]
+    rng = np.random.default_rng(4)
+    sweep = np.zeros((n, 8))
+    sweep[:, :3] = g['c6_pc']
+    sweep[:, 3] = rng.integers(0, 256, n)
+    sweep[:, 6] = rng.integers(-1, 3, n)
+
+    class FakeNusc:
+        scene = [{'first_sample_token': 's0'}]
+        tables = {('sample', 's0'): {'next': 's1', 'scene_token': 'sc', 'data': {'LIDAR_TOP': 'l0'}},
+                  ('sample', 's1'): {'next': '', 'scene_token': 'sc', 'data': {'LIDAR_TOP': 'l1'}},
+                  ('sample_data', 'l0'): {'ego_pose_token': 'e0'}, ('sample_data', 'l1'): {'ego_pose_token': 'e0'},
+                  ('ego_pose', 'e0'): {'translation': [411.5, 1180.25, 0.0]}}
+
+        def get(self, table, token):
+            return self.tables[(table, token)]
+
+    class Loader(NuScenesDataloader):
+        def _lidar(self, sample):
+            return SimpleNamespace(ego_from_self=g['c6_ego_from_lidar'], glob_from_ego=g['c6_glob_from_ego'])
+
+        def _cameras(self, sample):
+            return [SimpleNamespace(img=f'img{j}', glob_from_self=g['c6_glob_from_cam'][j], cam_K=g['pp_K'],
+                                    img_wh=g['pp_wh']) for j in range(6)]
+
+    seen = {}
+
+    def provider(nusc, token, **cfg):
+        seen.update(cfg, token=token)
+        return {'points': sweep, 'instances_token': ['a', 'b'], 'instances_name': [np.int64(0), np.int64(3)],
+                'instances_center': [np.zeros(3), np.ones(3)]}
+
+    loader = Loader(FakeNusc(), scene_ids=[0], batch_size=1, num_sweeps=5)
+    loader.sweep_provider = provider
+    assert len(loader) == 2 and loader.sample_tokens == ['s0', 's1']
+    obs = next(iter(loader))[0]
+    assert seen['token'] == 's0' and seen['n_sweeps'] == 5 and seen['map_point_feat2idx']['inst_idx'] == 6
+    assert np.array_equal(obs['pc'][:, :3], g['c6_pc_in_ego'])
+    assert np.array_equal(obs['pc'][:, 4:6], g['c6_uv'])
+    assert np.array_equal(obs['pc_cam_idx'], g['c6_cam_idx'])
+    assert np.array_equal(obs['pc'][:, 3], sweep[:, 3]) and np.array_equal(obs['pc'][:, 6], sweep[:, 6])
+    assert obs['pc'].shape == (n, 7) and obs['images'] == [f'img{j}' for j in range(6)]
+    assert obs['inst_cls'] == [0, 3] and obs['inst_tokens'] == ['a', 'b']
+    assert obs['ego_global_x'] == 411.5 and obs['ego_global_y'] == 1180.25
+    assert np.array_equal(obs['ego_at_lidar_ts'], g['c6_glob_from_ego'])
+    assert set(obs) == {'meta', 'ego_at_lidar_ts', 'images', 'pc_cam_idx', 'pc', 'inst_tokens', 'inst_cls', 'inst_center',
+                        'ego_global_x', 'ego_global_y'}
+    with pytest.raises(TypeError):
+        NuScenesDataloader(FakeNusc())                       # scene_ids=None: range(list), as in the reference

@@ -30,3 +30,35 @@ def test_unchanged_kitti_driver_runs_up_to_the_device(tmp_path):
         # no GPU here: the first integrate() must die loudly in the product, not fall back to anything
         assert 'no CPU fallback' in out, out[-2000:]
         assert PKG in out
+
+
+REF_NUSC_DRIVER = '/root/reference/run_nuscenes_bev_gen.py'
+
+
+@pytest.mark.skipif(not os.path.exists(REF_NUSC_DRIVER), reason='reference checkout not present')
+def test_unchanged_nuscenes_driver_resolves_its_imports(tmp_path):
+    """run_nuscenes_bev_gen.py:7-12 imports nuscenes_oracle_sem_pc_accum, nuscenes_sem_pc_accum and
+    obs_dataloaders.nuscenes_obs_dataloader: all three must come from the drop-in root.  nuscenes-devkit is not
+    installed here, so an empty stand-in package satisfies the driver's own `from nuscenes.nuscenes import NuScenes`;
+    `--help` stops the script after its imports."""
+    stub = tmp_path / 'stubs' / 'nuscenes'
+    stub.mkdir(parents=True)
+    (stub / '__init__.py').write_text('')
+    (stub / 'nuscenes.py').write_text('class NuScenes:\n    pass\n')
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([PKG, str(tmp_path / 'stubs')]), PYTHONDONTWRITEBYTECODE='1')
+    probe = ('import sys, runpy\n'
+             'sys.argv = [sys.argv[1], "--help"]\n'
+             'try:\n'
+             '    runpy.run_path(sys.argv[0], run_name="__main__")\n'
+             'except SystemExit:\n'
+             '    pass\n'
+             'import nuscenes_oracle_sem_pc_accum as a, nuscenes_sem_pc_accum as b\n'
+             'import obs_dataloaders.nuscenes_obs_dataloader as c\n'
+             'print("FROM", a.__file__, b.__file__, c.__file__)\n')
+    r = subprocess.run([sys.executable, '-c', probe, REF_NUSC_DRIVER], cwd=str(tmp_path), env=env, capture_output=True,
+                       text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and 'ModuleNotFoundError' not in out and 'ImportError' not in out, out[-2000:]
+    line = [ln for ln in out.splitlines() if ln.startswith('FROM')][0]
+    assert line.count(PKG) == 3, line
+    assert 'usage:' in out and 'nuscenes_path' in out
