@@ -105,7 +105,7 @@ def test_icp_recovers_known_ego_motion(dx, dy, dyaw):
     np.testing.assert_allclose(again.transformation, res.transformation, rtol=0, atol=1e-9)   # sums: fixed order
 
 
-@pytest.mark.parametrize('n_beams,n_az,max_range,tol', [(64, 700, 18.0, 1e-6), (96, 500, 14.0, 1e-6), (32, 900, 30.0, 1e-2)])
+@pytest.mark.parametrize('n_beams,n_az,max_range,tol', [(64, 700, 18.0, 1e-5), (96, 500, 14.0, 1e-5), (32, 900, 30.0, 1e-2)])
 def test_icp_matches_kdtree_model(n_beams, n_az, max_range, tol):
     """Same algorithm with exact k-d-tree neighbours (scipy).  Where every 30-neighbourhood and every correspondence
     lies inside the device search caps (3 m / 4 m) the two agree to rounding; on the sparse far rings of the third
