@@ -207,6 +207,32 @@ def ring_model_pass(steps, frame_fn=None):
             'note': '64 beams x 1875 azimuths over a ground plane with boxes; density ~1/r^2 (contention case)'}
 
 
+def extras_pass(acc):
+    """Timings of the opt-in / next-row pieces on the benchmark's own data (rank 0, after the headline measurement;
+    reported beside, never as, `value`): voxel de-duplication of the full window and the device ICP on two frames."""
+    import torch
+    from pca_amd.icp import GpuIcp
+    out = {}
+    st = acc.store
+    before = int(st.offsets()[-1] - st.offsets()[0])
+    st.voxel_dedup(0.1)                                   # warm-up (allocates the table)
+    torch.cuda.synchronize()
+    mid = int(st.offsets()[-1] - st.offsets()[0])
+    t0 = time.perf_counter()
+    st.voxel_dedup(0.1)
+    torch.cuda.synchronize()
+    out['voxel_dedup'] = {'voxel_m': 0.1, 'points_before': before, 'points_after': mid,
+                          'ms_second_pass_over_%d_pts' % mid: 1e3 * (time.perf_counter() - t0)}
+    a, b = GpuIcp.to_device(ring_frame(0, 3)[0]), GpuIcp.to_device(ring_frame(0, 4)[0])
+    icp = GpuIcp()
+    icp.register(a, b, 1e3, np.eye(4))
+    t0 = time.perf_counter()
+    r = icp.register(a, b, 1e3, np.eye(4))
+    out['device_icp'] = {'ms_per_registration': 1e3 * (time.perf_counter() - t0), 'points': N_PTS,
+                         'iterations': r.iterations, 'scene': 'two consecutive ring-model frames'}
+    return out
+
+
 def cpu_baseline(steps=20):
     """Oracle (scalar C port of the reference algorithm, 1 core) on a bounded sample of the same workload:
     fill the 200-frame window, then time `steps` full steps (re-transform + integrate + BEV)."""
@@ -357,6 +383,7 @@ def main():
     acc.store.check_status()
     stored = int(acc.store.offsets()[-1] - acc.store.offsets()[0])
     n_live = acc.store.n_frames
+    sizes = acc.store.sizes()
 
     # ---- second identical pass with per-kernel HIP events (on the launch stream, inside the library) ----
     ctx = _lib.Context.get()
@@ -411,9 +438,10 @@ def main():
     ctx.profile(False)
     k1b_kept = int(tmp.offsets()[-1])
     del tmp
-    ring = None
+    ring, extras = None, None
     if rank == 0 and not args.no_ring and args.scene == 'uniform':
         ring = ring_model_pass(min(args.steps, 50))
+        extras = extras_pass(acc)                          # mutates the store: last use of `acc`
     builtins.print = real_print
 
     if rank != 0:
@@ -427,7 +455,6 @@ def main():
     #   BEV (hist+scan+scatter+cells as one unit): 40 B per window point + 21 px^2 4 B.
     # In steady state the owed re-transform of a step is applied by the BEV's first pass (it reads every
     # coordinate anyway): the BEV unit then also does K2's work, so its algorithmic bytes include K2's.
-    sizes = acc.store.sizes()
     m_kept = float(np.mean(sizes))
     m_proj = m_kept * 19.0 / 14.0 / 0.99               # 14 of 19 uniform classes survive, 1 % 'ignore'
     k2_fused = 'retransform' not in kern
@@ -495,6 +522,7 @@ def main():
     }
     if ring is not None:
         out['ring_model'] = ring
+        out['extras'] = extras
     if not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))
