@@ -440,7 +440,11 @@ __device__ __forceinline__ void hist16_medians(TileStats &S, const uint32_t *row
 {
     const uint4 p = hist16_bins(row_p), f = hist16_bins(row_f);
     const uint4 u = make_uint4(p.x + f.x, p.y + f.y, p.z + f.z, p.w + f.w);
-    const uint32_t m_p = hist_med2_regs(p, n_p), m_f = hist_med2_regs(f, n_f), m_u = hist_med2_regs(u, n_p + n_f);
+    // two scans serve three histograms: the prefix of the union is the sum of the prefixes
+    const uint32_t s_p = p.x + p.y + p.z + p.w, s_f = f.x + f.y + f.z + f.w;
+    const uint32_t e_p = wave_incl_scan_add(s_p) - s_p, e_f = wave_incl_scan_add(s_f) - s_f;
+    const uint32_t m_p = hist_med2_scanned(p, e_p, s_p, n_p), m_f = hist_med2_scanned(f, e_f, s_f, n_f),
+                   m_u = hist_med2_scanned(u, e_p + e_f, s_p + s_f, n_p + n_f);
     if ((threadIdx.x & 63) == 0) { S.med2[0][cell][ch] = m_p; S.med2[1][cell][ch] = m_f; S.med2[2][cell][ch] = m_u; }
 }
 

@@ -37,14 +37,19 @@ __device__ __forceinline__ uint32_t hist_rank(const uint4 h, uint32_t excl, uint
     return __builtin_amdgcn_readlane(val, src);
 }
 
-// 2*median (lower + upper middle value) of a 256-bin histogram with n entries, 4 bins per lane, one whole wave
+// 2*median (lower + upper middle value) given the lane's 4 bins, their sum s and its exclusive prefix over the wave
+__device__ __forceinline__ uint32_t hist_med2_scanned(const uint4 h, uint32_t excl, uint32_t s, uint32_t n)
+{
+    if (n == 0) return 0;
+    const uint32_t lo = hist_rank(h, excl, s, (n - 1) >> 1);
+    return (n & 1u) ? 2u * lo : lo + hist_rank(h, excl, s, n >> 1);      // odd n: both middles are the same entry
+}
+// 2*median of a 256-bin histogram with n entries, 4 bins per lane, one whole wave
 __device__ __forceinline__ uint32_t hist_med2_regs(const uint4 h, uint32_t n)
 {
     if (n == 0) return 0;
     const uint32_t s = h.x + h.y + h.z + h.w;
-    const uint32_t inc = wave_incl_scan_add(s);
-    const uint32_t excl = inc - s;
-    return hist_rank(h, excl, s, (n - 1) >> 1) + hist_rank(h, excl, s, n >> 1);
+    return hist_med2_scanned(h, wave_incl_scan_add(s) - s, s, n);
 }
 __device__ __forceinline__ uint32_t hist_med2(const uint32_t *hist256, uint32_t n)
 {
