@@ -439,7 +439,7 @@ def main():
     k1b_kept = int(tmp.offsets()[-1])
     del tmp
     ring, extras = None, None
-    if rank == 0 and not args.no_ring and args.scene == 'uniform':
+    if rank == 0 and world == 1 and not args.no_ring and args.scene == 'uniform':
         ring = ring_model_pass(min(args.steps, 50))
         extras = extras_pass(acc)                          # mutates the store: last use of `acc`
     builtins.print = real_print
@@ -523,7 +523,7 @@ def main():
     if ring is not None:
         out['ring_model'] = ring
         out['extras'] = extras
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:           # reported at N = 1 only
         out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))
     if world > 1:
