@@ -8,7 +8,9 @@
 // Open3D is third-party and unpinned (README.md:14): PARITY IS UNPINNED.  The tests check known motions and a CPU model
 // of this same algorithm (exact k-d tree neighbours), not Open3D.
 //
-//   icp_grid_insert   uniform grid (0.5 m cells, 256 m x 256 m x 32 m around the sensor) as per-cell linked lists
+//   icp_grid_count / icp_cell_scan / icp_grid_fill   uniform grid (0.5 m cells, 256 m x 256 m x 32 m around the
+//                     sensor): counting sort of the target points by cell -- a cell's points are contiguous, so a
+//                     neighbour search streams them instead of chasing a linked list
 //   icp_normals       per target point: the K = 30 nearest neighbours (shell-by-shell grid search, exact within the
 //                     search cap), covariance, eigenvector of the smallest eigenvalue (cyclic Jacobi, f64)
 //   icp_accumulate    per source point: q = T p, nearest target point (exact within the cap), r = (q - t).n,
@@ -34,9 +36,13 @@ struct IcpArgs {
     const float *src;            // [n_src,4]
     const float *tgt;            // [n_tgt,4]
     int n_src, n_tgt;
-    int32_t *head;               // [NX*NY*NZ] first target point of the cell, -1 = empty
-    int32_t *next;               // [n_tgt]
-    float *normal;               // [n_tgt,4]  nx, ny, nz, valid
+    uint32_t *cnt;               // [cells] points per cell (counting pass), all zero again after the fill pass
+    uint32_t *start;             // [cells + 1] first sorted position of the cell; start[cells] = points inside the grid
+    float4 *spts;                // [n_tgt] target points sorted by cell: x, y, z, original index (bits)
+    float *normal;               // [n_tgt,4]  nx, ny, nz, valid -- in SORTED order
+    uint64_t *lb_state;          // decoupled look-back of the cell scan
+    uint32_t *ticket;
+    uint32_t epoch;
     double *partial;             // [grid][ICP_NACC]
     double *state;               // [0..15] T (row-major), [16] fitness, [17] rmse, [18] prev fitness, [19] prev rmse,
                                  // [20] converged flag, [21] iterations done
@@ -54,19 +60,70 @@ __device__ __forceinline__ bool icp_cell_of(double x, double y, double z, int &c
 }
 __device__ __forceinline__ int icp_cell_index(int cx, int cy, int cz) { return (cz * ICP_NY + cy) * ICP_NX + cx; }
 
-__global__ __launch_bounds__(ICP_THREADS) void icp_grid_insert(const IcpArgs a)
+#define ICP_CELLS ((int64_t)ICP_NX * ICP_NY * ICP_NZ)
+#define ICP_SCAN_THREADS 1024
+#define ICP_SCAN_TILE (4 * ICP_SCAN_THREADS)
+
+__global__ __launch_bounds__(ICP_THREADS) void icp_grid_count(const IcpArgs a)
 {
     const int p = blockIdx.x * ICP_THREADS + threadIdx.x;
     if (p >= a.n_tgt) return;
     const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
     int cx, cy, cz;
-    if (!icp_cell_of(v.x, v.y, v.z, cx, cy, cz)) { a.next[p] = -2; return; }     // outside the grid: never matched
-    a.next[p] = atomicExch(&a.head[icp_cell_index(cx, cy, cz)], p);
+    if (icp_cell_of(v.x, v.y, v.z, cx, cy, cz)) atomicAdd(&a.cnt[icp_cell_index(cx, cy, cz)], 1u);   // else: never matched
 }
 
-// visits every target point of the shell of Chebyshev radius r around cell (cx,cy,cz), skipping the cells whose box
-// lies farther from the query (qx,qy,qz) than bound() -- the caller's current search radius squared (after the own
-// cell has produced a candidate a few centimetres away, almost every neighbouring cell is culled)
+// exclusive scan of the per-cell counts (single pass, decoupled look-back; tiles handed out by ticket)
+__global__ __launch_bounds__(ICP_SCAN_THREADS) void icp_cell_scan(const IcpArgs a)
+{
+    __shared__ int s_tile;
+    __shared__ uint32_t s_w[ICP_SCAN_THREADS / 64];
+    __shared__ uint64_t s_excl;
+    const int n_tiles = (int)(ICP_CELLS / ICP_SCAN_TILE);
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(a.ticket, 1u);
+        if ((int)t == n_tiles - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_tile = (int)t;
+    }
+    __syncthreads();
+    const int tile = s_tile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)tile * ICP_SCAN_TILE + threadIdx.x * 4;
+    const uint4 c = *reinterpret_cast<const uint4 *>(a.cnt + base);
+    const uint32_t tsum = c.x + c.y + c.z + c.w;
+    const uint32_t inc = wave_incl_scan_add(tsum);
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t v = lane < ICP_SCAN_THREADS / 64 ? s_w[lane] : 0u;
+        const uint32_t winc = wave_incl_scan_add(v);
+        if (lane < ICP_SCAN_THREADS / 64) s_w[lane] = winc - v;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)winc, 63);
+        const uint64_t e = lb_exclusive_prefix(a.lb_state, tile, (uint64_t)total, a.epoch);
+        if (lane == 0) s_excl = (e << 32) | total;
+    }
+    __syncthreads();
+    const uint32_t excl = (uint32_t)(s_excl >> 32), total = (uint32_t)s_excl;
+    const uint32_t r0 = excl + s_w[wave] + (inc - tsum);
+    *reinterpret_cast<uint4 *>(a.start + base) = make_uint4(r0, r0 + c.x, r0 + c.x + c.y, r0 + c.x + c.y + c.z);
+    if (tile == n_tiles - 1 && threadIdx.x == ICP_SCAN_THREADS - 1) a.start[ICP_CELLS] = excl + total;
+}
+
+__global__ __launch_bounds__(ICP_THREADS) void icp_grid_fill(const IcpArgs a)
+{
+    const int p = blockIdx.x * ICP_THREADS + threadIdx.x;
+    if (p >= a.n_tgt) return;
+    const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
+    int cx, cy, cz;
+    if (!icp_cell_of(v.x, v.y, v.z, cx, cy, cz)) return;
+    const int cell = icp_cell_index(cx, cy, cz);
+    const uint32_t pos = a.start[cell] + atomicSub(&a.cnt[cell], 1u) - 1u;     // fills the cell's range from the back
+    a.spts[pos] = make_float4(v.x, v.y, v.z, __int_as_float(p));
+}
+
+// visits every target point (by sorted position) of the shell of Chebyshev radius r around cell (cx,cy,cz), skipping
+// the cells whose box lies farther from the query (qx,qy,qz) than bound() -- the caller's current search radius squared
+// (after the own cell has produced a candidate a few centimetres away, almost every neighbouring cell is culled)
 template <typename B, typename F>
 __device__ __forceinline__ void icp_visit_shell(const IcpArgs &a, int cx, int cy, int cz, int r, double qx, double qy,
                                                 double qz, B &&bound, F &&f)
@@ -84,13 +141,24 @@ __device__ __forceinline__ void icp_visit_shell(const IcpArgs &a, int cx, int cy
             const double eyz = ey * ey + ez * ez;
             if (eyz >= bound()) continue;
             const bool face = (dz == -r || dz == r || dy == -r || dy == r);
-            for (int dx = -r; dx <= r; dx += (face || r == 0) ? 1 : 2 * r) {     // interior rows: only the two end cells
-                const int x = cx + dx;
-                if (x < 0 || x >= ICP_NX) continue;
-                const double x0 = ICP_OX + x * ICP_CELL;
-                const double ex = qx < x0 ? x0 - qx : (qx > x0 + ICP_CELL ? qx - (x0 + ICP_CELL) : 0.0);
-                if (ex * ex + eyz >= bound()) continue;
-                for (int q = a.head[icp_cell_index(x, y, z)]; q >= 0; q = a.next[q]) f(q);
+            if (face) {
+                // a whole row of the shell: its cells are neighbours in memory, one range of sorted points
+                const int x_lo = cx - r < 0 ? 0 : cx - r, x_hi = cx + r >= ICP_NX ? ICP_NX - 1 : cx + r;
+                if (x_lo > x_hi) continue;
+                const int c0 = icp_cell_index(x_lo, y, z);
+                const uint32_t e = a.start[c0 + (x_hi - x_lo) + 1];
+                for (uint32_t q = a.start[c0]; q < e; ++q) f((int)q);
+            } else {                                        // interior rows: only the two end cells
+                for (int dx = -r; dx <= r; dx += 2 * r) {
+                    const int x = cx + dx;
+                    if (x < 0 || x >= ICP_NX) continue;
+                    const double x0 = ICP_OX + x * ICP_CELL;
+                    const double ex = qx < x0 ? x0 - qx : (qx > x0 + ICP_CELL ? qx - (x0 + ICP_CELL) : 0.0);
+                    if (ex * ex + eyz >= bound()) continue;
+                    const int c0 = icp_cell_index(x, y, z);
+                    const uint32_t e = a.start[c0 + 1];
+                    for (uint32_t q = a.start[c0]; q < e; ++q) f((int)q);
+                }
             }
         }
     }
@@ -139,9 +207,9 @@ __device__ __forceinline__ void icp_smallest_eigvec(double A[3][3], double n[3])
 __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
 {
     __shared__ float s_d[ICP_K][ICP_THREADS];               // per thread: the K smallest squared distances, ascending
-    const int p = blockIdx.x * ICP_THREADS + threadIdx.x;
-    if (p >= a.n_tgt) return;
-    const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
+    const int p = blockIdx.x * ICP_THREADS + threadIdx.x;         // sorted position
+    if (p >= (int)a.start[ICP_CELLS]) return;
+    const float4 v = a.spts[p];
     float4 out = make_float4(0.f, 0.f, 1.f, 0.f);
     int cx, cy, cz;
     if (icp_cell_of(v.x, v.y, v.z, cx, cy, cz)) {
@@ -151,7 +219,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
             icp_visit_shell(a, cx, cy, cz, r, v.x, v.y, v.z,
                             [&]() { return found == ICP_K ? (double)s_d[ICP_K - 1][t] * (1.0 + 1e-6) + 1e-12 : 1e300; },
                             [&](int q) {
-                const float4 w = reinterpret_cast<const float4 *>(a.tgt)[q];
+                const float4 w = a.spts[q];
                 const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z;
                 const float d2 = dx * dx + dy * dy + dz * dz;
                 if (found == ICP_K && d2 >= s_d[ICP_K - 1][t]) return;
@@ -171,7 +239,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
             for (int r = 0; r <= rmax && r <= ICP_NORMAL_RINGS; ++r)
                 icp_visit_shell(a, cx, cy, cz, r, v.x, v.y, v.z, [&]() { return (double)lim * (1.0 + 1e-6) + 1e-12; },
                                 [&](int q) {
-                    const float4 w = reinterpret_cast<const float4 *>(a.tgt)[q];
+                    const float4 w = a.spts[q];
                     const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z;
                     if (dx * dx + dy * dy + dz * dz > lim) return;
                     const double x = dx, y = dy, z = dz;                        // relative to the query: well conditioned
@@ -213,15 +281,16 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_accumulate(const IcpArgs a)
         int bi = -1;
         for (int r = 0; r <= ICP_MATCH_RINGS; ++r) {
             icp_visit_shell(a, cx, cy, cz, r, qx, qy, qz, [&]() { return best * (1.0 + 1e-12) + 1e-300; }, [&](int q) {
-                const float4 w = reinterpret_cast<const float4 *>(a.tgt)[q];
+                const float4 w = a.spts[q];
                 const double dx = w.x - qx, dy = w.y - qy, dz = w.z - qz;
                 const double d2 = dx * dx + dy * dy + dz * dz;
-                if (d2 < best || (d2 == best && q < bi)) { best = d2; bi = q; }   // ties: lowest index (list order varies)
+                // ties: lowest ORIGINAL index (the order inside a cell varies from run to run)
+                if (d2 < best || (d2 == best && bi >= 0 && __float_as_int(w.w) < __float_as_int(a.spts[bi].w))) { best = d2; bi = q; }
             });
             if (bi >= 0 && best <= (r * ICP_CELL) * (r * ICP_CELL)) break;
         }
         if (bi < 0) continue;
-        const float4 w = reinterpret_cast<const float4 *>(a.tgt)[bi];
+        const float4 w = a.spts[bi];
         const float4 nn = reinterpret_cast<const float4 *>(a.normal)[bi];
         acc[27] += best;                                    // Open3D: fitness / rmse over all correspondences
         acc[28] += 1.0;
@@ -314,7 +383,7 @@ static inline int icp_grid(int n) { const int g = (n + ICP_THREADS - 1) / ICP_TH
 int64_t pca_icp_workspace_bytes(int32_t max_points)
 {
     if (max_points < 1) max_points = 1;
-    return icp_align((int64_t)ICP_NX * ICP_NY * ICP_NZ * 4) + icp_align((int64_t)max_points * 4) + icp_align((int64_t)max_points * 16) +
+    return icp_align(ICP_CELLS * 4) + icp_align((ICP_CELLS + 1) * 4) + 2 * icp_align((int64_t)max_points * 16) +
            icp_align((int64_t)1024 * ICP_NACC * 8) + icp_align(32 * 8) + 512;
 }
 
@@ -333,8 +402,9 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
     a.src = src_pts; a.tgt = tgt_pts; a.n_src = n_src; a.n_tgt = n_tgt;
     char *w = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     const int64_t cells = (int64_t)ICP_NX * ICP_NY * ICP_NZ;
-    a.head = reinterpret_cast<int32_t *>(w); w += icp_align(cells * 4);
-    a.next = reinterpret_cast<int32_t *>(w); w += icp_align((int64_t)n_tgt * 4);
+    a.cnt = reinterpret_cast<uint32_t *>(w); w += icp_align(cells * 4);
+    a.start = reinterpret_cast<uint32_t *>(w); w += icp_align((cells + 1) * 4);
+    a.spts = reinterpret_cast<float4 *>(w); w += icp_align((int64_t)n_tgt * 16);
     a.normal = reinterpret_cast<float *>(w); w += icp_align((int64_t)n_tgt * 16);
     a.partial = reinterpret_cast<double *>(w); w += icp_align((int64_t)1024 * ICP_NACC * 8);
     a.state = reinterpret_cast<double *>(w);
@@ -344,9 +414,17 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
     double st[32] = {0};
     static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     for (int i = 0; i < 16; ++i) st[i] = init ? init[i] : eye[i];
-    PCA_CHECK(ctx, hipMemsetAsync(a.head, 0xff, (size_t)cells * 4, s));
+    PCA_CHECK(ctx, hipMemsetAsync(a.cnt, 0, (size_t)cells * 4, s));
     PCA_CHECK(ctx, hipMemcpyAsync(a.state, st, sizeof st, hipMemcpyHostToDevice, s));
-    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_insert, dim3((n_tgt + ICP_THREADS - 1) / ICP_THREADS), dim3(ICP_THREADS), s, a);
+    const int scan_tiles = (int)(cells / ICP_SCAN_TILE);
+    if (pca_ctx_reserve_tiles(ctx, scan_tiles, s)) return -1;
+    a.lb_state = ctx->tile_state;
+    a.ticket = ctx->ticket;
+    a.epoch = pca_ctx_next_epoch(ctx, s);
+    const dim3 per_point((n_tgt + ICP_THREADS - 1) / ICP_THREADS);
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_count, per_point, dim3(ICP_THREADS), s, a);
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_cell_scan, dim3(scan_tiles), dim3(ICP_SCAN_THREADS), s, a);
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_fill, per_point, dim3(ICP_THREADS), s, a);
     PCA_LAUNCH(ctx, PCA_K_ICP, icp_normals, dim3((n_tgt + ICP_THREADS - 1) / ICP_THREADS), dim3(ICP_THREADS), s, a);
     // one more evaluation than updates: Open3D reports fitness / rmse of the final transform
     for (int it = 0; it <= max_iter; ++it) {
