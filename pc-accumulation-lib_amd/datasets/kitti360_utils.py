@@ -32,18 +32,22 @@ def extract_seseg_pc(pc, filter):
     return pc[pc[:, -1] == filter]
 
 
+def _calibration(root, name):
+    return os.path.join(root, 'calibration', name)
+
+
 def get_transf_matrices(kitti360_path: str):
-    """(H_cam_velo, H_velo_cam): camera->velodyne 4x4 from calib_cam_to_velo.txt and its inverse."""
-    flat = np.genfromtxt(os.path.join(kitti360_path, 'calibration', 'calib_cam_to_velo.txt'), delimiter=" ")
-    H_cam_velo = np.concatenate((flat.reshape((3, 4)), np.array([0, 0, 0, 1]).reshape(1, 4)), axis=0)
-    return H_cam_velo, np.linalg.inv(H_cam_velo)
+    """(camera -> velodyne, velodyne -> camera) as 4x4 matrices; the file holds the 12 numbers of the top 3x4 block."""
+    top = np.genfromtxt(_calibration(kitti360_path, 'calib_cam_to_velo.txt'), delimiter=" ").reshape((3, 4))
+    cam_to_velo = np.vstack([top, [[0, 0, 0, 1]]]).astype(float)
+    return cam_to_velo, np.linalg.inv(cam_to_velo)
 
 
 def get_camera_intrinsics(kitti360_path: str):
-    """3x4 rectified projection matrix P_rect_00 from calibration/perspective.txt."""
-    with open(os.path.join(kitti360_path, 'calibration', 'perspective.txt'), 'r') as f:
-        for line in f:
-            key, _, rest = line.partition(':')
-            if key == 'P_rect_00':
-                return np.array(rest.split(), dtype=float).reshape((3, 4))
-    raise Exception('Did not find \'P_rect_00\' entry in calibration file.')
+    """The 3x4 rectified projection of camera 00 ('P_rect_00: <12 numbers>' in perspective.txt)."""
+    wanted = 'P_rect_00'
+    for line in open(_calibration(kitti360_path, 'perspective.txt')):
+        key, _, numbers = line.partition(':')
+        if key == wanted:
+            return np.array(numbers.split(), dtype=float).reshape((3, 4))
+    raise Exception(f"Did not find '{wanted}' entry in calibration file.")

@@ -1,29 +1,32 @@
-"""Iterator protocol of the observation loaders (reference: obs_dataloaders/obs_dataloader.py)."""
+"""Iterator protocol of the observation loaders (reference: obs_dataloaders/obs_dataloader.py).
+
+A loader is its own iterator: `for batch in loader` yields lists of `batch_size` consecutive observations
+(`read_obs(i)`), a trailing partial batch is dropped, and iterating again restarts from observation 0.
+"""
 from abc import ABC, abstractmethod
 
 
 class ObservationDataloader(ABC):
 
     def __init__(self, root_path: str, batch_size: int):
-        self.root_path = root_path
-        self.batch_size = batch_size
+        self.root_path, self.batch_size = root_path, batch_size
+        self.idx = 0
 
     @abstractmethod
     def read_obs(self, idx):
-        pass
+        """One observation (KITTI-360: (PIL image, (N,4) points, labels | None); NuScenes: a dict)."""
 
     @abstractmethod
     def __len__(self):
-        pass
+        """Number of observations."""
 
     def __iter__(self):
         self.idx = 0
         return self
 
     def __next__(self):
-        """Next list of `batch_size` observations; a trailing partial batch is dropped."""
-        if self.idx + self.batch_size > len(self):
+        first, stop = self.idx, self.idx + self.batch_size
+        if stop > len(self):
             raise StopIteration
-        batch = [self.read_obs(self.idx + k) for k in range(self.batch_size)]
-        self.idx += self.batch_size
-        return batch
+        self.idx = stop
+        return [self.read_obs(k) for k in range(first, stop)]
