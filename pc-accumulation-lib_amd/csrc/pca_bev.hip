@@ -25,8 +25,10 @@
 #define AB_THREADS 1024           // workgroup size of the hist / scatter kernels
 #define MAX_G 512                 // workgroups of the hist / scatter kernels
 #define C_THREADS 256             // workgroup size of the tile kernel
-#define RGB_CAP 4096              // colour records resident in LDS: larger tiles go to bev_tile_cells_heavy
+#define RGB_CAP 4096              // colour records resident in LDS
 #define CONTIG_MIN 2560           // tiles above this many records are read thread-contiguously (runs form)
+#define HEAVY_MIN_DEFAULT 3072    // tiles above this many records go to bev_tile_cells_heavy (PCA_BEV_HEAVY_MIN; the
+                                  // uniform benchmark's tiles hold ~2000, a dense tile costs the light kernel 4x its neighbours)
 #define FLAG_ROAD (1u << 24)
 #define FLAG_DYNOBJ (1u << 25)
 
@@ -49,6 +51,7 @@ struct BevArgs {
     int pend_slot_end;    // <= slot_begin: none
     int tx, T, G;
     int tile_mult;        // bev_tile_cells: workgroup -> tile permutation (coprime to T)
+    int heavy_min;        // tiles with more records than this are bev_tile_cells_heavy's (<= RGB_CAP)
     uint32_t *key;        // [max_points]
     uint32_t *bh;         // [T][G] kept records per (tile, workgroup)
     uint32_t *boff;       // [T][G] exclusive scan of bh in that order
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_scatter(const BevArgs a)
     // queue of the tiles whose records exceed the LDS colour buffer of bev_tile_cells: they are bev_tile_cells_heavy's
     if (blockIdx.x == 0)
         for (int t = threadIdx.x; t < a.T; t += AB_THREADS)
-            if (a.tile_off[t + 1] - a.tile_off[t] > RGB_CAP) a.heavy[3 + atomicAdd(&a.heavy[0], 1u)] = (uint32_t)t;
+            if (a.tile_off[t + 1] - a.tile_off[t] > (uint32_t)a.heavy_min) a.heavy[3 + atomicAdd(&a.heavy[0], 1u)] = (uint32_t)t;
     for (int t = threadIdx.x; t < a.T; t += AB_THREADS) s_cur[t] = a.boff[(int64_t)t * a.G + blockIdx.x];
     __syncthreads();
     const pca_bev_params &q = a.prm;
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
     // (tile_mult coprime to T), which interleaves them with the empty ones in dispatch order.
     const int tile = (int)(((int64_t)blockIdx.x * a.tile_mult) % a.T);
     const uint32_t r_lo = a.tile_off[tile], r_hi = a.tile_off[tile + 1];
-    if (r_hi - r_lo > RGB_CAP) return;                      // bev_tile_cells_heavy's (queued by bev_tile_scatter)
+    if (r_hi - r_lo > (uint32_t)a.heavy_min) return;        // bev_tile_cells_heavy's (queued by bev_tile_scatter)
     const unsigned long long t_begin = wall_clock64();
     stats_init(L.S, C_THREADS);
     __syncthreads();
@@ -871,6 +874,7 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
     a.planes = planes;
     a.planes_f16 = planes_f16;
     a.extra = extra_planes;
+    { static int hm = -1; if (hm < 0) { const char *e = getenv("PCA_BEV_HEAVY_MIN"); hm = e ? atoi(e) : HEAVY_MIN_DEFAULT; if (hm < 1 || hm > RGB_CAP) hm = RGB_CAP; } a.heavy_min = hm; }
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("PCA_BEV_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     static bool heavy_lds_set = false;                      // > 64 KiB of dynamic LDS has to be asked for once
     if (!heavy_lds_set) {
