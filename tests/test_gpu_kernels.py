@@ -576,3 +576,45 @@ def test_voxel_dedup_first_point_per_voxel_stays(T, n_frames, size):
     assert np.array_equal(st.sizes(), sizes_before)
     assert all(np.array_equal(a, b) for a, b in zip(st.frame_rows(), got))
     assert 0 < keep.sum() < len(allrows) or len(allrows) == 0
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_bev_randomised_configs_match_oracle(T, orc, seed):
+    """Seeded random sweep over the rasteriser's parameter space -- grid size (including non-multiples of the 8x8 tile
+    and single-tile grids), view, rotation, augmentation shift, height filter, intensity encoding, class mix, dynamic
+    flags, clustered vs uniform points (light and heavy tiles, cells above and below 64 values), empty present or
+    future sets -- every plane against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    px = int(rng.choice([1, 5, 8, 13, 32, 57, 64, 96, 129, 200, 256]))
+    view = float(rng.choice([8.0, 20.0, 51.2, 80.0, 123.4]))
+    n = int(rng.choice([0, 1, 70, 3000, 40000, 120000]))
+    rows = np.zeros((n, 10))
+    mode = rng.integers(0, 3)
+    if mode == 0:                                            # uniform
+        rows[:, :2] = rng.uniform(-0.6 * view, 0.6 * view, (n, 2))
+    elif mode == 1:                                          # a few dense clusters + background
+        centres = rng.uniform(-0.4 * view, 0.4 * view, (5, 2))
+        pick = rng.integers(0, 5, n)
+        rows[:, :2] = centres[pick] + rng.normal(0, 0.01 * view, (n, 2))
+        bg = rng.random(n) < 0.2
+        rows[bg, :2] = rng.uniform(-0.6 * view, 0.6 * view, (int(bg.sum()), 2))
+    else:                                                    # along a path
+        rows[:, 0] = rng.uniform(-0.6 * view, 0.6 * view, n)
+        rows[:, 1] = rng.normal(0, 0.03 * view, n)
+    rows[:, 2] = rng.uniform(-2, 4, n)
+    div255 = bool(rng.integers(0, 2))
+    rows[:, 3] = rng.integers(0, 256, n) / 255. if div255 else rng.uniform(0, 1, n).astype(np.float32)
+    spread = int(rng.choice([0, 3, 40, 255]))
+    base = rng.integers(0, 256, 3)
+    rows[:, 4:7] = np.clip(base + rng.integers(-spread, spread + 1, (n, 3)), 0, 255)
+    rows[:, 7] = rng.choice([0, 1, 2, 8, 13, 14, 15, 17], n)
+    rows[:, 9] = rng.random(n) < float(rng.choice([0.0, 0.05, 0.5]))
+    cut = int(rng.choice([0, n // 3, n // 2, n]))
+    hf = None if rng.integers(0, 2) else float(rng.uniform(0, 3))
+    ints = (20., 20., 0.5) if not div255 else (1., 30., 0.12)
+    rot = float(rng.uniform(-np.pi, np.pi))
+    dx, dy = (0., 0.) if rng.integers(0, 2) else tuple(rng.uniform(-0.1 * view, 0.1 * view, 2))
+    origin = tuple(rng.uniform(-1, 1, 3))
+    p16, p64, _ = run_dev_bev(T, rows[:cut], rows[cut:], view, px, hf, ints, div255, rot, dx, dy, origin)
+    ref = run_orc_bev(orc, rows[:cut], rows[cut:], view, px, hf, ints, div255, rot, dx, dy, origin)
+    assert_planes_match(p16, p64, ref, f'seed {seed}: px={px} view={view} n={n} mode={mode}')
