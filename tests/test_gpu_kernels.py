@@ -618,3 +618,47 @@ def test_bev_randomised_configs_match_oracle(T, orc, seed):
     p16, p64, _ = run_dev_bev(T, rows[:cut], rows[cut:], view, px, hf, ints, div255, rot, dx, dy, origin)
     ref = run_orc_bev(orc, rows[:cut], rows[cut:], view, px, hf, ints, div255, rot, dx, dy, origin)
     assert_planes_match(p16, p64, ref, f'seed {seed}: px={px} view={view} n={n} mode={mode}')
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_k1_k2_randomised_batches_match_oracle(T, orc, seed):
+    """Seeded random sweep over K1 + K2: image sizes (down to 1x2), projection matrices (random rotations, focal
+    lengths, points behind / on the camera plane), filter sets, batch compositions (empty, tiny, tile-boundary and
+    large frames, several launches), interleaved re-transforms -- stored rows and segment sizes against the oracle."""
+    rng = np.random.default_rng(5000 + seed)
+    H, W = int(rng.choice([1, 2, 7, 64, 376])), int(rng.choice([2, 3, 96, 1408]))
+    f = float(rng.uniform(0.3, 2.0)) * W
+    K = np.array([[f, 0, W / 2 + rng.uniform(-3, 3), 0], [0, f, H / 2 + rng.uniform(-3, 3), 0], [0, 0, 1, 0]])
+    ang = rng.uniform(-np.pi, np.pi, 3)
+    Rx = np.array([[1, 0, 0], [0, np.cos(ang[0]), -np.sin(ang[0])], [0, np.sin(ang[0]), np.cos(ang[0])]])
+    Rz = np.array([[np.cos(ang[2]), -np.sin(ang[2]), 0], [np.sin(ang[2]), np.cos(ang[2]), 0], [0, 0, 1]])
+    E = np.eye(4)
+    E[:3, :3] = Rz @ Rx
+    E[:3, 3] = rng.uniform(-2, 2, 3)
+    P = K @ E
+    filters = sorted(set(rng.integers(0, 20, int(rng.integers(0, 6))).tolist()) | ({255} if rng.integers(0, 2) else set()))
+    pool = [0, 1, 2, 63, 64, 65, 2047, 2048, 2049, 5000, 30000, 121111]
+    st = dev_store(capacity=700000, max_frames=64)
+    ost = orc.Store(700000)
+    sizes = []
+    for launch in range(int(rng.integers(1, 4))):
+        if launch and rng.integers(0, 2):
+            Tm = np.eye(4)
+            a = rng.uniform(-0.05, 0.05)
+            Tm[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+            Tm[:3, 3] = rng.uniform(-1.5, 1.5, 3)
+            st.retransform(Tm, defer=bool(rng.integers(0, 2)))
+            orc.retransform(ost, Tm)
+        frames = []
+        for _ in range(int(rng.integers(1, 6))):
+            n = int(rng.choice(pool))
+            pc, img, sem = kitti_frame(rng, n, H, W, lim=float(rng.choice([3.0, 60.0])))
+            if n > 4:
+                pc[0, :3] = 0.0                              # exactly on the camera centre / plane
+                pc[1, :3] = -pc[2, :3]
+            frames.append(dict(pts=cu(T, pc), rgb=cu(T, img), sem=cu(T, sem)))
+            sizes.append(orc.kitti_project_sample_filter(ost, pc, P, img, sem, None, H, W, filters))
+        st.append_kitti(frames, P, H, W, filters)
+    st.check_status()
+    assert st.sizes().tolist() == sizes
+    assert np.array_equal(st.rows(), ost.rows()), f'seed {seed}: H={H} W={W} filters={filters}'
