@@ -662,3 +662,63 @@ def test_k1_k2_randomised_batches_match_oracle(T, orc, seed):
     st.check_status()
     assert st.sizes().tolist() == sizes
     assert np.array_equal(st.rows(), ost.rows()), f'seed {seed}: H={H} W={W} filters={filters}'
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_nuscenes_kernels_randomised_match_oracle(T, orc, seed):
+    """Seeded random sweep over the NuScenes kernels: K0n (1..6 cameras, random poses / intrinsics, points behind the
+    cameras), K1n (random images, assignments incl. 'on no camera', class filters, poses), K3 (dynamic marking of
+    instances over several frames)."""
+    from datasets.nuscenes_utils import project_to_cameras
+    rng = np.random.default_rng(9000 + seed)
+    ncam = int(rng.integers(1, 7))
+    H, W = int(rng.choice([8, 90, 225])), int(rng.choice([12, 160, 400]))
+
+    def pose():
+        a = rng.uniform(-np.pi, np.pi)
+        M = np.eye(4)
+        M[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        M[:3, 3] = rng.uniform(-30, 30, 3) * [1, 1, 0.05]
+        return M
+    # K0n
+    n0 = int(rng.choice([1, 64, 3333, 20000]))
+    lidar = np.c_[rng.uniform(-40, 40, (n0, 2)), rng.uniform(-2, 3, n0)]
+    ego_from_lidar, glob_from_ego = pose(), pose()
+    cam_R = np.array([[0, -1, 0, 0], [0, 0, -1, 0], [1, 0, 0, 0], [0, 0, 0, 1.]])      # camera looks along ego x
+    cams = [glob_from_ego @ pose() @ np.linalg.inv(cam_R) for _ in range(ncam)]
+    Ks = [np.array([[rng.uniform(0.5, 1.5) * W, 0, W / 2], [0, rng.uniform(0.5, 1.5) * W, H / 2], [0, 0, 1.]])
+          for _ in range(ncam)]
+    whs = [np.array([W, H], dtype=float)] * ncam
+    ego, uv, cam = project_to_cameras(lidar, ego_from_lidar, glob_from_ego, cams, Ks, whs)
+    o_ego, o_uv, o_cam = orc.nusc_project_cams(lidar, ego_from_lidar, glob_from_ego,
+                                               np.stack([np.linalg.inv(c) for c in cams]), np.stack(Ks), np.stack(whs))
+    assert np.array_equal(ego, o_ego) and np.array_equal(cam, o_cam) and np.array_equal(uv, o_uv)
+    # K1n + K3 over a few frames
+    filters = sorted(set(rng.integers(0, 19, int(rng.integers(0, 5))).tolist()))
+    st = dev_store(capacity=200000, max_frames=16, intensity_div255=True)
+    ost = orc.Store(200000, intensity_div255=True)
+    offs = [0]
+    for k in range(int(rng.integers(1, 5))):
+        n = int(rng.choice([0, 1, 255, 256, 257, 9000, 34720]))
+        pc = np.zeros((n, 7))
+        pc[:, :2] = rng.uniform(-50, 50, (n, 2))
+        pc[:, 2] = rng.uniform(-2, 4, n)
+        pc[:, 3] = rng.integers(0, 256, n)
+        pc[:, 4] = rng.uniform(1.01, W - 1.01, n)
+        pc[:, 5] = rng.uniform(1.01, H - 1.01, n)
+        pc[:, 6] = rng.integers(-1, 5, n)
+        cidx = rng.integers(-1, ncam, n)
+        imgs = rng.integers(0, 256, (ncam, H, W, 3), dtype=np.uint8)
+        sems = rng.integers(0, 19, (ncam, H, W)).astype(np.uint8)
+        Tw = pose()
+        st.append_nusc(cu(T, pc), cu(T, cidx), cu(T, imgs), cu(T, sems), Tw, filters)
+        offs.append(offs[-1] + orc.nusc_sample_filter_transform(ost, pc, cidx, imgs, sems, Tw, filters))
+    st.check_status()
+    assert np.array_equal(st.offsets(), np.array(offs))
+    assert np.array_equal(st.rows(), ost.rows())
+    nf = len(offs) - 1
+    pairs = [(int(rng.integers(0, nf)), int(rng.integers(-1, 5))) for _ in range(int(rng.integers(0, 7)))]
+    st.mark_dynamic(pairs)
+    for f, i in pairs:
+        orc.mark_dynamic(ost, offs[f], offs[f + 1], i)
+    assert np.array_equal(st.rows(), ost.rows())
