@@ -5,15 +5,17 @@
 //                       height / floor -> key = tile<<7 | cell_in_tile<<1 | set; per-workgroup LDS histogram
 //                       over tiles -> bh[workgroup][tile]           (reads 25 B/pt, writes 4 B/pt)
 //     bev_tile_scan     exclusive scan of bh in (tile, workgroup) order (decoupled look-back)
-//     bev_tile_scatter  records {z, intensity, rgb|flags, fine key} -> tile-ordered SoA streams; the position
-//                       comes from an LDS cursor per tile (returning LDS atomics)
+//     bev_tile_scatter  16-byte records {z, intensity | set, rgb | flags | cell} -> one tile-ordered stream; the
+//                       position comes from an LDS cursor per tile (returning LDS atomics); workgroup 0 also queues
+//                       the tiles that are too dense for the light tile kernel
 //   level 2 (one workgroup per tile)
-//     bev_tile_cells    tiles of at most RGB_CAP records.  pass 1: per (cell,set) counts / exact integer intensity
-//                       sums / min z by LDS atomics; pass 2: LDS counting sort of the colours by (cell,set); exact
-//                       medians per cell (n <= 64: bit-sliced radix select, one lane per target; else a per-wave
+//     bev_tile_cells    tiles of at most heavy_min (<= RGB_CAP) records.  pass 1: per (cell,set) counts / exact
+//                       integer intensity sums / min z (per-thread runs of equal keys, then LDS atomics); pass 2: LDS
+//                       counting sort of the colours by (cell,set); exact medians per cell (n <= 64: bit-sliced radix
+//                       select on bit planes obtained by a cross-lane transpose, one lane per target; else a per-wave
 //                       256-bin histogram); closed-form maps, fp16, tile written back.
-//     bev_tile_cells_heavy  the other tiles: 1024 threads, 256-bin histograms of 32 cells at a time filled
-//                       straight from the record stream (two passes over the tile's records, no sort).
+//     bev_tile_cells_heavy  the queued tiles, drawn by one resident 1024-thread workgroup per CU: 256-bin histograms
+//                       of 32 cells at a time filled straight from the record stream (two passes, no sort).
 // 'full' = present (+) future is formed per cell (counts add, min of mins, median of the union).
 #include "pca_bev_common.h"
 #include <cstdlib>
@@ -57,8 +59,7 @@ struct BevArgs {
     uint32_t *boff;       // [T][G] exclusive scan of bh in that order
     uint32_t *tile_off;   // [T+1]
     uint32_t *heavy_hint; // host-visible word: the heavy count of this call, read by the host before the next one
-    uint32_t *heavy;      // [3+T]: heavy count, heavy cursor, tile ticket of bev_tile_cells, ids of the tiles it
-                          //        leaves to bev_tile_cells_heavy
+    uint32_t *heavy;      // [3+T]: heavy count, heavy cursor, (reserved), ids of the tiles left to bev_tile_cells_heavy
     void *recs;           // RecF / RecD [max_points], tile-ordered; c = r | g<<8 | b<<16 | FLAG_*
     double *planes;
     uint16_t *planes_f16;
