@@ -210,6 +210,16 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
                         uint16_t *planes_f16 /*dev*/, double *extra_planes /*dev, may be NULL*/, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Host helper (no device work): the ego trajectory of one BEV sample -- rotate, translate, clip to the view box
+ * with bisected border crossings, grid coordinates.  Replaces bev_generator/bev_generator.py:207-371, :737-747 for
+ * the ego polyline (plain IEEE arithmetic, bit-identical to the numpy form in pca_amd/host_logic.py).
+ * full: host [F,3] f64; R: 3x3 row-major; rows: host [2(F-1),3] out; start: host [F] out (first row of every
+ * edge; start[F-1] = number of rows).  Returns the number of rows.
+ * ------------------------------------------------------------------------------------------------ */
+int pca_host_ego_to_grid(const double *full, int F, const double R[9], double dx, double dy, double view, int px,
+                         double *rows, int32_t *start);
+
+/* ------------------------------------------------------------------------------------------------
  * Optional timing with HIP events recorded on the call's stream.  on = 1: every kernel launch is bracketed
  * (ids PCA_K_KITTI .. PCA_K_DEDUP); on = 2: only whole multi-kernel units are (PCA_K_BEV_UNIT = one
  * pca_bev_generate call, launch gaps included, without the per-kernel events in between); 0: off.  pca_profile_read synchronises, returns the accumulated time / launch count of one

@@ -17,7 +17,7 @@ STATUS_NEGATIVE_INTENSITY = 4
 EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error', 'pca_status',
            'pca_kitti_tile_points', 'pca_kitti_tiles', 'pca_kitti_project_sample_filter',
            'pca_nusc_sample_filter_transform', 'pca_nusc_project_cams', 'pca_retransform', 'pca_mark_dynamic',
-           'pca_bev_workspace_bytes', 'pca_bev_generate', 'pca_bev_generate_ex', 'pca_voxel_dedup_workspace_bytes', 'pca_voxel_dedup', 'pca_icp_workspace_bytes', 'pca_icp_register',
+           'pca_bev_workspace_bytes', 'pca_bev_generate', 'pca_bev_generate_ex', 'pca_voxel_dedup_workspace_bytes', 'pca_voxel_dedup', 'pca_icp_workspace_bytes', 'pca_icp_register', 'pca_host_ego_to_grid',
            'pca_profile_enable', 'pca_profile_read')
 
 KERNEL_IDS = ('kitti_project_sample_filter', 'nusc_sample_filter_transform', 'nusc_project_cams', 'retransform',
@@ -113,6 +113,7 @@ def load():
     lib.pca_icp_register.argtypes = [vp, vp, i32, vp, i32, C.c_double, C.POINTER(C.c_double), i32, C.c_double,
                                      C.c_double, vp, i64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(C.c_int), vp]
+    lib.pca_host_ego_to_grid.argtypes = [vp, i32, vp, C.c_double, C.c_double, C.c_double, i32, vp, vp]
     lib.pca_profile_enable.argtypes = [vp, i32]
     lib.pca_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = lib
