@@ -163,7 +163,11 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_hist(const BevArgs a)
 // level 1b: exclusive scan of bh in (tile-major, workgroup-minor) order -> boff, tile_off
 // ---------------------------------------------------------------------------------------------
 #define SCAN_THREADS 1024
-#define SCAN_TILE (4 * SCAN_THREADS)       // few large scan tiles: the look-back then spans at most one window
+#ifndef SCAN_PER
+#define SCAN_PER 4                         // counters per thread (8: same time, 16: slower)
+#endif
+#define SCAN_TILE (SCAN_PER * SCAN_THREADS) // few large scan tiles: all of them run at once and each waits for its
+                                           // predecessor's prefix, so the critical path grows with their number
 __global__ __launch_bounds__(SCAN_THREADS) void bev_tile_scan(const BevArgs a)
 {
     __shared__ int s_tile;
@@ -179,11 +183,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void bev_tile_scan(const BevArgs a)
     __syncthreads();
     const int tile = s_tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int base = tile * SCAN_TILE + threadIdx.x * 4;    // bh and boff are both [tile][workgroup]: contiguous
-    uint32_t c[4];
+    const int base = tile * SCAN_TILE + threadIdx.x * SCAN_PER;    // bh and boff are both [tile][workgroup]: contiguous
+    uint32_t c[SCAN_PER];
+    if (base + SCAN_PER <= n) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) c[k] = (base + k < n) ? a.bh[base + k] : 0u;
-    const uint32_t tsum = c[0] + c[1] + c[2] + c[3];
+        for (int k = 0; k < SCAN_PER; k += 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.bh + base + k);
+            c[k] = v.x; c[k + 1] = v.y; c[k + 2] = v.z; c[k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) c[k] = (base + k < n) ? a.bh[base + k] : 0u;
+    }
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) tsum += c[k];
     const uint32_t inc = wave_incl_scan_add(tsum);
     if (lane == 63) s_w[wave] = inc;
     __syncthreads();
@@ -198,14 +212,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void bev_tile_scan(const BevArgs a)
     __syncthreads();
     const uint32_t excl = (uint32_t)(s_excl >> 32), total = (uint32_t)s_excl;
     uint32_t run = excl + s_w[wave] + (inc - tsum);
+    uint32_t o[SCAN_PER];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < SCAN_PER; ++k) {
         const int i = base + k;
-        if (i < n) {
-            a.boff[i] = run;
-            if (i % a.G == 0) a.tile_off[i / a.G] = run;
-        }
+        o[k] = run;
+        if (i < n && i % a.G == 0) a.tile_off[i / a.G] = run;
         run += c[k];
+    }
+    if (base + SCAN_PER <= n) {
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; k += 4) *reinterpret_cast<uint4 *>(a.boff + base + k) = make_uint4(o[k], o[k + 1], o[k + 2], o[k + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) if (base + k < n) a.boff[base + k] = o[k];
     }
     if (tile == a.scan_tiles - 1 && threadIdx.x == SCAN_THREADS - 1) a.tile_off[a.T] = excl + total;
 }
