@@ -151,7 +151,7 @@ int pca_voxel_dedup(pca_ctx *ctx, const pca_store *store, int64_t *frame_off /*d
  *     src_pts / tgt_pts: dev [n,4] f32 rows x,y,z,(ignored).  init / T_out: host 4x4 row-major; T_out maps source
  *     coordinates into the target frame (T_new_prev).  Synchronises `stream` before returning.
  * ------------------------------------------------------------------------------------------------ */
-int64_t pca_icp_workspace_bytes(int32_t max_points);
+int64_t pca_icp_workspace_bytes(int32_t max_points);   /* max_points >= max(n_src, n_tgt) */
 int pca_icp_register(pca_ctx *ctx, const float *src_pts /*dev*/, int32_t n_src, const float *tgt_pts /*dev*/,
                      int32_t n_tgt, double max_corr_dist, const double init[16], int max_iter, double rel_fitness,
                      double rel_rmse, void *workspace /*dev*/, int64_t workspace_bytes, double T_out[16],

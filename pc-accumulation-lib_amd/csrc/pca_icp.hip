@@ -19,30 +19,41 @@
 //                     T <- exp(x) T, fitness / rmse, convergence flag -- the iteration loop never leaves the device
 #include "pca_common.h"
 
-#define ICP_CELL 0.5
+// Two uniform grids of 512 x 512 x 64 cells around the sensor: level 0 = 0.5 m cells (256 m x 256 m x 32 m), level 1 =
+// 0.25 m cells (128 m x 128 m x 16 m).  Next to the sensor a 0.5 m cell holds ~300 returns: a query settles in the fine
+// grid (<= 1 m search radius) and only the sparse far field expands through the coarse one.
 #define ICP_NX 512
 #define ICP_NY 512
 #define ICP_NZ 64
-#define ICP_OX (-128.0)
-#define ICP_OY (-128.0)
-#define ICP_OZ (-16.0)
+#define ICP_CELLS ((int64_t)ICP_NX * ICP_NY * ICP_NZ)
+template <int LV> struct IcpLevel {
+    static constexpr double cell = LV ? 0.25 : 0.5;
+    static constexpr double ox = LV ? -64.0 : -128.0, oy = LV ? -64.0 : -128.0, oz = LV ? -8.0 : -16.0;
+};
 #define ICP_K 30                 // neighbours of a normal (Open3D's default KDTreeSearchParamKNN)
-#define ICP_NORMAL_RINGS 6       // search cap of the normals: 3 m
+#define ICP_FINE_RINGS 4         // fine-grid search radius: 1 m
+#define ICP_NORMAL_RINGS 6       // search cap of the normals: 3 m (coarse rings)
 #define ICP_MATCH_RINGS 8        // search cap of a correspondence: 4 m (the reference passes 1e3 m = everything)
 #define ICP_THREADS 256
 #define ICP_NACC 30              // 21 (J^T J upper) + 6 (J^T r) + sum d^2 + inliers + sum r^2
+
+struct IcpGrid {
+    uint32_t *cnt;               // [cells] points per cell (counting pass), all zero again after the fill pass
+    uint32_t *start;             // [cells + 1] first sorted position of the cell; start[cells] = points inside the grid
+    float4 *spts;                // [n_tgt] target points sorted by cell: x, y, z, original index (bits)
+};
 
 struct IcpArgs {
     const float *src;            // [n_src,4]
     const float *tgt;            // [n_tgt,4]
     int n_src, n_tgt;
-    uint32_t *cnt;               // [cells] points per cell (counting pass), all zero again after the fill pass
-    uint32_t *start;             // [cells + 1] first sorted position of the cell; start[cells] = points inside the grid
-    float4 *spts;                // [n_tgt] target points sorted by cell: x, y, z, original index (bits)
-    float *normal;               // [n_tgt,4]  nx, ny, nz, valid -- in SORTED order
+    IcpGrid g[2];                // [0] coarse, [1] fine
+    float *normal;               // [n_tgt,4]  nx, ny, nz, valid -- by ORIGINAL index
+    int32_t *nn_prev;            // [n_src] original index of the previous iteration's correspondence, -1 = none
     uint64_t *lb_state;          // decoupled look-back of the cell scan
     uint32_t *ticket;
     uint32_t epoch;
+    int scan_level;              // grid the scan kernel works on
     double *partial;             // [grid][ICP_NACC]
     double *state;               // [0..15] T (row-major), [16] fitness, [17] rmse, [18] prev fitness, [19] prev rmse,
                                  // [20] converged flag, [21] iterations done
@@ -51,26 +62,28 @@ struct IcpArgs {
     int grid;
 };
 
+template <int LV>
 __device__ __forceinline__ bool icp_cell_of(double x, double y, double z, int &cx, int &cy, int &cz)
 {
-    const double fx = floor((x - ICP_OX) / ICP_CELL), fy = floor((y - ICP_OY) / ICP_CELL), fz = floor((z - ICP_OZ) / ICP_CELL);
+    using G = IcpLevel<LV>;
+    const double fx = floor((x - G::ox) / G::cell), fy = floor((y - G::oy) / G::cell), fz = floor((z - G::oz) / G::cell);
     if (!(fx >= 0 && fx < ICP_NX && fy >= 0 && fy < ICP_NY && fz >= 0 && fz < ICP_NZ)) return false;
     cx = (int)fx; cy = (int)fy; cz = (int)fz;
     return true;
 }
 __device__ __forceinline__ int icp_cell_index(int cx, int cy, int cz) { return (cz * ICP_NY + cy) * ICP_NX + cx; }
 
-#define ICP_CELLS ((int64_t)ICP_NX * ICP_NY * ICP_NZ)
 #define ICP_SCAN_THREADS 1024
 #define ICP_SCAN_TILE (4 * ICP_SCAN_THREADS)
 
+template <int LV>
 __global__ __launch_bounds__(ICP_THREADS) void icp_grid_count(const IcpArgs a)
 {
     const int p = blockIdx.x * ICP_THREADS + threadIdx.x;
     if (p >= a.n_tgt) return;
     const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
     int cx, cy, cz;
-    if (icp_cell_of(v.x, v.y, v.z, cx, cy, cz)) atomicAdd(&a.cnt[icp_cell_index(cx, cy, cz)], 1u);   // else: never matched
+    if (icp_cell_of<LV>(v.x, v.y, v.z, cx, cy, cz)) atomicAdd(&a.g[LV].cnt[icp_cell_index(cx, cy, cz)], 1u);   // else: not in this grid
 }
 
 // exclusive scan of the per-cell counts (single pass, decoupled look-back; tiles handed out by ticket)
@@ -79,6 +92,7 @@ __global__ __launch_bounds__(ICP_SCAN_THREADS) void icp_cell_scan(const IcpArgs 
     __shared__ int s_tile;
     __shared__ uint32_t s_w[ICP_SCAN_THREADS / 64];
     __shared__ uint64_t s_excl;
+    const IcpGrid &g = a.g[a.scan_level];
     const int n_tiles = (int)(ICP_CELLS / ICP_SCAN_TILE);
     if (threadIdx.x == 0) {
         const uint32_t t = atomicAdd(a.ticket, 1u);
@@ -89,7 +103,7 @@ __global__ __launch_bounds__(ICP_SCAN_THREADS) void icp_cell_scan(const IcpArgs 
     const int tile = s_tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t base = (int64_t)tile * ICP_SCAN_TILE + threadIdx.x * 4;
-    const uint4 c = *reinterpret_cast<const uint4 *>(a.cnt + base);
+    const uint4 c = *reinterpret_cast<const uint4 *>(g.cnt + base);
     const uint32_t tsum = c.x + c.y + c.z + c.w;
     const uint32_t inc = wave_incl_scan_add(tsum);
     if (lane == 63) s_w[wave] = inc;
@@ -105,39 +119,58 @@ __global__ __launch_bounds__(ICP_SCAN_THREADS) void icp_cell_scan(const IcpArgs 
     __syncthreads();
     const uint32_t excl = (uint32_t)(s_excl >> 32), total = (uint32_t)s_excl;
     const uint32_t r0 = excl + s_w[wave] + (inc - tsum);
-    *reinterpret_cast<uint4 *>(a.start + base) = make_uint4(r0, r0 + c.x, r0 + c.x + c.y, r0 + c.x + c.y + c.z);
-    if (tile == n_tiles - 1 && threadIdx.x == ICP_SCAN_THREADS - 1) a.start[ICP_CELLS] = excl + total;
+    *reinterpret_cast<uint4 *>(g.start + base) = make_uint4(r0, r0 + c.x, r0 + c.x + c.y, r0 + c.x + c.y + c.z);
+    if (tile == n_tiles - 1 && threadIdx.x == ICP_SCAN_THREADS - 1) g.start[ICP_CELLS] = excl + total;
 }
 
+template <int LV>
 __global__ __launch_bounds__(ICP_THREADS) void icp_grid_fill(const IcpArgs a)
 {
     const int p = blockIdx.x * ICP_THREADS + threadIdx.x;
     if (p >= a.n_tgt) return;
     const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
     int cx, cy, cz;
-    if (!icp_cell_of(v.x, v.y, v.z, cx, cy, cz)) return;
+    if (!icp_cell_of<LV>(v.x, v.y, v.z, cx, cy, cz)) return;
+    const IcpGrid &g = a.g[LV];
     const int cell = icp_cell_index(cx, cy, cz);
-    const uint32_t pos = a.start[cell] + atomicSub(&a.cnt[cell], 1u) - 1u;     // fills the cell's range from the back
-    a.spts[pos] = make_float4(v.x, v.y, v.z, __int_as_float(p));
+    const uint32_t pos = g.start[cell] + atomicSub(&g.cnt[cell], 1u) - 1u;     // fills the cell's range from the back
+    g.spts[pos] = make_float4(v.x, v.y, v.z, __int_as_float(p));
 }
 
-// visits every target point (by sorted position) of the shell of Chebyshev radius r around cell (cx,cy,cz), skipping
-// the cells whose box lies farther from the query (qx,qy,qz) than bound() -- the caller's current search radius squared
-// (after the own cell has produced a candidate a few centimetres away, almost every neighbouring cell is culled)
-template <typename B, typename F>
-__device__ __forceinline__ void icp_visit_shell(const IcpArgs &a, int cx, int cy, int cz, int r, double qx, double qy,
+// the records [s0, e) of a range of cells, four loads in flight (a one-record-per-trip loop is a chain of memory latencies:
+// measured 1 ms per 120 k queries, independent of how much the search is culled)
+template <typename F>
+__device__ __forceinline__ void icp_scan_range(const float4 *spts, uint32_t s0, uint32_t e, F &&f)
+{
+    for (uint32_t q = s0; q < e; q += 4) {
+        const uint32_t last = e - 1;
+        const float4 w0 = spts[q], w1 = spts[q + 1 < e ? q + 1 : last], w2 = spts[q + 2 < e ? q + 2 : last],
+                     w3 = spts[q + 3 < e ? q + 3 : last];
+        f(w0);
+        if (q + 1 < e) f(w1);
+        if (q + 2 < e) f(w2);
+        if (q + 3 < e) f(w3);
+    }
+}
+
+// visits every target point (its sorted record) of the shell of Chebyshev radius r around cell (cx,cy,cz) of grid LV,
+// skipping the cells whose box lies farther from the query (qx,qy,qz) than bound() -- the caller's current search
+// radius squared (after the own cell has produced a candidate a few centimetres away, almost every neighbour is culled)
+template <int LV, typename B, typename F>
+__device__ __forceinline__ void icp_visit_shell(const IcpGrid &g, int cx, int cy, int cz, int r, double qx, double qy,
                                                 double qz, B &&bound, F &&f)
 {
+    using G = IcpLevel<LV>;
     for (int dz = -r; dz <= r; ++dz) {
         const int z = cz + dz;
         if (z < 0 || z >= ICP_NZ) continue;
-        const double z0 = ICP_OZ + z * ICP_CELL;
-        const double ez = qz < z0 ? z0 - qz : (qz > z0 + ICP_CELL ? qz - (z0 + ICP_CELL) : 0.0);
+        const double z0 = G::oz + z * G::cell;
+        const double ez = qz < z0 ? z0 - qz : (qz > z0 + G::cell ? qz - (z0 + G::cell) : 0.0);
         for (int dy = -r; dy <= r; ++dy) {
             const int y = cy + dy;
             if (y < 0 || y >= ICP_NY) continue;
-            const double y0 = ICP_OY + y * ICP_CELL;
-            const double ey = qy < y0 ? y0 - qy : (qy > y0 + ICP_CELL ? qy - (y0 + ICP_CELL) : 0.0);
+            const double y0 = G::oy + y * G::cell;
+            const double ey = qy < y0 ? y0 - qy : (qy > y0 + G::cell ? qy - (y0 + G::cell) : 0.0);
             const double eyz = ey * ey + ez * ez;
             if (eyz >= bound()) continue;
             const bool face = (dz == -r || dz == r || dy == -r || dy == r);
@@ -146,22 +179,35 @@ __device__ __forceinline__ void icp_visit_shell(const IcpArgs &a, int cx, int cy
                 const int x_lo = cx - r < 0 ? 0 : cx - r, x_hi = cx + r >= ICP_NX ? ICP_NX - 1 : cx + r;
                 if (x_lo > x_hi) continue;
                 const int c0 = icp_cell_index(x_lo, y, z);
-                const uint32_t e = a.start[c0 + (x_hi - x_lo) + 1];
-                for (uint32_t q = a.start[c0]; q < e; ++q) f((int)q);
+                icp_scan_range(g.spts, g.start[c0], g.start[c0 + (x_hi - x_lo) + 1], f);
             } else {                                        // interior rows: only the two end cells
                 for (int dx = -r; dx <= r; dx += 2 * r) {
                     const int x = cx + dx;
                     if (x < 0 || x >= ICP_NX) continue;
-                    const double x0 = ICP_OX + x * ICP_CELL;
-                    const double ex = qx < x0 ? x0 - qx : (qx > x0 + ICP_CELL ? qx - (x0 + ICP_CELL) : 0.0);
+                    const double x0 = G::ox + x * G::cell;
+                    const double ex = qx < x0 ? x0 - qx : (qx > x0 + G::cell ? qx - (x0 + G::cell) : 0.0);
                     if (ex * ex + eyz >= bound()) continue;
                     const int c0 = icp_cell_index(x, y, z);
-                    const uint32_t e = a.start[c0 + 1];
-                    for (uint32_t q = a.start[c0]; q < e; ++q) f((int)q);
+                    icp_scan_range(g.spts, g.start[c0], g.start[c0 + 1], f);
                 }
             }
         }
     }
+}
+
+// the fine grid can serve a query alone iff its whole search box (ICP_FINE_RINGS cells each way) lies inside the grid
+__device__ __forceinline__ bool icp_fine_box(double x, double y, double z, int &cx, int &cy, int &cz)
+{
+    if (!icp_cell_of<1>(x, y, z, cx, cy, cz)) return false;
+    return cx >= ICP_FINE_RINGS && cx < ICP_NX - ICP_FINE_RINGS && cy >= ICP_FINE_RINGS && cy < ICP_NY - ICP_FINE_RINGS &&
+           cz >= ICP_FINE_RINGS && cz < ICP_NZ - ICP_FINE_RINGS;
+}
+// was record w visited by the fine pass of a query whose fine cell is (cx,cy,cz)?
+__device__ __forceinline__ bool icp_in_fine_box(const float4 w, int cx, int cy, int cz)
+{
+    int wx, wy, wz;
+    if (!icp_cell_of<1>(w.x, w.y, w.z, wx, wy, wz)) return false;
+    return abs(wx - cx) <= ICP_FINE_RINGS && abs(wy - cy) <= ICP_FINE_RINGS && abs(wz - cz) <= ICP_FINE_RINGS;
 }
 
 // symmetric 3x3 eigen decomposition by cyclic Jacobi rotations; returns the eigenvector of the smallest eigenvalue
@@ -207,46 +253,65 @@ __device__ __forceinline__ void icp_smallest_eigvec(double A[3][3], double n[3])
 __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
 {
     __shared__ float s_d[ICP_K][ICP_THREADS];               // per thread: the K smallest squared distances, ascending
-    const int p = blockIdx.x * ICP_THREADS + threadIdx.x;         // sorted position
-    if (p >= (int)a.start[ICP_CELLS]) return;
-    const float4 v = a.spts[p];
+    const int p = blockIdx.x * ICP_THREADS + threadIdx.x;   // original index
+    if (p >= a.n_tgt) return;
+    const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
     float4 out = make_float4(0.f, 0.f, 1.f, 0.f);
-    int cx, cy, cz;
-    if (icp_cell_of(v.x, v.y, v.z, cx, cy, cz)) {
-        const int t = threadIdx.x;
-        int found = 0;
-        for (int r = 0; r <= ICP_NORMAL_RINGS; ++r) {
-            icp_visit_shell(a, cx, cy, cz, r, v.x, v.y, v.z,
-                            [&]() { return found == ICP_K ? (double)s_d[ICP_K - 1][t] * (1.0 + 1e-6) + 1e-12 : 1e300; },
-                            [&](int q) {
-                const float4 w = a.spts[q];
-                const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                if (found == ICP_K && d2 >= s_d[ICP_K - 1][t]) return;
-                int i = found < ICP_K ? found : ICP_K - 1;                      // insertion into the sorted list
-                while (i > 0 && s_d[i - 1][t] > d2) { s_d[i][t] = s_d[i - 1][t]; --i; }
-                s_d[i][t] = d2;
-                if (found < ICP_K) ++found;
-            });
-            // every unvisited point is farther than r cells: the list is final once its last entry is inside that
-            if (found == ICP_K && s_d[ICP_K - 1][t] <= (float)(r * ICP_CELL) * (float)(r * ICP_CELL)) break;
+    const int t = threadIdx.x;
+    int found = 0;
+    auto bound_k = [&]() { return found == ICP_K ? (double)s_d[ICP_K - 1][t] * (1.0 + 1e-6) + 1e-12 : 1e300; };
+    auto offer = [&](float d2) {                            // insertion into the sorted list of the K smallest
+        if (found == ICP_K && d2 >= s_d[ICP_K - 1][t]) return;
+        int i = found < ICP_K ? found : ICP_K - 1;
+        while (i > 0 && s_d[i - 1][t] > d2) { s_d[i][t] = s_d[i - 1][t]; --i; }
+        s_d[i][t] = d2;
+        if (found < ICP_K) ++found;
+    };
+    auto dist2 = [&](const float4 w) { const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z; return dx * dx + dy * dy + dz * dz; };
+    // pass A: the K-th smallest distance.  Fine grid first; every unvisited point is farther than r cells, so the list
+    // is final once its last entry lies inside that radius.
+    int fx, fy, fz, cx, cy, cz;
+    const bool fine = icp_fine_box(v.x, v.y, v.z, fx, fy, fz);
+    bool settled = false;
+    if (fine)
+        for (int r = 0; r <= ICP_FINE_RINGS && !settled; ++r) {
+            icp_visit_shell<1>(a.g[1], fx, fy, fz, r, v.x, v.y, v.z, bound_k, [&](const float4 w) { offer(dist2(w)); });
+            const float lim = (float)(r * IcpLevel<1>::cell);
+            settled = found == ICP_K && s_d[ICP_K - 1][t] <= lim * lim;
         }
-        if (found >= 3) {
-            const float lim = s_d[found - 1][t];
-            const int rmax = (int)ceil(sqrt((double)lim) / ICP_CELL);
-            double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-            int cnt = 0;
-            for (int r = 0; r <= rmax && r <= ICP_NORMAL_RINGS; ++r)
-                icp_visit_shell(a, cx, cy, cz, r, v.x, v.y, v.z, [&]() { return (double)lim * (1.0 + 1e-6) + 1e-12; },
-                                [&](int q) {
-                    const float4 w = a.spts[q];
-                    const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z;
-                    if (dx * dx + dy * dy + dz * dz > lim) return;
-                    const double x = dx, y = dy, z = dz;                        // relative to the query: well conditioned
-                    sx += x; sy += y; sz += z;
-                    sxx += x * x; sxy += x * y; sxz += x * z; syy += y * y; syz += y * z; szz += z * z;
-                    ++cnt;
-                });
+    const bool coarse = icp_cell_of<0>(v.x, v.y, v.z, cx, cy, cz);
+    if (!settled && coarse)
+        for (int r = 0; r <= ICP_NORMAL_RINGS && !settled; ++r) {
+            icp_visit_shell<0>(a.g[0], cx, cy, cz, r, v.x, v.y, v.z, bound_k, [&](const float4 w) {
+                if (fine && icp_in_fine_box(w, fx, fy, fz)) return;             // already offered by the fine pass
+                offer(dist2(w));
+            });
+            const float lim = (float)(r * IcpLevel<0>::cell);
+            settled = found == ICP_K && s_d[ICP_K - 1][t] <= lim * lim;
+        }
+    if (found >= 3) {
+        // pass B: covariance of every point within that distance (relative to the query: well conditioned)
+        const float lim = s_d[found - 1][t];
+        double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+        int cnt = 0;
+        auto bound_l = [&]() { return (double)lim * (1.0 + 1e-6) + 1e-12; };
+        auto add = [&](const float4 w) {
+            const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z;
+            if (dx * dx + dy * dy + dz * dz > lim) return;
+            const double x = dx, y = dy, z = dz;
+            sx += x; sy += y; sz += z;
+            sxx += x * x; sxy += x * y; sxz += x * z; syy += y * y; syz += y * z; szz += z * z;
+            ++cnt;
+        };
+        const float fine_reach = (float)(ICP_FINE_RINGS * IcpLevel<1>::cell);
+        if (fine && lim <= fine_reach * fine_reach) {                           // the whole ball lies in the fine box
+            const int rmax = (int)ceil(sqrt((double)lim) / IcpLevel<1>::cell);
+            for (int r = 0; r <= rmax && r <= ICP_FINE_RINGS; ++r) icp_visit_shell<1>(a.g[1], fx, fy, fz, r, v.x, v.y, v.z, bound_l, add);
+        } else if (coarse) {
+            const int rmax = (int)ceil(sqrt((double)lim) / IcpLevel<0>::cell);
+            for (int r = 0; r <= rmax && r <= ICP_NORMAL_RINGS; ++r) icp_visit_shell<0>(a.g[0], cx, cy, cz, r, v.x, v.y, v.z, bound_l, add);
+        }
+        if (cnt >= 3) {
             const double inv = 1.0 / cnt;
             const double mx = sx * inv, my = sy * inv, mz = sz * inv;
             double A[3][3];
@@ -275,23 +340,39 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_accumulate(const IcpArgs a)
         const double qx = T[0] * v.x + T[1] * v.y + T[2] * v.z + T[3];
         const double qy = T[4] * v.x + T[5] * v.y + T[6] * v.z + T[7];
         const double qz = T[8] * v.x + T[9] * v.y + T[10] * v.z + T[11];
-        int cx, cy, cz;
-        if (!icp_cell_of(qx, qy, qz, cx, cy, cz)) continue;
         double best = a.max_dist2;
-        int bi = -1;
-        for (int r = 0; r <= ICP_MATCH_RINGS; ++r) {
-            icp_visit_shell(a, cx, cy, cz, r, qx, qy, qz, [&]() { return best * (1.0 + 1e-12) + 1e-300; }, [&](int q) {
-                const float4 w = a.spts[q];
-                const double dx = w.x - qx, dy = w.y - qy, dz = w.z - qz;
-                const double d2 = dx * dx + dy * dy + dz * dz;
-                // ties: lowest ORIGINAL index (the order inside a cell varies from run to run)
-                if (d2 < best || (d2 == best && bi >= 0 && __float_as_int(w.w) < __float_as_int(a.spts[bi].w))) { best = d2; bi = q; }
-            });
-            if (bi >= 0 && best <= (r * ICP_CELL) * (r * ICP_CELL)) break;
+        float4 bw = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool have = false;
+        auto bound = [&]() { return best * (1.0 + 1e-12) + 1e-300; };
+        auto offer = [&](const float4 w) {
+            const double dx = w.x - qx, dy = w.y - qy, dz = w.z - qz;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            // ties: lowest ORIGINAL index (the order inside a cell varies from run to run)
+            if (d2 < best || (d2 == best && have && __float_as_int(w.w) < __float_as_int(bw.w))) { best = d2; bw = w; have = true; }
+        };
+        // warm start: the previous iteration's partner bounds the search from the first cell on (the transform moved
+        // by a fraction of a cell), so nearly every cell is culled; the result is still the exact nearest neighbour
+        const int prev = a.nn_prev[p];
+        if (prev >= 0) {
+            const float4 t = reinterpret_cast<const float4 *>(a.tgt)[prev];
+            offer(make_float4(t.x, t.y, t.z, __int_as_float(prev)));
         }
-        if (bi < 0) continue;
-        const float4 w = a.spts[bi];
-        const float4 nn = reinterpret_cast<const float4 *>(a.normal)[bi];
+        int fx, fy, fz, cx, cy, cz;
+        bool settled = false;
+        if (icp_fine_box(qx, qy, qz, fx, fy, fz))
+            for (int r = 0; r <= ICP_FINE_RINGS && !settled; ++r) {
+                icp_visit_shell<1>(a.g[1], fx, fy, fz, r, qx, qy, qz, bound, offer);
+                settled = have && best <= (r * IcpLevel<1>::cell) * (r * IcpLevel<1>::cell);
+            }
+        if (!settled && icp_cell_of<0>(qx, qy, qz, cx, cy, cz))
+            for (int r = 0; r <= ICP_MATCH_RINGS && !settled; ++r) {
+                icp_visit_shell<0>(a.g[0], cx, cy, cz, r, qx, qy, qz, bound, offer);      // re-offering a point is harmless
+                settled = have && best <= (r * IcpLevel<0>::cell) * (r * IcpLevel<0>::cell);
+            }
+        a.nn_prev[p] = have ? __float_as_int(bw.w) : -1;
+        if (!have) continue;
+        const float4 w = bw;
+        const float4 nn = reinterpret_cast<const float4 *>(a.normal)[__float_as_int(w.w)];
         acc[27] += best;                                    // Open3D: fitness / rmse over all correspondences
         acc[28] += 1.0;
         if (nn.w == 0.f) continue;                          // no normal: the pair carries no point-to-plane row
@@ -383,8 +464,9 @@ static inline int icp_grid(int n) { const int g = (n + ICP_THREADS - 1) / ICP_TH
 int64_t pca_icp_workspace_bytes(int32_t max_points)
 {
     if (max_points < 1) max_points = 1;
-    return icp_align(ICP_CELLS * 4) + icp_align((ICP_CELLS + 1) * 4) + 2 * icp_align((int64_t)max_points * 16) +
-           icp_align((int64_t)1024 * ICP_NACC * 8) + icp_align(32 * 8) + 512;
+    return 2 * (icp_align(ICP_CELLS * 4) + icp_align((ICP_CELLS + 1) * 4) + icp_align((int64_t)max_points * 16)) +
+           icp_align((int64_t)max_points * 16) + icp_align((int64_t)max_points * 4) + icp_align((int64_t)1024 * ICP_NACC * 8) +
+           icp_align(32 * 8) + 512;
 }
 
 int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const float *tgt_pts, int32_t n_tgt,
@@ -394,7 +476,7 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
 {
     if (!ctx) return -1;
     if (!src_pts || !tgt_pts || n_src < 1 || n_tgt < 1 || !workspace || !T_out) { ctx->err = "icp: bad arguments"; return -1; }
-    if (workspace_bytes < pca_icp_workspace_bytes(n_tgt)) { ctx->err = "icp: workspace too small"; return -1; }
+    if (workspace_bytes < pca_icp_workspace_bytes(n_tgt > n_src ? n_tgt : n_src)) { ctx->err = "icp: workspace too small"; return -1; }
     if (max_iter < 1) max_iter = 30;
     hipStream_t s = (hipStream_t)stream;
     PCA_CHECK(ctx, hipSetDevice(ctx->device));
@@ -402,10 +484,13 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
     a.src = src_pts; a.tgt = tgt_pts; a.n_src = n_src; a.n_tgt = n_tgt;
     char *w = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     const int64_t cells = (int64_t)ICP_NX * ICP_NY * ICP_NZ;
-    a.cnt = reinterpret_cast<uint32_t *>(w); w += icp_align(cells * 4);
-    a.start = reinterpret_cast<uint32_t *>(w); w += icp_align((cells + 1) * 4);
-    a.spts = reinterpret_cast<float4 *>(w); w += icp_align((int64_t)n_tgt * 16);
+    for (int lv = 0; lv < 2; ++lv) {
+        a.g[lv].cnt = reinterpret_cast<uint32_t *>(w); w += icp_align(cells * 4);
+        a.g[lv].start = reinterpret_cast<uint32_t *>(w); w += icp_align((cells + 1) * 4);
+        a.g[lv].spts = reinterpret_cast<float4 *>(w); w += icp_align((int64_t)n_tgt * 16);
+    }
     a.normal = reinterpret_cast<float *>(w); w += icp_align((int64_t)n_tgt * 16);
+    a.nn_prev = reinterpret_cast<int32_t *>(w); w += icp_align((int64_t)n_src * 4);
     a.partial = reinterpret_cast<double *>(w); w += icp_align((int64_t)1024 * ICP_NACC * 8);
     a.state = reinterpret_cast<double *>(w);
     a.max_dist2 = max_corr_dist * max_corr_dist;
@@ -414,17 +499,24 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
     double st[32] = {0};
     static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     for (int i = 0; i < 16; ++i) st[i] = init ? init[i] : eye[i];
-    PCA_CHECK(ctx, hipMemsetAsync(a.cnt, 0, (size_t)cells * 4, s));
+    PCA_CHECK(ctx, hipMemsetAsync(a.g[0].cnt, 0, (size_t)cells * 4, s));
+    PCA_CHECK(ctx, hipMemsetAsync(a.g[1].cnt, 0, (size_t)cells * 4, s));
+    PCA_CHECK(ctx, hipMemsetAsync(a.nn_prev, 0xff, (size_t)n_src * 4, s));
     PCA_CHECK(ctx, hipMemcpyAsync(a.state, st, sizeof st, hipMemcpyHostToDevice, s));
     const int scan_tiles = (int)(cells / ICP_SCAN_TILE);
     if (pca_ctx_reserve_tiles(ctx, scan_tiles, s)) return -1;
     a.lb_state = ctx->tile_state;
     a.ticket = ctx->ticket;
-    a.epoch = pca_ctx_next_epoch(ctx, s);
     const dim3 per_point((n_tgt + ICP_THREADS - 1) / ICP_THREADS);
-    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_count, per_point, dim3(ICP_THREADS), s, a);
-    PCA_LAUNCH(ctx, PCA_K_ICP, icp_cell_scan, dim3(scan_tiles), dim3(ICP_SCAN_THREADS), s, a);
-    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_fill, per_point, dim3(ICP_THREADS), s, a);
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_count<0>, per_point, dim3(ICP_THREADS), s, a);
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_count<1>, per_point, dim3(ICP_THREADS), s, a);
+    for (int lv = 0; lv < 2; ++lv) {
+        a.scan_level = lv;
+        a.epoch = pca_ctx_next_epoch(ctx, s);
+        PCA_LAUNCH(ctx, PCA_K_ICP, icp_cell_scan, dim3(scan_tiles), dim3(ICP_SCAN_THREADS), s, a);
+    }
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_fill<0>, per_point, dim3(ICP_THREADS), s, a);
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_fill<1>, per_point, dim3(ICP_THREADS), s, a);
     PCA_LAUNCH(ctx, PCA_K_ICP, icp_normals, dim3((n_tgt + ICP_THREADS - 1) / ICP_THREADS), dim3(ICP_THREADS), s, a);
     // one more evaluation than updates: Open3D reports fitness / rmse of the final transform
     for (int it = 0; it <= max_iter; ++it) {

@@ -55,7 +55,7 @@ class GpuIcp:
         import torch
         ctx = _lib.Context.get()
         lib = ctx.lib
-        need = lib.pca_icp_workspace_bytes(int(target.shape[0]))
+        need = lib.pca_icp_workspace_bytes(int(max(source.shape[0], target.shape[0])))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(int(need) + 256, dtype=torch.uint8, device=target.device)
         T = (C.c_double * 16)()
