@@ -8,12 +8,13 @@
 // Open3D is third-party and unpinned (README.md:14): PARITY IS UNPINNED.  The tests check known motions and a CPU model
 // of this same algorithm (exact k-d tree neighbours), not Open3D.
 //
-//   icp_grid_count / icp_cell_scan / icp_grid_fill   uniform grid (0.5 m cells, 256 m x 256 m x 32 m around the
-//                     sensor): counting sort of the target points by cell -- a cell's points are contiguous, so a
-//                     neighbour search streams them instead of chasing a linked list
+//   icp_grid_count / icp_cell_scan / icp_grid_fill   two uniform grids around the sensor (0.5 m and 0.25 m cells):
+//                     counting sort of the target points by cell -- a cell's points are contiguous, a row of cells is
+//                     one range, and a neighbour search streams them (four loads in flight)
 //   icp_normals       per target point: the K = 30 nearest neighbours (shell-by-shell grid search, exact within the
 //                     search cap), covariance, eigenvector of the smallest eigenvalue (cyclic Jacobi, f64)
-//   icp_accumulate    per source point: q = T p, nearest target point (exact within the cap), r = (q - t).n,
+//   icp_accumulate    per source point: q = T p, nearest target point (exact within the cap; the previous iteration's
+//                     partner bounds the search from the start), r = (q - t).n,
 //                     J = [q x n, n]; per-workgroup partial sums of J^T J, J^T r, |q - t|^2, inlier count
 //   icp_solve         one workgroup: fixed-order reduction of the partials (deterministic), 6x6 Cholesky solve,
 //                     T <- exp(x) T, fitness / rmse, convergence flag -- the iteration loop never leaves the device
