@@ -30,7 +30,35 @@ def counters(dirname, counter):
     return per
 
 
+def all_counters(dirname):
+    per = defaultdict(lambda: defaultdict(list))
+    for path in glob.glob(os.path.join(dirname, '**', '*counter_collection.csv'), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                per[short(row['Kernel_Name'])][row['Counter_Name']].append(float(row['Counter_Value']))
+    return per
+
+
+def main_sq(out, tag):
+    res = {}
+    for d in ('sq1', 'sq2'):
+        for k, counters in all_counters(os.path.join(out, d)).items():
+            if not (k.startswith('bev_') or k.startswith('k1_') or k.startswith('k2_')):
+                continue
+            for name, v in counters.items():
+                tail = v[len(v) // 2:]
+                res.setdefault(k, {})[name] = round(sum(tail) / len(tail))
+    json.dump({'note': 'rocprofv3 --pmc SQ_* (two passes, --kernel-trace only), per launch, bench.py steady state',
+               'kernels': res}, open(os.path.join(out, f'{tag}_pmc_sq_per_kernel_avg.json'), 'w'), indent=1)
+    for k, c in res.items():
+        if 'SQ_WAVE_CYCLES' in c and 'SQ_ACTIVE_INST_ANY' in c:
+            print(k, 'issue share of wave cycles: %.2f' % (c['SQ_ACTIVE_INST_ANY'] / c['SQ_WAVE_CYCLES']),
+                  'VALU insts per wave: %.0f' % (c.get('SQ_INSTS_VALU', 0) / max(c.get('SQ_WAVES', 1), 1)))
+
+
 def main():
+    if sys.argv[1] == '--sq':
+        return main_sq(sys.argv[2], sys.argv[3])
     out, tag = sys.argv[1], sys.argv[2]
     stats = glob.glob(os.path.join(out, 'stats', '**', '*kernel_stats.csv'), recursive=True)
     if stats:
