@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_fp16.h>
 #include "../../include/pca.h"
 #include "pca_wave.h"
 
@@ -81,8 +82,19 @@ __device__ __forceinline__ double row4(const double *r, double x, double y, doub
     return a;
 }
 
-// f64 -> f16 bits, round-to-nearest-even straight from the double (numpy astype(np.float16))
+// f64 -> f16 bits, round-to-nearest-even straight from the double (numpy astype(np.float16)).
+// Shipped form: f64 -> f32 with round-to-ODD (truncate, then set the last bit if anything was lost: the sticky bit
+// survives), then the hardware's f32 -> f16 round-to-nearest-even.  Rounding to odd into a format with more than
+// 2*11+2 significant bits makes the second rounding see exactly what a direct rounding would; checked bit for bit
+// against the integer routine below on 16.7 M values incl. halfway cases and subnormals (tools/experiments/f16_cvt.hip).
+__device__ __forceinline__ uint16_t f64_to_f16_bits_reference(double d);
 __device__ __forceinline__ uint16_t f64_to_f16_bits(double d)
+{
+    float t = __double2float_rz(d);
+    if ((double)t != d) t = __uint_as_float(__float_as_uint(t) | 1u);
+    return __half_as_ushort(__float2half_rn(t));
+}
+__device__ __forceinline__ uint16_t f64_to_f16_bits_reference(double d)
 {
     uint64_t b = (uint64_t)__double_as_longlong(d);
     uint16_t sign = (uint16_t)((b >> 48) & 0x8000u);
