@@ -51,6 +51,7 @@ typedef struct {
 #define PCA_STATUS_STORE_OVERFLOW 1u /* a kernel wanted to write past store.capacity (points dropped)     */
 #define PCA_STATUS_UV_OUT_OF_IMAGE 2u /* NuScenes: pixel coords outside (1, wh-1): reference AssertionError */
 #define PCA_STATUS_NEGATIVE_INTENSITY 4u /* BEV: a negative f32 intensity (pass intensity64 for such data)   */
+#define PCA_STATUS_LOOKBACK_TIMEOUT 8u /* a compaction workgroup gave up waiting for a predecessor (output invalid) */
 
 int pca_version(void);
 int pca_ctx_create(int device, pca_ctx **out);
@@ -75,11 +76,8 @@ typedef struct {
     const uint8_t *sem;    /* dev [H,W]   u8 class map, or NULL with sem_gt                    */
     const uint8_t *sem_gt; /* dev [n] u8 per-point class, or NULL                              */
     int32_t n;             /* points in this frame                                             */
-    int32_t tile0;         /* index of the frame's first tile in the launch: sum of pca_kitti_tiles(n_j), j<k */
+    int32_t reserved;      /* ignored                                                          */
 } pca_kitti_frame;
-
-int pca_kitti_tile_points(void);            /* points per tile (launch granularity)             */
-int pca_kitti_tiles(int32_t n);             /* tiles a frame of n points occupies (>= 1)        */
 
 /* frames: HOST array of n_frames descriptors (copied into the launch).  P: 3x4 row-major f64
  * (P_velo_frame).  filter_mask: 256-bit class set.  frame_off[first_slot] must hold the append position;

@@ -1,6 +1,6 @@
-// pca_accum.hip -- per-frame "integrate" kernels for gfx950 (MI355X):
-//   K1  kitti_project_sample_filter      K1n nusc_sample_filter_transform    K0n nusc_project_cams
-//   K2  retransform                      K3  mark_dynamic
+// pca_accum.hip -- per-frame "integrate" kernels for gfx950 (MI355X)  (K1 lives in pca_k1.hip):
+//   K1n nusc_sample_filter_transform    K0n nusc_project_cams
+//   K2  retransform                      K3  mark_dynamic                  voxel de-duplication
 // All are HBM-bound streaming kernels (no MFMA: the only contractions are 3x4 / 4x4 per point).
 #include "pca_common.h"
 #include <cstdlib>
@@ -9,7 +9,7 @@
 // (= the distance the decoupled look-back has to walk when all workgroups run in lock step) small and
 // amortise ticket / look-back / barrier costs over more points.
 #define PPT 4              // points per thread; point (k, t) of a tile is tile*TILE + k*BLK + t
-#define K1_DEFAULT_BLK 512 // threads per compaction workgroup (tile = 4 * BLK points); PCA_K1_BLK overrides (tuning)
+#define CBLK 512           // threads per compaction workgroup (tile = 4 * CBLK points)
 #define SBLK 256           // workgroup size of the plain streaming kernels (K0n, K2, K3)
 
 // loads through the global address space (pointers that arrive inside structs are generic to the compiler)
@@ -43,7 +43,7 @@ struct TileScan {
 
 template <int BLK>
 __device__ __forceinline__ TileScan tile_compact(const bool keep[PPT], uint64_t *state, int tile, uint32_t epoch,
-                                                 bool skip_lookback = false)
+                                                 uint32_t *status)
 {
     constexpr int NW = BLK / PCA_WAVE;
     static_assert(PPT * NW <= 64, "the per-(row, wave) totals are scanned by one wave");
@@ -65,7 +65,7 @@ __device__ __forceinline__ TileScan tile_compact(const bool keep[PPT], uint64_t 
         if (lane < PPT * NW) s_woff[lane] = inc - v;
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         if (lane == 0) s_woff[PPT * NW] = total;
-        const uint64_t e = skip_lookback ? 0 : lb_exclusive_prefix(state, tile, (uint64_t)total, epoch);
+        const uint64_t e = lb_exclusive_prefix(state, tile, (uint64_t)total, epoch, status);
         if (lane == 0) s_excl = e;
     }
     __syncthreads();
@@ -86,332 +86,6 @@ __device__ __forceinline__ int draw_tile(uint32_t *ticket, int total_tiles)
     }
     __syncthreads();
     return s_tile;
-}
-
-// =============================================================================================
-// K1  KITTI-360: project + frustum mask + nearest sample + class filter + stable append
-// =============================================================================================
-struct K1Args {
-    const pca_kitti_frame *frames;   // dev array, or nullptr -> `one`
-    pca_kitti_frame one;
-    int n_frames, total_tiles;
-    Mat34 P;
-    int H, W;
-    ClassMask filt;
-    pca_store st;
-    int64_t *frame_off;
-    int first_slot;
-    uint64_t *state;
-    uint32_t *ticket;   // [0] ticket, [1] status
-    uint32_t epoch;
-    unsigned long long *ticket64;      // monotonic ticket counter of the persistent kernel
-    unsigned long long ticket_base;    // its value when this launch starts
-    int one_tile_each;                 // grid == total_tiles: no second draw needed
-    unsigned long long *dbg;   // diagnostic stamps (PCA_K1_STAMPS=1), else nullptr
-    int dbg_skip;              // diagnostic ablation (PCA_K1_SKIP bits: 1 look-back, 2 gathers, 4 stores); results invalid
-};
-
-#define K1_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-
-// velo2frame + velo2img of one point: pixel index v*W+u, or -1 if outside the frustum (sem_pc_accum.py:347-394)
-__device__ __forceinline__ int project_pixel(const Mat34 &P, float xf, float yf, float zf, int W, int H)
-{
-    const double x = (double)xf, y = (double)yf, z = (double)zf;
-    const double fx = row4(P.m + 0, x, y, z);
-    const double fy = row4(P.m + 4, x, y, z);
-    double d = row4(P.m + 8, x, y, z);
-    if (d == 0.0) d = -1e-6;
-    const double ad = fabs(d);
-    const double uf = rint(fx / ad);
-    const double vf = rint(fy / ad);
-    const bool ok = (uf >= 0.0) && (uf < (double)W) && (vf >= 0.0) && (vf < (double)H) && (d > 0.0) && (d < __builtin_huge_val());
-    return ok ? (int)vf * W + (int)uf : -1;
-}
-
-template <int BLK>
-__global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a)
-{
-    constexpr int TILE_PTS = PPT * BLK;
-    K1_STAMP(0);
-    const int tile = draw_tile(a.ticket, a.total_tiles);
-    K1_STAMP(1);
-    // frame of this tile: one lane-parallel probe per 64 frames (tile0 is ascending), a single memory round trip
-    // instead of a chain of dependent binary-search loads
-    int f = 0;
-    pca_kitti_frame fr = a.one;
-    if (a.frames) {
-        const int lane = threadIdx.x & 63;
-        int below = 0;
-        for (int f0 = 0; f0 < a.n_frames; f0 += 64) {
-            const bool le = (f0 + lane < a.n_frames) && (ldg(&a.frames[f0 + lane].tile0) <= tile);
-            const int c = (int)__popcll(__ballot(le));
-            below += c;
-            if (c < 64) break;
-        }
-        f = below - 1;
-        fr = a.frames[f];
-    }
-    const int tin = tile - fr.tile0;                       // tile index inside the frame
-    const int ftiles = fr.n > 0 ? (fr.n + TILE_PTS - 1) / TILE_PTS : 1;
-    const int64_t base_pt = (int64_t)tin * TILE_PTS;
-
-    bool keep[PPT];
-    float4 q[PPT];
-    uint32_t packed[PPT];
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int64_t p = base_pt + k * BLK + threadIdx.x;
-        keep[k] = false;
-        packed[k] = 0;
-        q[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < fr.n) q[k] = ldg4(fr.pts + 4 * p);         // 16 B / lane, fully coalesced
-    }
-    K1_STAMP(2);
-    if (fr.n > 0 && fr.sem_gt) {                           // use_gt_sem: no projection, rgb = 0
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int64_t p = base_pt + k * BLK + threadIdx.x;
-            if (p >= fr.n) continue;
-            const unsigned c = ldg(fr.sem_gt + p);
-            keep[k] = !in_mask(a.filt, c);
-            packed[k] = (uint32_t)c << 24;
-        }
-    } else if (fr.n > 0) {
-        // straight-line, predicated: all projections, then all gathers (independent loads in flight), then the filter
-        bool ok[PPT];
-        int64_t pix[PPT];
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int64_t p = base_pt + k * BLK + threadIdx.x;
-            const int px = project_pixel(a.P, q[k].x, q[k].y, q[k].z, a.W, a.H);
-            ok[k] = (p < fr.n) && px >= 0;
-            pix[k] = ok[k] ? px : 0;                                     // pixel 0 is always a valid address
-        }
-        // two gathers per point: the class byte and ONE unaligned dword holding r,g,b (address-divergent loads
-        // cost the texture addresser a pass per distinct line, so their number matters more than their bytes)
-        unsigned c[PPT], rgb[PPT];
-        const int64_t last = (int64_t)a.H * a.W * 3 - 4;   // last legal 4-byte window of the image
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            c[k] = ldg(fr.sem + pix[k]);
-            int64_t off = pix[k] * 3;
-            if (last >= 0) {
-                const int sh = off > last ? (int)(off - last) * 8 : 0;
-                off = off > last ? last : off;
-                rgb[k] = (ldg_u32_unaligned(fr.rgb + off) >> sh) & 0xffffffu;
-            } else {                                        // image smaller than four bytes
-                rgb[k] = (uint32_t)ldg(fr.rgb + off) | ((uint32_t)ldg(fr.rgb + off + 1) << 8) | ((uint32_t)ldg(fr.rgb + off + 2) << 16);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            keep[k] = ok[k] && !in_mask(a.filt, c[k]);
-            packed[k] = rgb[k] | (c[k] << 24);
-        }
-    }
-
-    K1_STAMP(3);
-    const TileScan sc = tile_compact<BLK>(keep, a.state, tile, a.epoch, a.dbg_skip & 1);
-    K1_STAMP(4);
-    const int64_t origin = a.frame_off[a.first_slot];      // written by an earlier launch (stream order)
-    const int64_t tile_base = origin + (int64_t)sc.excl;
-    bool overflow = false;
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        if (!keep[k] || (a.dbg_skip & 4)) continue;
-        const int64_t o = tile_base + sc.local[k];
-        if (o >= a.st.capacity) { overflow = true; continue; }
-        a.st.x[o] = (double)q[k].x;
-        a.st.y[o] = (double)q[k].y;
-        a.st.z[o] = (double)q[k].z;
-        a.st.intensity[o] = q[k].w;
-        a.st.rgbs[o] = packed[k];
-        a.st.inst[o] = 0;
-        a.st.dyn[o] = 0;
-        __builtin_amdgcn_sched_barrier(0);                 // one point's 7 store addresses at a time (registers)
-    }
-    if (overflow) atomicOr(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
-    if (threadIdx.x == 0 && tin == ftiles - 1)             // last tile of the frame closes its segment
-        a.frame_off[a.first_slot + f + 1] = tile_base + sc.total;
-    K1_STAMP(5);
-    if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)tile;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Persistent, software-pipelined form of K1 (batched launches).  A workgroup loops over tiles handed out by a
-// monotonic ticket.  Per iteration:
-//   A  draw tile i+1, load / project / gather / filter, block scan, PUBLISH its aggregate;
-//   B  finish tile i: decoupled look-back (its predecessors have had a whole tile-time to publish, so the walk is
-//      short and its latency sits behind stage A instead of in front of the stores), append its records;
-//   C  park tile i+1's records in LDS as the new pending tile.
-// Every aggregate is published before the workgroup ever waits, and a wait only concerns tiles whose tickets were
-// drawn earlier, so progress never depends on dispatch order or residency.
-// ---------------------------------------------------------------------------------------------
-template <int BLK>
-__global__ __launch_bounds__(BLK) void k1_kitti_persistent(const K1Args a)
-{
-    constexpr int TILE_PTS = PPT * BLK;
-    constexpr int NW = BLK / PCA_WAVE;
-    __shared__ float4 s_q[TILE_PTS];           // pending tile: x, y, z, intensity of every point
-    __shared__ uint32_t s_packed[TILE_PTS];    // rgb | class<<24
-    __shared__ uint32_t s_rank[TILE_PTS];      // rank among the tile's kept points, 0xffffffff = dropped
-    __shared__ uint32_t s_wtot[PPT * NW];
-    __shared__ uint32_t s_woff[PPT * NW + 1];
-    __shared__ long long s_bcast[2];           // [0] ticket / tile of stage A, [1] exclusive prefix of stage B
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t origin = a.frame_off[a.first_slot];
-    bool have_pending = false;
-    int p_tile = 0, p_f = 0, p_last = 0;
-    uint32_t p_total = 0;
-    bool first = true;
-
-    for (;;) {
-        // ---------------- stage A: next tile ----------------
-        bool have_cur = false;
-        int tile = 0, f = 0, tin = 0, ftiles = 1;
-        if (first || !a.one_tile_each) {
-            if (threadIdx.x == 0)
-                s_bcast[0] = (long long)(atomicAdd(a.ticket64, 1ull) - a.ticket_base);
-            __syncthreads();
-            const long long t = s_bcast[0];
-            have_cur = t < (long long)a.total_tiles;
-            tile = (int)t;
-        }
-        first = false;
-        bool keep[PPT];
-        float4 q[PPT];
-        uint32_t packed[PPT], rank[PPT];
-        uint32_t total = 0;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) { keep[k] = false; packed[k] = 0; rank[k] = 0; q[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        if (have_cur) {
-            pca_kitti_frame fr = a.one;
-            if (a.frames) {
-                int below = 0;
-                for (int f0 = 0; f0 < a.n_frames; f0 += 64) {
-                    const bool le = (f0 + lane < a.n_frames) && (ldg(&a.frames[f0 + lane].tile0) <= tile);
-                    const int c = (int)__popcll(__ballot(le));
-                    below += c;
-                    if (c < 64) break;
-                }
-                f = below - 1;
-                fr = a.frames[f];
-            }
-            tin = tile - fr.tile0;
-            ftiles = fr.n > 0 ? (fr.n + TILE_PTS - 1) / TILE_PTS : 1;
-            const int64_t base_pt = (int64_t)tin * TILE_PTS;
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int64_t p = base_pt + k * BLK + threadIdx.x;
-                if (p < fr.n) q[k] = ldg4(fr.pts + 4 * p);
-            }
-            if (fr.n > 0 && fr.sem_gt) {
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) {
-                    const int64_t p = base_pt + k * BLK + threadIdx.x;
-                    if (p >= fr.n) continue;
-                    const unsigned c = ldg(fr.sem_gt + p);
-                    keep[k] = !in_mask(a.filt, c);
-                    packed[k] = (uint32_t)c << 24;
-                }
-            } else if (fr.n > 0) {
-                bool ok[PPT];
-                int64_t pix[PPT];
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) {
-                    const int64_t p = base_pt + k * BLK + threadIdx.x;
-                    const int px = project_pixel(a.P, q[k].x, q[k].y, q[k].z, a.W, a.H);
-                    ok[k] = (p < fr.n) && px >= 0;
-                    pix[k] = ok[k] ? px : 0;
-                }
-                unsigned c[PPT], rgb[PPT];
-                const int64_t last = (int64_t)a.H * a.W * 3 - 4;
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) {
-                    c[k] = ldg(fr.sem + pix[k]);
-                    int64_t off = pix[k] * 3;
-                    if (last >= 0) {
-                        const int sh = off > last ? (int)(off - last) * 8 : 0;
-                        off = off > last ? last : off;
-                        rgb[k] = (ldg_u32_unaligned(fr.rgb + off) >> sh) & 0xffffffu;
-                    } else {
-                        rgb[k] = (uint32_t)ldg(fr.rgb + off) | ((uint32_t)ldg(fr.rgb + off + 1) << 8) | ((uint32_t)ldg(fr.rgb + off + 2) << 16);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) {
-                    keep[k] = ok[k] && !in_mask(a.filt, c[k]);
-                    packed[k] = rgb[k] | (c[k] << 24);
-                }
-            }
-            // block scan of the keep flags (point order: row k, then thread)
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const uint64_t b = __ballot(keep[k]);
-                rank[k] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-                if (lane == 0) s_wtot[k * NW + wave] = (uint32_t)__popcll(b);
-            }
-            __syncthreads();
-            if (wave == 0) {
-                const uint32_t v = lane < PPT * NW ? s_wtot[lane] : 0u;
-                const uint32_t inc = wave_incl_scan_add(v);
-                if (lane < PPT * NW) s_woff[lane] = inc - v;
-                if (lane == 63) {
-                    s_woff[PPT * NW] = inc;
-                    lb_publish_aggregate(a.state, tile, (uint64_t)inc, a.epoch);      // before any waiting
-                }
-            }
-            __syncthreads();
-            total = s_woff[PPT * NW];
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) rank[k] = keep[k] ? rank[k] + s_woff[k * NW + wave] : 0xffffffffu;
-        }
-
-        // ---------------- stage B: finish the pending tile ----------------
-        if (have_pending) {
-            if (wave == 0) {
-                const uint64_t e = lb_walk(a.state, p_tile, (uint64_t)p_total, a.epoch);
-                if (lane == 0) s_bcast[1] = (long long)e;
-            }
-            __syncthreads();
-            const int64_t tile_base = origin + s_bcast[1];
-            bool overflow = false;
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int i = k * BLK + threadIdx.x;
-                const uint32_t r = s_rank[i];
-                if (r == 0xffffffffu) continue;
-                const int64_t o = tile_base + r;
-                if (o >= a.st.capacity) { overflow = true; continue; }
-                const float4 v = s_q[i];
-                a.st.x[o] = (double)v.x;
-                a.st.y[o] = (double)v.y;
-                a.st.z[o] = (double)v.z;
-                a.st.intensity[o] = v.w;
-                a.st.rgbs[o] = s_packed[i];
-                a.st.inst[o] = 0;
-                a.st.dyn[o] = 0;
-            }
-            if (overflow) atomicOr(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
-            if (threadIdx.x == 0 && p_last) a.frame_off[a.first_slot + p_f + 1] = tile_base + p_total;
-            __syncthreads();                                 // pending LDS consumed
-        }
-
-        // ---------------- stage C: the current tile becomes the pending one ----------------
-        if (have_cur) {
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int i = k * BLK + threadIdx.x;
-                s_q[i] = q[k];
-                s_packed[i] = packed[k];
-                s_rank[i] = rank[k];
-            }
-            p_tile = tile; p_f = f; p_last = (tin == ftiles - 1); p_total = total;
-        }
-        have_pending = have_cur;
-        if (!have_cur) break;
-        __syncthreads();
-    }
 }
 
 // =============================================================================================
@@ -463,7 +137,7 @@ __global__ __launch_bounds__(BLK) void k1n_nusc(const K1nArgs a)
     }
     if (bad_uv) atomicOr(a.ticket + 1, PCA_STATUS_UV_OUT_OF_IMAGE);
 
-    const TileScan sc = tile_compact<BLK>(keep, a.state, tile, a.epoch);
+    const TileScan sc = tile_compact<BLK>(keep, a.state, tile, a.epoch, a.ticket + 1);
     const int64_t tile_base = a.frame_off[a.slot] + (int64_t)sc.excl;
     bool overflow = false;
 #pragma unroll
@@ -701,7 +375,7 @@ __global__ __launch_bounds__(BLK) void dedup_compact(const DedupArgs a)
     }
     // every load of this workgroup has returned before its aggregate becomes visible (see the header)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const TileScan sc = tile_compact<BLK>(keep, a.state, tile, a.epoch);
+    const TileScan sc = tile_compact<BLK>(keep, a.state, tile, a.epoch, a.ticket + 1);
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         s_rank[k * BLK + threadIdx.x] = sc.local[k];
@@ -748,101 +422,6 @@ __global__ __launch_bounds__(SBLK) void dedup_offsets(const DedupArgs a)
 // =============================================================================================
 extern "C" {
 
-static int k1_blk()
-{
-    static int blk = 0;
-    if (!blk) {
-        const char *e = getenv("PCA_K1_BLK");
-        const int v = e ? atoi(e) : K1_DEFAULT_BLK;
-        blk = (v == 256 || v == 512 || v == 1024) ? v : K1_DEFAULT_BLK;
-    }
-    return blk;
-}
-
-// diagnostic: copies the stamps of the last K1 launch (8 words per workgroup) to `out`; returns the workgroup count
-int pca_debug_k1_stamps(pca_ctx *ctx, unsigned long long *out, int max_blocks)
-{
-    if (!ctx || !ctx->dbg) return 0;
-    const int n = ctx->dbg_blocks < max_blocks ? ctx->dbg_blocks : max_blocks;
-    if (hipMemcpy(out, ctx->dbg, sizeof(unsigned long long) * 8 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return n;
-}
-
-int pca_kitti_tile_points(void) { return PPT * k1_blk(); }
-int pca_kitti_tiles(int32_t n) { const int t = PPT * k1_blk(); return n > 0 ? (n + t - 1) / t : 1; }
-
-int pca_kitti_project_sample_filter(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames, const double P[12],
-                                    int H, int W, const uint64_t filter_mask[4], const pca_store *store,
-                                    int64_t *frame_off, int first_slot, void *stream)
-{
-    if (!ctx) return -1;
-    if (!frames || n_frames <= 0 || !store || !frame_off) { ctx->err = "k1: bad arguments"; return -1; }
-    hipStream_t s = (hipStream_t)stream;
-    PCA_CHECK(ctx, hipSetDevice(ctx->device));
-    int total = 0;
-    for (int k = 0; k < n_frames; ++k) {
-        if (frames[k].tile0 != total) { ctx->err = "k1: frames[k].tile0 must be the running sum of pca_kitti_tiles"; return -1; }
-        if (frames[k].n < 0 || (frames[k].n > 0 && !frames[k].pts)) { ctx->err = "k1: bad frame"; return -1; }
-        if (!frames[k].sem_gt && frames[k].n > 0 && (!frames[k].rgb || !frames[k].sem)) { ctx->err = "k1: frame needs rgb+sem or sem_gt"; return -1; }
-        total += pca_kitti_tiles(frames[k].n);
-    }
-    if (pca_ctx_reserve_tiles(ctx, total, s)) return -1;
-    K1Args a;
-    a.frames = nullptr;
-    a.one = frames[0];
-    if (n_frames > 1) {
-        if (n_frames > ctx->frames_cap) {
-            PCA_CHECK(ctx, hipStreamSynchronize(s));
-            if (ctx->frames_dev) PCA_CHECK(ctx, hipFree(ctx->frames_dev));
-            ctx->frames_cap = n_frames * 2;
-            PCA_CHECK(ctx, hipMalloc(&ctx->frames_dev, sizeof(pca_kitti_frame) * ctx->frames_cap));
-        }
-        // pageable source: the runtime stages it before returning, stream order protects the device copy
-        PCA_CHECK(ctx, hipMemcpyAsync(ctx->frames_dev, frames, sizeof(pca_kitti_frame) * n_frames,
-                                      hipMemcpyHostToDevice, s));
-        a.frames = ctx->frames_dev;
-    }
-    a.n_frames = n_frames;
-    a.total_tiles = total;
-    for (int i = 0; i < 12; ++i) a.P.m[i] = P[i];
-    a.H = H; a.W = W;
-    for (int i = 0; i < 4; ++i) a.filt.w[i] = filter_mask ? filter_mask[i] : 0;
-    a.st = *store;
-    a.frame_off = frame_off;
-    a.first_slot = first_slot;
-    a.state = ctx->tile_state;
-    a.ticket = ctx->ticket;
-    a.epoch = pca_ctx_next_epoch(ctx, s);
-    a.ticket64 = nullptr; a.ticket_base = 0; a.one_tile_each = 0;
-    a.dbg = nullptr;
-    a.dbg_skip = getenv("PCA_K1_SKIP") ? atoi(getenv("PCA_K1_SKIP")) : 0;
-    if (getenv("PCA_K1_STAMPS")) {
-        if (!ctx->dbg) { PCA_CHECK(ctx, hipMalloc(&ctx->dbg, sizeof(unsigned long long) * 8 * 65536)); }
-        if (total <= 65536) a.dbg = ctx->dbg;
-        ctx->dbg_blocks = total;
-    }
-    // persistent pipelined kernel: tiles are pulled by at most `resident` workgroups (3 x 512 threads fit a CU:
-    // 48 KB LDS and 70 VGPRs each); a single frame (fewer tiles than that) runs one tile per workgroup
-    const bool legacy = getenv("PCA_K1_LEGACY") != nullptr;
-    if (!legacy && k1_blk() == 512) {
-        const int resident = ctx->n_cu * 3;
-        const int grid = total < resident ? total : resident;
-        a.ticket64 = ctx->ticket64;
-        a.ticket_base = ctx->ticket64_base;
-        a.one_tile_each = grid == total;
-        ctx->ticket64_base += (unsigned long long)total + (a.one_tile_each ? 0 : grid);
-        PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti_persistent<512>, dim3(grid), dim3(512), s, a);
-    } else {
-        switch (k1_blk()) {
-            case 256: PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti<256>, dim3(total), dim3(256), s, a); break;
-            case 1024: PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti<1024>, dim3(total), dim3(1024), s, a); break;
-            default: PCA_LAUNCH(ctx, PCA_K_KITTI, k1_kitti<512>, dim3(total), dim3(512), s, a); break;
-        }
-    }
-    PCA_CHECK(ctx, hipGetLastError());
-    return 0;
-}
-
 int pca_nusc_sample_filter_transform(pca_ctx *ctx, const double *pc, const int64_t *cam_idx, int32_t n,
                                      const uint8_t *imgs, const uint8_t *sems, int ncam, int H, int W,
                                      const double T[16], const uint64_t filter_mask[4], const pca_store *store,
@@ -852,7 +431,7 @@ int pca_nusc_sample_filter_transform(pca_ctx *ctx, const double *pc, const int64
     if (n < 0 || (n > 0 && (!pc || !cam_idx || !imgs || !sems)) || !store || !frame_off) { ctx->err = "k1n: bad arguments"; return -1; }
     hipStream_t s = (hipStream_t)stream;
     PCA_CHECK(ctx, hipSetDevice(ctx->device));
-    const int total = pca_kitti_tiles(n);
+    const int total = n > 0 ? (n + PPT * CBLK - 1) / (PPT * CBLK) : 1;
     if (pca_ctx_reserve_tiles(ctx, total, s)) return -1;
     K1nArgs a;
     a.pc = pc; a.cam_idx = cam_idx; a.n = n; a.total_tiles = total;
@@ -862,11 +441,7 @@ int pca_nusc_sample_filter_transform(pca_ctx *ctx, const double *pc, const int64
     a.st = *store; a.frame_off = frame_off; a.slot = slot;
     a.state = ctx->tile_state; a.ticket = ctx->ticket;
     a.epoch = pca_ctx_next_epoch(ctx, s);
-    switch (k1_blk()) {
-        case 256: PCA_LAUNCH(ctx, PCA_K_NUSC, k1n_nusc<256>, dim3(total), dim3(256), s, a); break;
-        case 1024: PCA_LAUNCH(ctx, PCA_K_NUSC, k1n_nusc<1024>, dim3(total), dim3(1024), s, a); break;
-        default: PCA_LAUNCH(ctx, PCA_K_NUSC, k1n_nusc<512>, dim3(total), dim3(512), s, a); break;
-    }
+    PCA_LAUNCH(ctx, PCA_K_NUSC, k1n_nusc<CBLK>, dim3(total), dim3(CBLK), s, a);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }

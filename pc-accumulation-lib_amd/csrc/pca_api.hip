@@ -130,8 +130,6 @@ int pca_ctx_create(int device, pca_ctx **out)
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->ticket, 2 * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(ctx->ticket, 0, 2 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&ctx->ticket64, sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->ticket64, 0, sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(&ctx->status_host, sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc(&ctx->heavy_hint, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) {
         delete ctx;
@@ -154,8 +152,12 @@ void pca_ctx_destroy(pca_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->tile_state) (void)hipFree(ctx->tile_state);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
-    if (ctx->ticket64) (void)hipFree(ctx->ticket64);
-    if (ctx->frames_dev) (void)hipFree(ctx->frames_dev);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->k1_ws[i]) (void)hipFree(ctx->k1_ws[i]);
+        if (ctx->k1_pin[i]) (void)hipHostFree(ctx->k1_pin[i]);
+        if (ctx->k1_pin_ev[i]) (void)hipEventDestroy(ctx->k1_pin_ev[i]);
+    }
+    if (ctx->k1_frames_dev) (void)hipFree(ctx->k1_frames_dev);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     if (ctx->heavy_hint) (void)hipHostFree(ctx->heavy_hint);
     prof_fold(ctx);

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void bev_tile_scan(const BevArgs a)
         const uint32_t winc = wave_incl_scan_add(v);
         if (lane < SCAN_THREADS / 64) s_w[lane] = winc - v;                // exclusive wave offsets
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)winc, 63);
-        const uint64_t e = lb_exclusive_prefix(a.state, tile, (uint64_t)total, a.epoch);
+        const uint64_t e = lb_exclusive_prefix(a.state, tile, (uint64_t)total, a.epoch, a.ticket + 1);
         if (lane == 0) s_excl = (e << 32) | total;                          // both fit 32 bits (checked by the host)
     }
     __syncthreads();

@@ -14,6 +14,15 @@
 
 #define PCA_WAVE 64
 
+struct K1Frame {           // device-side frame descriptor of K1 (pca_k1.hip); the array is sorted by (queue, frame)
+    const float *pts;
+    const uint8_t *rgb, *sem, *sem_gt;
+    int32_t n;
+    int32_t tile0;         // first tile of the frame in OUTPUT (frame-major) order = index into the look-back state
+    int32_t qpos0;         // first position of the frame in its queue
+    int32_t f;             // frame index in the launch: slot = first_slot + f
+};
+
 struct pca_ctx {
     int device = 0;
     int n_cu = 256;                   // compute units of the device (MI355X: 256)
@@ -22,16 +31,21 @@ struct pca_ctx {
     uint64_t *tile_state = nullptr;   // dev [tile_cap]
     int64_t tile_cap = 0;
     uint32_t *ticket = nullptr;       // dev [2]: [0] ticket counter, [1] status bits
-    unsigned long long *ticket64 = nullptr;   // dev: monotonic ticket of the persistent K1 (never reset)
-    unsigned long long ticket64_base = 0;     // host mirror: draws issued so far
     uint32_t epoch = 0;               // 22-bit launch tag of tile_state entries
-    pca_kitti_frame *frames_dev = nullptr;
-    int frames_cap = 0;
+    void *k1_frames_dev = nullptr;    // dev: K1's frame descriptors of a batched launch
+    int64_t k1_frames_cap = 0;        // bytes
+    void *k1_ws[2] = {nullptr, nullptr};   // dev: counts / kept records of K1's split form, one per sub-batch in flight
+    int64_t k1_ws_cap[2] = {0, 0};         // bytes
+    K1Frame *k1_pin[2] = {nullptr, nullptr};   // pinned staging of the descriptors, alternating between calls
+    int k1_pin_cap[2] = {0, 0};
+    hipEvent_t k1_pin_ev[2] = {nullptr, nullptr};
+    bool k1_pin_busy[2] = {false, false};
+    int k1_pin_next = 0;
+    unsigned long long *dbg = nullptr; // diagnostic stamps of the last K1 launch (PCA_K1_STAMPS)
+    int dbg_blocks = 0;
     uint32_t *status_host = nullptr;  // pinned
     uint32_t *heavy_hint = nullptr;   // pinned, device-visible: heavy-tile count of the latest rasteriser call
     uint32_t *heavy_hint_dev = nullptr;
-    unsigned long long *dbg = nullptr; // diagnostic stamps of the last K1 launch (PCA_K1_STAMPS)
-    int dbg_blocks = 0;
     // optional per-kernel event timing
     struct Ev { hipEvent_t a, b; int kid; };
     int profiling = 0;                // 0 off, 1 every kernel launch, 2 whole units only (pca_profile_enable)
@@ -152,8 +166,12 @@ __device__ __forceinline__ void lb_publish_aggregate(uint64_t *state, int tile, 
 }
 
 // Called by ALL lanes of ONE wave after the aggregate was published: walks back over the predecessors,
-// publishes the inclusive prefix, returns the exclusive prefix.
-__device__ __forceinline__ uint64_t lb_walk(uint64_t *state, int tile, uint64_t aggregate, uint32_t epoch)
+// publishes the inclusive prefix, returns the exclusive prefix.  The spin is bounded: a predecessor that does not
+// publish within LB_MAX_POLLS fetches (seconds; a protocol or dispatch failure, never seen) raises
+// PCA_STATUS_LOOKBACK_TIMEOUT in *status and the walk returns what it has, so the grid always drains.
+#define LB_MAX_POLLS (1u << 21)
+__device__ __forceinline__ uint64_t lb_walk(uint64_t *state, int tile, uint64_t aggregate, uint32_t epoch,
+                                            uint32_t *status = nullptr)
 {
     const int lane = threadIdx.x & 63;
     if (tile == 0) return 0;
@@ -163,7 +181,12 @@ __device__ __forceinline__ uint64_t lb_walk(uint64_t *state, int tile, uint64_t 
     // when all workgroups run in lock step the walk is as long as the number of tiles in flight.
     constexpr int LB_W = 4;
     bool done = false;
+    uint32_t polls = 0;
     while (!done) {
+        if (++polls > LB_MAX_POLLS) {
+            if (status && lane == 0) atomicOr(status, PCA_STATUS_LOOKBACK_TIMEOUT);
+            break;
+        }
         uint64_t w[LB_W];
 #pragma unroll
         for (int j = 0; j < LB_W; ++j) {
@@ -202,8 +225,9 @@ __device__ __forceinline__ uint64_t lb_walk(uint64_t *state, int tile, uint64_t 
 }
 
 // publish + walk in one go (non-pipelined users)
-__device__ __forceinline__ uint64_t lb_exclusive_prefix(uint64_t *state, int tile, uint64_t aggregate, uint32_t epoch)
+__device__ __forceinline__ uint64_t lb_exclusive_prefix(uint64_t *state, int tile, uint64_t aggregate, uint32_t epoch,
+                                                        uint32_t *status = nullptr)
 {
     if ((threadIdx.x & 63) == 0) lb_publish_aggregate(state, tile, aggregate, epoch);
-    return lb_walk(state, tile, aggregate, epoch);
+    return lb_walk(state, tile, aggregate, epoch, status);
 }

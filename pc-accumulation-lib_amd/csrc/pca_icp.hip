@@ -114,7 +114,7 @@ __global__ __launch_bounds__(ICP_SCAN_THREADS) void icp_cell_scan(const IcpArgs 
         const uint32_t winc = wave_incl_scan_add(v);
         if (lane < ICP_SCAN_THREADS / 64) s_w[lane] = winc - v;
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)winc, 63);
-        const uint64_t e = lb_exclusive_prefix(a.lb_state, tile, (uint64_t)total, a.epoch);
+        const uint64_t e = lb_exclusive_prefix(a.lb_state, tile, (uint64_t)total, a.epoch, a.ticket + 1);
         if (lane == 0) s_excl = (e << 32) | total;
     }
     __syncthreads();

@@ -1,0 +1,674 @@
+// pca_k1.hip -- K1  kitti_project_sample_filter for gfx950 (MI355X)
+//   fused  velo2frame -> velo2img (frustum mask) -> nearest sample of semseg + RGB -> class filter -> stable append
+//   (sem_pc_accum.py:317-402, kitti360_sem_pc_accum.py:132-156 of the reference), one launch for a batch of frames.
+//
+// What bounds it (measured): per frame the kernel moves 1.9 MB of points, the ~2 MB of image lines its
+// 35 k gathers touch and 1 MB of kept records; it does ~30 f64 operations for the 29 % of the points that fall into
+// the frustum.  So the design is about (1) not fetching an image into eight L2s, (2) not spending vector issue slots
+// on the 71 % of the points that are outside the frustum, (3) enough independent workgroups in flight to cover the
+// chain  ticket -> points -> gathers -> look-back -> stores.
+//
+//   * one workgroup = one tile of BLK*PPT consecutive points of one frame.
+//   * phase 1 (every point): 16-byte load, f32 estimate of the three projection rows with a certified error bound,
+//     conservative frustum test -> candidates (a superset of the in-frustum points), compacted into an LDS list.
+//   * phase 2 (candidates only, dense lanes): the exact f64 path -- fma chain, IEEE divide, rint, 6-way mask -- two
+//     gathers (class byte, one unaligned dword for r,g,b), 256-bit class filter from LDS.  The rounds of a tile are
+//     software-pipelined: all point re-loads, then all projections and gathers, then all filters.
+//   * stable compaction inside the tile: ballot ranks + one 64-lane DPP scan per workgroup.
+//   * across tiles, two forms:
+//       FUSED (a launch of at most one tile per CU: every workgroup is resident, tile = blockIdx): decoupled
+//         look-back (8-byte {flag, epoch, value} granules, relaxed agent-scope atomics, bounded spin), then the SoA
+//         stores of the kept records (points re-read from L2).  One launch: this is what integrate() of one frame runs.
+//       SPLIT (batches): no workgroup ever waits for another.  k1_front writes each tile's kept list
+//         (tile-local index | rgb | class, 8 B per kept point) and its count; k1_scan (one workgroup) turns the counts
+//         into store offsets and closes the frames' segments; k1_append streams list + points into the SoA store,
+//         fully coalesced.  Block b of k1_front takes position b / Q of queue b % Q, queue q holding the tiles of the
+//         frames f = q (mod Q): with the round-robin placement of blocks on the 8 XCDs a frame's image lines are
+//         pulled into ONE L2 instead of eight (placement is a speed matter only, nothing depends on it).
+//     Measured on 64 x 120 k points: a single fused launch with tickets and look-back spends its time
+//     in convoys of spinning workgroups (polls alone are TB/s of fabric traffic); the split form has no spin at all.
+#include "pca_common.h"
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+template <typename T>
+__device__ __forceinline__ T k1_ldg(const T *p)
+{
+    return *reinterpret_cast<const __attribute__((address_space(1))) T *>(reinterpret_cast<uintptr_t>(p));
+}
+struct __attribute__((packed)) K1U32u { uint32_t v; };
+__device__ __forceinline__ uint32_t k1_ldg_u32_unaligned(const uint8_t *p)     // one global_load_dword at any byte address
+{
+    return reinterpret_cast<const __attribute__((address_space(1))) K1U32u *>(reinterpret_cast<uintptr_t>(p))->v;
+}
+typedef float k1_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 k1_ldg4(const float *p)      // one 16-byte global load
+{
+    const k1_f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) k1_f32x4 *>(reinterpret_cast<uintptr_t>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t k1_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }
+__device__ __forceinline__ int64_t k1_uniform_i64(int64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ uint32_t k1_mbcnt(uint64_t m)      // set bits of m below this lane
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+#define K1_MAXQ 8
+#define K1_APPEND_BLK 256
+#define K1_SCAN_BLK 1024
+
+struct K1Args {
+    const K1Frame *frames;              // dev [n_frames], or nullptr -> `one`.  FUSED: frame order; SPLIT: sorted by queue
+    K1Frame one;
+    int n_frames;
+    int n_queues;
+    int qframe0[K1_MAXQ + 1];           // SPLIT: frames of queue q = [qframe0[q], qframe0[q+1]) of `frames`
+    int qtiles[K1_MAXQ];                // SPLIT: tiles in queue q
+    Mat34 P;
+    int H, W;
+    float cull[16];                     // f32 rows x[4] y[4] d[4] of P, then s, c (error bound = s*max|xyz| + c), W-.5, H-.5
+    ClassMask filt;
+    pca_store st;                       // FUSED
+    int64_t *frame_off;
+    int first_slot;
+    uint64_t *state;
+    uint32_t *status;
+    uint32_t epoch;
+    int tpf;                            // tiles per frame if every frame of the launch has the same, else 0
+    float4 *rec_p;                      // SPLIT: [tiles][TILE] kept records: x, y, z, intensity (f32, as loaded)
+    uint32_t *rec_c;                    // SPLIT: [tiles][TILE]               rgb | class << 24
+    uint32_t *counts;                   // SPLIT: [tiles] kept points
+    int32_t *lastf;                     // SPLIT: [tiles] frame index if the tile is the last of its frame, else -1
+    unsigned long long *dbg;            // diagnostic stamps (PCA_K1_STAMPS=1): 8 words per workgroup, else nullptr
+};
+
+#define K1_FLAT_BLOCK ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x)
+#define K1_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[K1_FLAT_BLOCK * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
+// velo2frame + velo2img of one point: pixel index v*W+u, or -1 if outside the frustum (sem_pc_accum.py:347-394).
+// P rows as fma chains in k order (= the dgemm numpy runs), IEEE f64 divide, np.round = rint.
+__device__ __forceinline__ int k1_project_pixel(const Mat34 &P, float xf, float yf, float zf, int W, int H)
+{
+    const double x = (double)xf, y = (double)yf, z = (double)zf;
+    const double fx = row4(P.m + 0, x, y, z);
+    const double fy = row4(P.m + 4, x, y, z);
+    double d = row4(P.m + 8, x, y, z);
+    if (d == 0.0) d = -1e-6;
+    const double ad = fabs(d);
+    const double uf = rint(fx / ad);
+    const double vf = rint(fy / ad);
+    const bool ok = (uf >= 0.0) && (uf < (double)W) && (vf >= 0.0) && (vf < (double)H) && (d > 0.0) && (d < __builtin_huge_val());
+    return ok ? (int)vf * W + (int)uf : -1;
+}
+
+// The frame whose key (tile0 or qpos0, ascending over frames[f_lo, f_hi)) is the last one <= pos.  Every lane loads one
+// whole 48-byte descriptor, so the lookup is a single memory round trip; the holder hands it out through readlane.
+template <bool BY_TILE0>
+__device__ __forceinline__ K1Frame k1_find_frame(const K1Frame *frames, int f_lo, int f_hi, int pos, int lane)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t best[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int f0 = f_lo; f0 < f_hi; f0 += 64) {
+        const int f = f0 + lane;
+        u32x4 w[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        if (f < f_hi) {
+            const __attribute__((address_space(1))) u32x4 *p =
+                reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(reinterpret_cast<uintptr_t>(frames + f));
+            w[0] = p[0]; w[1] = p[1]; w[2] = p[2];
+        }
+        const int key = (int)(BY_TILE0 ? w[2].y : w[2].z);
+        const int c = (int)__popcll(__ballot(f < f_hi && key <= pos));
+        if (c > 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                best[4 * i + 0] = (uint32_t)__builtin_amdgcn_readlane((int)w[i].x, c - 1);
+                best[4 * i + 1] = (uint32_t)__builtin_amdgcn_readlane((int)w[i].y, c - 1);
+                best[4 * i + 2] = (uint32_t)__builtin_amdgcn_readlane((int)w[i].z, c - 1);
+                best[4 * i + 3] = (uint32_t)__builtin_amdgcn_readlane((int)w[i].w, c - 1);
+            }
+        }
+        if (c < 64) break;
+    }
+    K1Frame fr;
+    auto ptr = [&](int i) { return (uintptr_t)(((uint64_t)best[i + 1] << 32) | best[i]); };
+    fr.pts = reinterpret_cast<const float *>(ptr(0));
+    fr.rgb = reinterpret_cast<const uint8_t *>(ptr(2));
+    fr.sem = reinterpret_cast<const uint8_t *>(ptr(4));
+    fr.sem_gt = reinterpret_cast<const uint8_t *>(ptr(6));
+    fr.n = (int32_t)best[8]; fr.tile0 = (int32_t)best[9]; fr.qpos0 = (int32_t)best[10]; fr.f = (int32_t)best[11];
+    return fr;
+}
+static_assert(sizeof(K1Frame) == 48, "k1_find_frame reads a descriptor as three 16-byte words");
+
+template <int BLK, int PPT, bool SPLIT>
+__global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a)
+{
+    constexpr int TILE = BLK * PPT, NW = BLK / PCA_WAVE, NC = PPT * NW;
+    static_assert(NC <= 64, "the per-(row, wave) counts are scanned by one wave");
+    static_assert(TILE <= 65536, "tile-local indices are 16 bits");
+    static_assert(PPT % 2 == 0, "phase 1 tests two rows per packed instruction");
+    __shared__ float4 s_candp[TILE];       // the candidates (x, y, z, intensity), in point order
+    __shared__ uint16_t s_cand[TILE];      // their tile-local indices (use_gt_sem only)
+    __shared__ uint32_t s_cnt[NC];         // per (row, wave) counts: candidates, later kept points
+    __shared__ uint32_t s_filt[8];         // 256-bit class filter
+    __shared__ long long s_excl;           // FUSED: exclusive prefix of the tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    K1_STAMP(0);
+
+    // ---------------- which tile (no divisions: the grid is shaped by the host) ----------------
+    //   FUSED                  grid (tiles)                          block = tile in output order
+    //   SPLIT, equal frames    grid (Q, tiles per frame, frames / Q) x = queue, y = tile of the frame, z = frame of the queue
+    //   SPLIT, ragged          grid (Q, longest queue)               x = queue, y = position in the queue
+    K1Frame fr;
+    int tin;
+    if (!SPLIT) {
+        fr = a.frames ? k1_find_frame<true>(a.frames, 0, a.n_frames, (int)blockIdx.x, lane) : a.one;
+        tin = (int)blockIdx.x - fr.tile0;
+    } else {
+        const int q = blockIdx.x, f_lo = a.qframe0[q], f_hi = a.qframe0[q + 1];
+        if (a.tpf) {
+            if (f_lo + (int)blockIdx.z >= f_hi) return;                   // queues of unequal length
+            fr = a.frames ? a.frames[f_lo + blockIdx.z] : a.one;           // uniform index: a scalar load
+            tin = blockIdx.y;
+        } else {
+            if ((int)blockIdx.y >= a.qtiles[q]) return;
+            fr = k1_find_frame<false>(a.frames, f_lo, f_hi, (int)blockIdx.y, lane);
+            tin = (int)blockIdx.y - fr.qpos0;
+        }
+    }
+    if (threadIdx.x < 8) s_filt[threadIdx.x] = reinterpret_cast<const uint32_t *>(a.filt.w)[threadIdx.x];
+    const int tile = fr.tile0 + tin;                       // index in output (frame-major) order
+    const int ftiles = fr.n > 0 ? (fr.n + TILE - 1) / TILE : 1;
+    const int base_pt = tin * TILE;
+    const int n_here = fr.n - base_pt < TILE ? fr.n - base_pt : TILE;     // points of this tile (0 for an empty frame)
+    const bool gt = fr.sem_gt != nullptr;                  // use_gt_sem: no projection, rgb = 0
+    const float *pts = fr.pts + 4 * (int64_t)base_pt;
+    K1_STAMP(1);
+
+    // ---------------- phase 1: conservative frustum test of every point ----------------
+    // f32 estimates of the three projection rows, two points per packed instruction; a point is dropped only if one of
+    //   depth, u + 0.5 depth, (W - 0.5) depth - u, v + 0.5 depth, (H - 0.5) depth - v
+    // is below minus the error bound (NaN / inf never drop a point: every compare is false)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    uint64_t cm[PPT];
+    float4 v[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int idx = k * BLK + threadIdx.x;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < n_here) v[k] = k1_ldg4(pts + 4 * idx);                 // 16 B / lane, fully coalesced
+    }
+    {
+        const float *cu = a.cull;
+        auto sp = [](float c) { f2 r; r.x = c; r.y = c; return r; };
+#pragma unroll
+        for (int k = 0; k < PPT; k += 2) {
+            bool cand0 = k * BLK + (int)threadIdx.x < n_here, cand1 = (k + 1) * BLK + (int)threadIdx.x < n_here;
+            if (!gt) {
+                f2 x, y, z, m;
+                x.x = v[k].x; x.y = v[k + 1].x; y.x = v[k].y; y.y = v[k + 1].y; z.x = v[k].z; z.y = v[k + 1].z;
+                m.x = fmaxf(fmaxf(fabsf(x.x), fabsf(y.x)), fabsf(z.x));
+                m.y = fmaxf(fmaxf(fabsf(x.y), fabsf(y.y)), fabsf(z.y));
+                const f2 M = __builtin_elementwise_fma(sp(cu[12]), m, sp(cu[13]));       // error bound of every form
+                const f2 fx = __builtin_elementwise_fma(sp(cu[2]), z, __builtin_elementwise_fma(sp(cu[1]), y, __builtin_elementwise_fma(sp(cu[0]), x, sp(cu[3]))));
+                const f2 fy = __builtin_elementwise_fma(sp(cu[6]), z, __builtin_elementwise_fma(sp(cu[5]), y, __builtin_elementwise_fma(sp(cu[4]), x, sp(cu[7]))));
+                const f2 d = __builtin_elementwise_fma(sp(cu[10]), z, __builtin_elementwise_fma(sp(cu[9]), y, __builtin_elementwise_fma(sp(cu[8]), x, sp(cu[11]))));
+                const f2 t1 = __builtin_elementwise_fma(sp(0.5f), d, fx), t2 = __builtin_elementwise_fma(sp(cu[14]), d, -fx);
+                const f2 t3 = __builtin_elementwise_fma(sp(0.5f), d, fy), t4 = __builtin_elementwise_fma(sp(cu[15]), d, -fy);
+                // bitwise on purpose: compares, no branches
+                const int rej0 = (int)(d.x < -M.x) | (int)(t1.x < -M.x) | (int)(t2.x < -M.x) | (int)(t3.x < -M.x) | (int)(t4.x < -M.x);
+                const int rej1 = (int)(d.y < -M.y) | (int)(t1.y < -M.y) | (int)(t2.y < -M.y) | (int)(t3.y < -M.y) | (int)(t4.y < -M.y);
+                cand0 = cand0 && !rej0;
+                cand1 = cand1 && !rej1;
+            }
+            cm[k] = __ballot(cand0);
+            cm[k + 1] = __ballot(cand1);
+            if (lane == 0) { s_cnt[k * NW + wave] = (uint32_t)__popcll(cm[k]); s_cnt[(k + 1) * NW + wave] = (uint32_t)__popcll(cm[k + 1]); }
+        }
+    }
+    __syncthreads();
+    K1_STAMP(2);
+    uint32_t ncand;
+    {
+        const uint32_t c = lane < NC ? s_cnt[lane] : 0u;
+        const uint32_t inc = wave_incl_scan_add(c);
+        const uint32_t exc = inc - c;
+        ncand = (uint32_t)__builtin_amdgcn_readlane((int)inc, NC - 1);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)exc, k * NW + wave);
+            if ((cm[k] >> lane) & 1ull) {
+                const uint32_t o = off + k1_mbcnt(cm[k]);
+                s_candp[o] = v[k];
+                if (gt) s_cand[o] = (uint16_t)(k * BLK + threadIdx.x);
+            }
+        }
+    }
+    __syncthreads();
+    K1_STAMP(3);
+
+    // ---------------- phase 2: exact projection, gathers and class filter of the candidates ----------------
+    // round r handles candidates r*BLK .. ; three sweeps over the rounds keep the loads of all rounds in flight together
+    uint64_t km[PPT];
+    uint32_t packed[PPT];
+    float4 p[PPT];
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        p[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint32_t j = (uint32_t)(r * BLK) + threadIdx.x;
+        if (j < ncand) p[r] = s_candp[j];
+    }
+    if (gt) {
+#pragma unroll
+        for (int r = 0; r < PPT; ++r) {
+            const uint32_t j = (uint32_t)(r * BLK) + threadIdx.x;
+            unsigned c = 0;
+            const bool act = j < ncand;
+            if (act) c = k1_ldg(fr.sem_gt + base_pt + s_cand[j]);
+            packed[r] = c << 24;
+            km[r] = __ballot(act && !((s_filt[c >> 5] >> (c & 31u)) & 1u));
+        }
+    } else {
+        unsigned cls[PPT], rgb[PPT];
+        bool ok[PPT];
+        const int last = a.H * a.W * 3 - 4;                               // last legal 4-byte window of the image
+#pragma unroll
+        for (int r = 0; r < PPT; ++r) {
+            ok[r] = false; cls[r] = 0; rgb[r] = 0;
+            if ((uint32_t)(r * BLK) < ncand) {
+                const uint32_t j = (uint32_t)(r * BLK) + threadIdx.x;
+                const int px = k1_project_pixel(a.P, p[r].x, p[r].y, p[r].z, a.W, a.H);
+                ok[r] = j < ncand && px >= 0;
+                const int pix = ok[r] ? px : 0;                           // pixel 0 is always a valid address
+                // two gathers per point: the class byte and ONE unaligned dword holding r,g,b
+                cls[r] = k1_ldg(fr.sem + pix);
+                int off = pix * 3;
+                if (last >= 0) {
+                    const int sh = off > last ? (off - last) * 8 : 0;
+                    off = off > last ? last : off;
+                    rgb[r] = k1_ldg_u32_unaligned(fr.rgb + off) >> sh;
+                } else {                                                   // image smaller than four bytes
+                    rgb[r] = (uint32_t)k1_ldg(fr.rgb + off) | ((uint32_t)k1_ldg(fr.rgb + off + 1) << 8) |
+                             ((uint32_t)k1_ldg(fr.rgb + off + 2) << 16);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PPT; ++r) {
+            const unsigned c = cls[r];
+            packed[r] = (rgb[r] & 0xffffffu) | (c << 24);
+            km[r] = __ballot(ok[r] && !((s_filt[c >> 5] >> (c & 31u)) & 1u));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PPT; ++r)
+        if (lane == 0) s_cnt[r * NW + wave] = (uint32_t)__popcll(km[r]);
+    __syncthreads();
+    K1_STAMP(4);
+    uint32_t koff[PPT], total;
+    {
+        const uint32_t c = lane < NC ? s_cnt[lane] : 0u;
+        const uint32_t inc = wave_incl_scan_add(c);
+        const uint32_t exc = inc - c;
+        total = (uint32_t)__builtin_amdgcn_readlane((int)inc, NC - 1);
+#pragma unroll
+        for (int r = 0; r < PPT; ++r) koff[r] = (uint32_t)__builtin_amdgcn_readlane((int)exc, r * NW + wave);
+    }
+
+    if (SPLIT) {
+        // ---------------- the tile's kept records, in point order ----------------
+        float4 *rp = a.rec_p + (size_t)tile * TILE;
+        uint32_t *rc = a.rec_c + (size_t)tile * TILE;
+#pragma unroll
+        for (int r = 0; r < PPT; ++r)
+            if ((km[r] >> lane) & 1ull) {
+                const uint32_t o = koff[r] + k1_mbcnt(km[r]);
+                rp[o] = p[r];
+                rc[o] = packed[r];
+            }
+        if (threadIdx.x == 0) { a.counts[tile] = total; a.lastf[tile] = tin == ftiles - 1 ? fr.f : -1; }
+        K1_STAMP(5);
+        K1_STAMP(6);
+        return;
+    }
+
+    // ---------------- FUSED: look-back, then append the kept records ----------------
+    if (wave == 0) {
+        const uint64_t e = lb_exclusive_prefix(a.state, tile, (uint64_t)total, a.epoch, a.status);
+        if (lane == 0) s_excl = (long long)e;
+    }
+    __syncthreads();
+    K1_STAMP(5);
+    const int64_t tile_base = a.frame_off[a.first_slot] + k1_uniform_i64(s_excl);
+    const int64_t room64 = a.st.capacity - tile_base;
+    const uint32_t room = room64 <= 0 ? 0u : (room64 > 0x7fffffffll ? 0x7fffffffu : (uint32_t)room64);
+    double *xb = a.st.x + tile_base, *yb = a.st.y + tile_base, *zb = a.st.z + tile_base;
+    float *ib = a.st.intensity + tile_base;
+    uint32_t *cb = a.st.rgbs + tile_base;
+    int32_t *nb = a.st.inst + tile_base;
+    uint8_t *db = a.st.dyn + tile_base;
+    bool overflow = false;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        if (km[r] == 0) continue;                          // uniform
+        if ((km[r] >> lane) & 1ull) {
+            const uint32_t o = koff[r] + k1_mbcnt(km[r]);
+            if (o >= room) { overflow = true; continue; }
+            xb[o] = (double)p[r].x;
+            yb[o] = (double)p[r].y;
+            zb[o] = (double)p[r].z;
+            ib[o] = p[r].w;
+            cb[o] = packed[r];
+            nb[o] = 0;
+            db[o] = 0;
+        }
+    }
+    if (overflow) atomicOr(a.status, PCA_STATUS_STORE_OVERFLOW);
+    if (threadIdx.x == 0 && tin == ftiles - 1)             // the last tile of a frame closes its segment
+        a.frame_off[a.first_slot + fr.f + 1] = tile_base + total;
+    K1_STAMP(6);
+}
+
+// SPLIT, second kernel: streams a tile's kept records into the SoA store (consecutive lanes write consecutive
+// records: every store instruction is fully coalesced).  The tile's store offset is the sum of the counts of the
+// tiles before it, which every workgroup adds up for itself (<= K1_MAX_SPLIT_TILES values from L2: no scan kernel,
+// no atomics, nobody waits); the last tile of a frame also closes the frame's segment.
+#define K1_MAX_SPLIT_TILES 16384
+struct K1AppendArgs {
+    const float4 *rec_p;
+    const uint32_t *rec_c;
+    const uint32_t *counts;
+    const int32_t *lastf;
+    int tile_points;
+    pca_store st;
+    int64_t *frame_off;
+    int first_slot;
+    uint32_t *status;
+};
+
+__global__ __launch_bounds__(K1_APPEND_BLK) void k1_append(const K1AppendArgs a)
+{
+    constexpr int BLK = K1_APPEND_BLK;
+    const int tile = blockIdx.x;
+    __shared__ uint32_t s_w[BLK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t sum = 0;
+    for (int t = threadIdx.x; t < tile; t += BLK) sum += k1_ldg(a.counts + t);
+    sum = wave_reduce_add(sum);
+    if (lane == 0) s_w[wave] = sum;
+    const uint32_t c = a.counts[tile];
+    const int32_t lf = a.lastf[tile];
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < BLK / 64; ++w) before += s_w[w];
+    const int64_t base = a.frame_off[a.first_slot] + before;
+    if (threadIdx.x == 0 && lf >= 0) a.frame_off[a.first_slot + lf + 1] = base + c;
+    const float4 *rp = a.rec_p + (size_t)tile * a.tile_points;
+    const uint32_t *rc = a.rec_c + (size_t)tile * a.tile_points;
+    bool overflow = false;
+    for (uint32_t j = threadIdx.x; j < c; j += BLK) {
+        const float4 p = k1_ldg4(reinterpret_cast<const float *>(rp + j));
+        const uint32_t col = k1_ldg(rc + j);
+        const int64_t o = base + j;
+        if (o >= a.st.capacity) { overflow = true; continue; }
+        a.st.x[o] = (double)p.x;
+        a.st.y[o] = (double)p.y;
+        a.st.z[o] = (double)p.z;
+        a.st.intensity[o] = p.w;
+        a.st.rgbs[o] = col;
+        a.st.inst[o] = 0;
+        a.st.dyn[o] = 0;
+    }
+    if (overflow) atomicOr(a.status, PCA_STATUS_STORE_OVERFLOW);
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+// diagnostic: copies the stamps of the last K1 launch (8 words per workgroup) to `out`; returns the workgroup count
+int pca_debug_k1_stamps(pca_ctx *ctx, unsigned long long *out, int max_blocks)
+{
+    if (!ctx || !ctx->dbg) return 0;
+    const int n = ctx->dbg_blocks < max_blocks ? ctx->dbg_blocks : max_blocks;
+    if (hipMemcpy(out, ctx->dbg, sizeof(unsigned long long) * 8 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+
+#define K1_FUSED_BLK 256        // FUSED: many small tiles (one frame = 118 workgroups), latency matters
+#define K1_FUSED_PPT 4
+
+static void k1_split_config(int *blk, int *ppt)
+{
+    static int eb = -1, ep = -1;
+    if (eb < 0) {
+        eb = 512; ep = 4;
+        const char *e = getenv("PCA_K1_CFG");                 // "BLKxPPT", tuning only
+        if (e) { if (sscanf(e, "%dx%d", &eb, &ep) != 2) { eb = 512; ep = 4; } }
+    }
+    *blk = eb; *ppt = ep;
+}
+
+static int k1_grow(pca_ctx *ctx, void **p, int64_t *cap, int64_t need, hipStream_t s)
+{
+    if (need <= *cap) return 0;
+    PCA_CHECK(ctx, hipStreamSynchronize(s));
+    if (*p) PCA_CHECK(ctx, hipFree(*p));
+    *p = nullptr; *cap = 0;
+    const int64_t want = need + need / 4;
+    PCA_CHECK(ctx, hipMalloc(p, (size_t)want));
+    *cap = want;
+    return 0;
+}
+
+struct K1Plan {
+    K1Args fa;
+    K1AppendArgs pa;
+    dim3 grid_front;     // FUSED: (tiles); SPLIT: see k1_kitti
+    int tiles;
+};
+
+// Fills the launch arguments of one (sub-)batch and its frame descriptors hf[0..n_frames) (the caller uploads them to
+// dev_frames before the launch).  ws_slot: which half of the SPLIT workspace.
+static int k1_prepare(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames, const double P[12], int H, int W,
+                      const uint64_t filter_mask[4], const pca_store *store, int64_t *frame_off, int first_slot,
+                      bool fused, int blk, int ppt, int ws_slot, K1Frame *hf, const K1Frame *dev_frames, K1Plan *plan,
+                      hipStream_t s)
+{
+    const int tile_pts = blk * ppt;
+    auto tiles_of = [&](int n) { return n > 0 ? (n + tile_pts - 1) / tile_pts : 1; };
+    K1Args &a = plan->fa;
+    // SPLIT: frame f -> queue f % Q, block b -> position b / Q of queue b % Q (a frame's image lines stay in one L2)
+    int Q = 1;
+    if (!fused && n_frames > 1) Q = n_frames < K1_MAXQ ? n_frames : K1_MAXQ;
+    if (const char *e = getenv("PCA_K1_QUEUES")) {
+        const int v = atoi(e);
+        if (!fused && v >= 1 && v <= K1_MAXQ) Q = v < n_frames ? v : n_frames;
+    }
+    std::vector<int> tile0(n_frames);
+    int total = 0;
+    bool equal = true;
+    for (int k = 0; k < n_frames; ++k) {
+        tile0[k] = total;
+        total += tiles_of(frames[k].n);
+        equal = equal && tiles_of(frames[k].n) == tiles_of(frames[0].n);
+    }
+    int w = 0, maxq = 0;
+    for (int q = 0; q < K1_MAXQ; ++q) {
+        a.qframe0[q] = w;
+        int qpos = 0;
+        if (q < Q)
+            for (int k = q; k < n_frames; k += Q) {
+                K1Frame &d = hf[w++];
+                d.pts = frames[k].pts; d.rgb = frames[k].rgb; d.sem = frames[k].sem; d.sem_gt = frames[k].sem_gt;
+                d.n = frames[k].n; d.tile0 = tile0[k]; d.qpos0 = qpos; d.f = k;
+                qpos += tiles_of(frames[k].n);
+            }
+        a.qtiles[q] = qpos;
+        if (qpos > maxq) maxq = qpos;
+    }
+    a.qframe0[K1_MAXQ] = w;
+    a.n_queues = Q;
+    a.n_frames = n_frames;
+    a.tpf = equal ? tiles_of(frames[0].n) : 0;
+    a.frames = n_frames > 1 ? dev_frames : nullptr;
+    a.one = hf[0];
+    for (int i = 0; i < 12; ++i) a.P.m[i] = P[i];
+    a.H = H; a.W = W;
+    {   // f32 rows and the error bound of the conservative test: 2^-19 relative is 6x the worst case of three
+        // rounded coefficients and four fma roundings per form (< 2^-21.6), so a point is only ever culled when its
+        // exact f64 projection is outside the frustum by a wide margin
+        const double g = 1.0 / 524288.0;
+        const double wh = (double)(W > H ? W : H) + 1.0;
+        double sx = 0, sy = 0, sd = 0;
+        for (int j = 0; j < 3; ++j) { sx += fabs(P[j]); sy += fabs(P[4 + j]); sd += fabs(P[8 + j]); }
+        for (int i = 0; i < 12; ++i) a.cull[i] = (float)P[i];
+        a.cull[12] = (float)(g * (sx + sy + wh * sd) * 1.0000002);
+        a.cull[13] = (float)(g * (fabs(P[3]) + fabs(P[7]) + wh * fabs(P[11])) * 1.0000002 + 1e-30);
+        a.cull[14] = (float)((double)W - 0.5);
+        a.cull[15] = (float)((double)H - 0.5);
+    }
+    for (int i = 0; i < 4; ++i) a.filt.w[i] = filter_mask ? filter_mask[i] : 0;
+    a.st = *store;
+    a.frame_off = frame_off;
+    a.first_slot = first_slot;
+    a.state = nullptr; a.epoch = 0;
+    a.status = ctx->ticket + 1;
+    a.rec_p = nullptr; a.rec_c = nullptr; a.counts = nullptr; a.lastf = nullptr;
+    a.dbg = nullptr;
+    plan->tiles = total;
+    int maxf = 0;
+    for (int q = 0; q < Q; ++q) maxf = a.qframe0[q + 1] - a.qframe0[q] > maxf ? a.qframe0[q + 1] - a.qframe0[q] : maxf;
+    plan->grid_front = fused ? dim3(total) : a.tpf ? dim3(Q, a.tpf, maxf) : dim3(Q, maxq);
+    if (!fused && (maxq > 65535 || maxf > 65535)) { ctx->err = "k1: batch too large"; return -1; }
+    const int64_t nblocks = (int64_t)plan->grid_front.x * plan->grid_front.y * plan->grid_front.z;
+    if (getenv("PCA_K1_STAMPS")) {
+        if (!ctx->dbg) PCA_CHECK(ctx, hipMalloc(&ctx->dbg, sizeof(unsigned long long) * 8 * 65536));
+        if (nblocks <= 65536) { a.dbg = ctx->dbg; PCA_CHECK(ctx, hipMemsetAsync(ctx->dbg, 0, sizeof(unsigned long long) * 8 * nblocks, s)); }
+        ctx->dbg_blocks = (int)(nblocks < 65536 ? nblocks : 65536);
+    }
+    if (fused) {
+        if (pca_ctx_reserve_tiles(ctx, total, s)) return -1;
+        a.state = ctx->tile_state;
+        a.epoch = pca_ctx_next_epoch(ctx, s);
+        return 0;
+    }
+    // workspace: counts u32[total] | lastf i32[total] | rec_c u32[total * tile_pts] | rec_p float4[total * tile_pts]
+    const int64_t slots = (int64_t)total * tile_pts;
+    const int64_t o_counts = 0, o_lastf = ((int64_t)total * 4 + 255) & ~255ll, o_c = (o_lastf + (int64_t)total * 4 + 255) & ~255ll,
+                  o_p = (o_c + slots * 4 + 255) & ~255ll, need = o_p + slots * 16;
+    if (k1_grow(ctx, &ctx->k1_ws[ws_slot], &ctx->k1_ws_cap[ws_slot], need, s)) return -1;
+    char *ws = reinterpret_cast<char *>(ctx->k1_ws[ws_slot]);
+    a.counts = reinterpret_cast<uint32_t *>(ws + o_counts);
+    a.lastf = reinterpret_cast<int32_t *>(ws + o_lastf);
+    a.rec_c = reinterpret_cast<uint32_t *>(ws + o_c);
+    a.rec_p = reinterpret_cast<float4 *>(ws + o_p);
+    K1AppendArgs &pa = plan->pa;
+    pa.rec_p = a.rec_p; pa.rec_c = a.rec_c; pa.counts = a.counts; pa.lastf = a.lastf; pa.tile_points = tile_pts;
+    pa.st = *store; pa.frame_off = frame_off; pa.first_slot = first_slot; pa.status = a.status;
+    return 0;
+}
+
+static int k1_launch_split(pca_ctx *ctx, int blk, int ppt, const K1Plan *plan, hipStream_t s)
+{
+    bool launched = false;
+#define K1_CASE(B, Pp) if (blk == B && ppt == Pp) { hipLaunchKernelGGL((k1_kitti<B, Pp, true>), plan->grid_front, dim3(B), 0, s, plan->fa); launched = true; }
+    K1_CASE(256, 4) K1_CASE(512, 4) K1_CASE(1024, 4) K1_CASE(128, 4) K1_CASE(256, 2) K1_CASE(512, 2)
+#undef K1_CASE
+    if (!launched) { ctx->err = "k1: unsupported PCA_K1_CFG"; return -1; }
+    hipLaunchKernelGGL(k1_append, dim3(plan->tiles), dim3(K1_APPEND_BLK), 0, s, plan->pa);
+    PCA_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+int pca_kitti_project_sample_filter(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames, const double P[12],
+                                    int H, int W, const uint64_t filter_mask[4], const pca_store *store,
+                                    int64_t *frame_off, int first_slot, void *stream)
+{
+    if (!ctx) return -1;
+    if (!frames || n_frames <= 0 || !store || !frame_off || !P) { ctx->err = "k1: bad arguments"; return -1; }
+    if (H < 0 || W < 0 || (int64_t)H * W * 3 >= (1ll << 31)) { ctx->err = "k1: image too large"; return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    for (int k = 0; k < n_frames; ++k) {
+        if (frames[k].n < 0 || (frames[k].n > 0 && !frames[k].pts)) { ctx->err = "k1: bad frame"; return -1; }
+        if (!frames[k].sem_gt && frames[k].n > 0 && (!frames[k].rgb || !frames[k].sem || H * W == 0)) { ctx->err = "k1: frame needs rgb+sem or sem_gt"; return -1; }
+    }
+    // FUSED when every workgroup of the launch is resident at once (one tile per CU at most), else SPLIT
+    auto count_tiles = [&](int k0, int k1, int tile_pts) {
+        int64_t t = 0;
+        for (int k = k0; k < k1; ++k) t += frames[k].n > 0 ? (frames[k].n + tile_pts - 1) / tile_pts : 1;
+        return t;
+    };
+    bool fused = count_tiles(0, n_frames, K1_FUSED_BLK * K1_FUSED_PPT) <= ctx->n_cu;
+    if (const char *e = getenv("PCA_K1_MODE")) { if (!strcmp(e, "split")) fused = false; }
+    // frame descriptors of the whole call: built in pinned memory, one asynchronous upload
+    const int slot = ctx->k1_pin_next;
+    ctx->k1_pin_next ^= 1;
+    if (ctx->k1_pin_busy[slot]) { PCA_CHECK(ctx, hipEventSynchronize(ctx->k1_pin_ev[slot])); ctx->k1_pin_busy[slot] = false; }
+    if (n_frames > ctx->k1_pin_cap[slot]) {
+        if (ctx->k1_pin[slot]) PCA_CHECK(ctx, hipHostFree(ctx->k1_pin[slot]));
+        ctx->k1_pin[slot] = nullptr; ctx->k1_pin_cap[slot] = 0;
+        PCA_CHECK(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->k1_pin[slot]), sizeof(K1Frame) * (size_t)n_frames * 2));
+        ctx->k1_pin_cap[slot] = n_frames * 2;
+    }
+    if (!ctx->k1_pin_ev[slot]) PCA_CHECK(ctx, hipEventCreateWithFlags(&ctx->k1_pin_ev[slot], hipEventDisableTiming));
+    K1Frame *hf = ctx->k1_pin[slot];
+    if (k1_grow(ctx, &ctx->k1_frames_dev, &ctx->k1_frames_cap, (int64_t)sizeof(K1Frame) * n_frames, s)) return -1;
+    const K1Frame *df = reinterpret_cast<const K1Frame *>(ctx->k1_frames_dev);
+    bool prof_open = false;
+    auto upload = [&]() -> int {
+        if (ctx->profiling == 1) { pca_prof_begin(ctx, PCA_K_KITTI, s); prof_open = true; }   // one event pair around the unit's GPU work
+        if (n_frames > 1) {
+            PCA_CHECK(ctx, hipMemcpyAsync(ctx->k1_frames_dev, hf, sizeof(K1Frame) * n_frames, hipMemcpyHostToDevice, s));
+            PCA_CHECK(ctx, hipEventRecord(ctx->k1_pin_ev[slot], s));
+            ctx->k1_pin_busy[slot] = true;
+        }
+        return 0;
+    };
+    int rc = 0;
+    if (fused) {
+        K1Plan plan;
+        rc = k1_prepare(ctx, frames, n_frames, P, H, W, filter_mask, store, frame_off, first_slot, true, K1_FUSED_BLK, K1_FUSED_PPT, 0, hf, df, &plan, s);
+        if (rc == 0) rc = upload();
+        if (rc == 0) {
+            hipLaunchKernelGGL((k1_kitti<K1_FUSED_BLK, K1_FUSED_PPT, false>), plan.grid_front, dim3(K1_FUSED_BLK), 0, s, plan.fa);
+            if (hipGetLastError() != hipSuccess) { ctx->err = "k1: launch failed"; rc = -1; }
+        }
+    } else {
+        int blk, ppt;
+        k1_split_config(&blk, &ppt);
+        // sub-batches of at most K1_MAX_SPLIT_TILES tiles (k1_append adds up the counts before its tile)
+        std::vector<K1Plan> plans;
+        for (int k0 = 0; k0 < n_frames && rc == 0;) {
+            int k1 = k0 + 1;
+            int64_t t = count_tiles(k0, k1, blk * ppt);
+            if (t > (1 << 28)) { ctx->err = "k1: frame too large"; rc = -1; break; }
+            while (k1 < n_frames) {
+                const int64_t tn = count_tiles(k1, k1 + 1, blk * ppt);
+                if (t + tn > K1_MAX_SPLIT_TILES) break;
+                t += tn; ++k1;
+            }
+            plans.emplace_back();
+            rc = k1_prepare(ctx, frames + k0, k1 - k0, P, H, W, filter_mask, store, frame_off, first_slot + k0, false, blk, ppt,
+                            0, hf + k0, df + k0, &plans.back(), s);
+            k0 = k1;
+        }
+        if (rc == 0) rc = upload();
+        for (size_t i = 0; i < plans.size() && rc == 0; ++i) rc = k1_launch_split(ctx, blk, ppt, &plans[i], s);
+    }
+    if (prof_open) pca_prof_end(ctx, s);
+    return rc;
+}
+
+}  // extern "C"

@@ -13,9 +13,10 @@ LIB_PATH = os.path.join(_HERE, 'libpca_hip.so')
 STATUS_STORE_OVERFLOW = 1
 STATUS_UV_OUT_OF_IMAGE = 2
 STATUS_NEGATIVE_INTENSITY = 4
+STATUS_LOOKBACK_TIMEOUT = 8
 
 EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error', 'pca_status',
-           'pca_kitti_tile_points', 'pca_kitti_tiles', 'pca_kitti_project_sample_filter',
+           'pca_kitti_project_sample_filter',
            'pca_nusc_sample_filter_transform', 'pca_nusc_project_cams', 'pca_retransform', 'pca_mark_dynamic',
            'pca_bev_workspace_bytes', 'pca_bev_generate', 'pca_bev_generate_ex', 'pca_voxel_dedup_workspace_bytes', 'pca_voxel_dedup', 'pca_icp_workspace_bytes', 'pca_icp_register', 'pca_host_ego_to_grid',
            'pca_profile_enable', 'pca_profile_read')
@@ -32,7 +33,7 @@ class PcaStore(C.Structure):
 
 class PcaKittiFrame(C.Structure):
     _fields_ = [('pts', C.c_void_p), ('rgb', C.c_void_p), ('sem', C.c_void_p), ('sem_gt', C.c_void_p),
-                ('n', C.c_int32), ('tile0', C.c_int32)]
+                ('n', C.c_int32), ('reserved', C.c_int32)]
 
 
 class PcaBevParams(C.Structure):
@@ -79,8 +80,6 @@ def load():
     lib.pca_last_error.argtypes = [vp]
     lib.pca_last_error.restype = C.c_char_p
     lib.pca_status.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
-    lib.pca_kitti_tile_points.restype = C.c_int
-    lib.pca_kitti_tiles.argtypes = [C.c_int32]
     lib.pca_kitti_project_sample_filter.argtypes = [
         vp, C.POINTER(PcaKittiFrame), i32, C.POINTER(C.c_double), i32, i32, C.POINTER(C.c_uint64),
         C.POINTER(PcaStore), vp, i32, vp

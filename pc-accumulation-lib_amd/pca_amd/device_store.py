@@ -82,6 +82,8 @@ class DeviceStore:
             raise AssertionError('pts_uv must be all inside image')
         if st & _lib.STATUS_STORE_OVERFLOW:
             raise RuntimeError('pca: device point store overflow (points were dropped)')
+        if st & _lib.STATUS_LOOKBACK_TIMEOUT:
+            raise RuntimeError('pca: a compaction workgroup timed out waiting for its predecessor (output invalid)')
         if st & _lib.STATUS_NEGATIVE_INTENSITY:
             raise ValueError('pca: negative lidar intensity on the f32 path (pass intensity64 to bev())')
 
@@ -131,14 +133,10 @@ class DeviceStore:
         self.frame_off.zero_()
 
     # ---- K1: KITTI ------------------------------------------------------------------------
-    def append_kitti(self, frames, P, H, W, filters):
-        """frames: list of dicts {pts (n,4) f32 cuda, rgb (H,W,3) u8 cuda | None, sem (H,W) u8 cuda | None,
-        sem_gt (n,) u8 cuda | None}.  One launch appends all of them (stable order) as new slots."""
-        lib, ctx = self.ctx.lib, self.ctx
-        n_in = sum(int(f['pts'].shape[0]) for f in frames)
-        self.reserve(n_in, len(frames))
+    @staticmethod
+    def kitti_descs(frames):
+        """The C descriptors of a list of frame dicts (see append_kitti)."""
         descs = (PcaKittiFrame * len(frames))()
-        tile0 = 0
         for k, f in enumerate(frames):
             n = int(f['pts'].shape[0])
             assert f['pts'].dtype == torch.float32 and f['pts'].is_contiguous()
@@ -147,13 +145,22 @@ class DeviceStore:
             descs[k].sem = f['sem'].data_ptr() if f.get('sem') is not None else None
             descs[k].sem_gt = f['sem_gt'].data_ptr() if f.get('sem_gt') is not None else None
             descs[k].n = n
-            descs[k].tile0 = tile0
-            tile0 += lib.pca_kitti_tiles(n)
+        return descs
+
+    def append_kitti(self, frames, P, H, W, filters, descs=None):
+        """frames: list of dicts {pts (n,4) f32 cuda, rgb (H,W,3) u8 cuda | None, sem (H,W) u8 cuda | None,
+        sem_gt (n,) u8 cuda | None}.  One call appends all of them (stable order) as new slots.
+        descs: kitti_descs(frames) built earlier (a caller that replays the same batch)."""
+        lib, ctx = self.ctx.lib, self.ctx
+        n_in = sum(int(f['pts'].shape[0]) for f in frames)
+        self.reserve(n_in, len(frames))
+        if descs is None:
+            descs = self.kitti_descs(frames)
         st = self.c_store()
-        key = (id(P), id(filters))
+        # keyed on VALUES (12 doubles + a short list): a calibration or filter list mutated in place is seen
+        key = (np.asarray(P, dtype=np.float64).tobytes(), tuple(int(c) for c in (filters or ())))
         if self._k1_cache is None or self._k1_cache[0] != key:
-            # the accumulator passes the same calibration / filter objects every frame
-            self._k1_cache = (key, _lib.f64_array(P, 12), _lib.class_mask(filters), P, filters)
+            self._k1_cache = (key, _lib.f64_array(P, 12), _lib.class_mask(filters))
         Pc, fmask = self._k1_cache[1], self._k1_cache[2]
         ctx.check(lib.pca_kitti_project_sample_filter(ctx.h, descs, len(frames), Pc, int(H), int(W),
                                                       fmask, C.byref(st),

@@ -1,6 +1,6 @@
-for MODE in persistent legacy; do
-  if [ $MODE = legacy ]; then export PCA_K1_LEGACY=1; else unset PCA_K1_LEGACY; fi
-  timeout -k 10 200 python bench.py --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/k1_$MODE.json 2>/dev/null
-  python -c "
-import json; d=json.load(open('gpurun_out/k1_$MODE.json')); print('$MODE', round(d['value'],1), round(d['roofline']['kernels']['kitti_project_sample_filter']['avg_us'],1), round(d['roofline']['k1_batched']['avg_launch_us'],1), round(d['roofline']['k1_batched']['frac'],3))"
+# K1 split form on the batched launch: tile shape; pool 8 = images shared by 8 frames, pool 64 = all distinct
+for CFG in 512x4 256x4 1024x4; do
+  for POOL in 8 64; do
+    PCA_K1_CFG=$CFG timeout -k 10 120 python tools/experiments/k1_batched.py $POOL 64 20 2>&1 | tail -1
+  done
 done
