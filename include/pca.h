@@ -167,7 +167,8 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts /*dev*/, int32_t n_src, 
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
     double origin[3];         /* bev_frame_coords                                                   */
-    double R[9];              /* rotation_matrix_3d(rot_ang) evaluated on the host (np.cos/np.sin)  */
+    double R[9];              /* rotation_matrix_3d(rot_ang) evaluated on the host (np.cos/np.sin);
+                                 must be a rotation about z (checked)                                */
     double dx, dy;            /* augmentation translation                                           */
     double view;              /* zoom_scalar * view_size                                            */
     double height_filter;     /* keep z < height_filter; NaN disables                               */
@@ -206,6 +207,16 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
                         int64_t max_points, const pca_bev_params *prm, const double *pending_T, int pending_slot_end,
                         void *workspace /*dev*/, int64_t workspace_bytes, double *planes /*dev*/,
                         uint16_t *planes_f16 /*dev*/, double *extra_planes /*dev, may be NULL*/, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Polynomial warp of finished fp16 planes (--bev_do_warp augmentation).  Replaces
+ *       bev_generator/bev_generator.py:482-525 (warp_dense_probmaps: a Python loop over px^2 cells).
+ *     out[n][jw][iw] = in[n][clamp(rint(b_1 jw + b_2 jw^2))][clamp(rint(a_1 iw + a_2 iw^2))], the index expressions
+ *     evaluated exactly as numpy evaluates them; (a_1, a_2) / (b_1, b_2) come from cal_warp_params (:563-569).
+ *     planes_f16, out_f16: dev [n_planes, px, px], distinct buffers.
+ * ------------------------------------------------------------------------------------------------ */
+int pca_bev_warp(pca_ctx *ctx, const uint16_t *planes_f16 /*dev*/, uint16_t *out_f16 /*dev*/, int n_planes, int px,
+                 double a_1, double a_2, double b_1, double b_2, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Host helper (no device work): the ego trajectory of one BEV sample -- rotate, translate, clip to the view box

@@ -24,12 +24,15 @@ class DeviceWindow:
     """Live frames [first, last) of a DeviceStore; frames before `split` form the 'present' set.
     `origin` is the BEV frame origin (the reference subtracts it on the host while concatenating)."""
 
-    def __init__(self, store, split, origin, first=0, last=None):
+    def __init__(self, store, split, origin, first=0, last=None, future_is_present=False):
         self.store = store
         self.split = int(split)
         self.origin = np.asarray(origin, dtype=np.float64)
         self.first = int(first)
         self.last = store.n_frames if last is None else int(last)
+        # generate_bev(present_idx=None, gen_future=True) of the reference: sem_pcs[:None] and sem_pcs[None:] are both
+        # the whole window, so 'present', 'future' and 'full' are the same point set
+        self.future_is_present = bool(future_is_present)
 
     def part(self, name):
         return WindowPart(self, name)
@@ -47,6 +50,8 @@ class WindowPart:
         w = self.window
         rows = w.store.frame_rows()
         lo, hi = {'present': (w.first, w.split), 'future': (w.split, w.last), 'full': (w.first, w.last)}[self.name]
+        if w.future_is_present:
+            lo, hi = w.first, w.last
         out = np.concatenate(rows[lo:hi]) if hi > lo else np.zeros((0, 10))
         out[:, :3] = out[:, :3] - w.origin
         return out

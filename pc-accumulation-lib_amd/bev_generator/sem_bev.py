@@ -1,8 +1,9 @@
 """Semantic BEV generator -- drop-in for the reference's ``bev_generator.sem_bev.SemBEVGenerator``.
 
-All 21 planes (7 per point set) come out of one device launch sequence (csrc/pca_bev.hip); this class
-only frames the problem (heading, augmentation), handles trajectories / optional warp on the host and
-packs the reference's output dict (README.md:60-99 of the reference: keys, shapes, float16).
+All 21 planes (7 per point set) come out of one device launch sequence (csrc/pca_bev.hip), the optional warp
+augmentation included (pca_bev_warp); this class only frames the problem (heading, augmentation), handles the
+trajectory polylines on the host and packs the reference's output dict (README.md:60-99 of the reference: keys,
+shapes, float16).
 """
 import numpy as np
 
@@ -49,32 +50,43 @@ class SemBEVGenerator(BEVGenerator):
             pc_present, pc_future, pc_full = (self._grid_rows_to_metres(p) for p in (pc_present, pc_future, pc_full))
         device_only, self._device_only = self._device_only, False
         out16, self._out16 = self._out16, None
-        p16, p64 = self.generate_bev_device(pc_present, pc_future, pc_full,
-                                            want_f64=self.do_warp and not device_only, out16=out16)
+        p16, _ = self.generate_bev_device(pc_present, pc_future, pc_full, out16=None if self.do_warp else out16)
         self._frame = None
-        if device_only:
-            out = {'planes_f16': p16, 'trajs_present': trajs_present, 'trajs_future': trajs_future,
-                   'trajs_full': trajs_full}
-            if gt_lane_trajs is not None:
-                out['gt_lanes'] = gt_lane_trajs
-            return out
+        if getattr(pc_present, 'window', None) is not None and pc_present.window.future_is_present:
+            p16[7:14] = p16[0:7]             # generate_bev(present_idx=None, gen_future=True): every set is the window
         if self.do_warp:
+            # polynomial warp augmentation: planes on the device (pca_bev_warp), trajectory vertices on the host
             px = self.pixel_size
             i_mid = j_mid = int(px / 2)
             i_warp, j_warp = self.get_random_warp_params(0.15, 0.30, px, px)
             a_1, a_2 = self.cal_warp_params(i_warp, i_mid, px - 1)
             b_1, b_2 = self.cal_warp_params(j_warp, j_mid, px - 1)
-            maps = self.warp_dense_probmaps(p64.cpu().numpy(), a_1, a_2, b_1, b_2)
+            p16 = self.warp_planes_device(p16, a_1, a_2, b_1, b_2, out16)
             args = (a_1, a_2, b_1, b_2, i_mid, j_mid, i_warp, j_warp)
             trajs_present = self.warp_trajs(trajs_present, *args)
             trajs_future = self.warp_trajs(trajs_future, *args)
             trajs_full = self.warp_trajs(trajs_full, *args)
             if gt_lane_trajs is not None:
                 gt_lane_trajs = self.warp_trajs(gt_lane_trajs, *args)
-            planes = maps.astype(np.float16)
-        else:
-            planes = p16.cpu().numpy()
-        return self.pack_bev(planes, trajs_present, trajs_future, trajs_full, gt_lane_trajs)
+        if device_only:
+            out = {'planes_f16': p16, 'trajs_present': trajs_present, 'trajs_future': trajs_future,
+                   'trajs_full': trajs_full}
+            if gt_lane_trajs is not None:
+                out['gt_lanes'] = gt_lane_trajs
+            return out
+        return self.pack_bev(p16.cpu().numpy(), trajs_present, trajs_future, trajs_full, gt_lane_trajs)
+
+    @staticmethod
+    def warp_planes_device(p16, a_1, a_2, b_1, b_2, out16=None):
+        """cuda float16 [n,px,px] -> warped copy (bev_generator.py:482-525 of the reference as one gather kernel)."""
+        import torch
+        from pca_amd import _lib
+        ctx = _lib.Context.get()
+        out = out16 if out16 is not None else torch.empty_like(p16)
+        assert p16.is_contiguous() and out.is_contiguous() and out.shape == p16.shape and out.dtype == torch.float16
+        ctx.check(ctx.lib.pca_bev_warp(ctx.h, p16.data_ptr(), out.data_ptr(), int(p16.shape[0]), int(p16.shape[1]),
+                                       float(a_1), float(a_2), float(b_1), float(b_2), ctx.stream()))
+        return out
 
     @staticmethod
     def pack_bev(planes, trajs_present, trajs_future, trajs_full, gt_lane_trajs=None):

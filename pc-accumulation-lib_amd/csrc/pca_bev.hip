@@ -862,6 +862,11 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
     if (!ctx) return -1;
     if (!store || !frame_off || !prm || !workspace || (!planes && !planes_f16)) { ctx->err = "bev: bad arguments"; return -1; }
     if (prm->px < 1 || prm->px > 1024) { ctx->err = "bev: px must be in 1..1024"; return -1; }
+    // the elevation plane is min(z - origin_z): the rotation has to leave z alone (rotation_matrix_3d of the reference)
+    if (!(prm->R[6] == 0.0 && prm->R[7] == 0.0 && prm->R[8] == 1.0 && prm->R[2] == 0.0 && prm->R[5] == 0.0)) {
+        ctx->err = "bev: R must be a rotation about the z axis (R[2] = R[5] = R[6] = R[7] = 0, R[8] = 1)";
+        return -1;
+    }
     if (!(slot_begin <= slot_split && slot_split <= slot_end)) { ctx->err = "bev: need slot_begin <= slot_split <= slot_end"; return -1; }
     if (max_points < 1) max_points = 1;
     if (max_points >= (1ll << 32)) { ctx->err = "bev: window too large for 32-bit positions"; return -1; }
@@ -938,6 +943,53 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
         PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, bev_tile_cells_heavy<false>, dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a);
     }
     if (ctx->profiling == 2) pca_prof_end(ctx, s);
+    PCA_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Polynomial warp of finished planes (bev_generator.py:482-525 of the reference, --bev_do_warp augmentation):
+//   out[n][jw][iw] = in[n][clamp(rint(b1 jw + b2 jw^2))][clamp(rint(a1 iw + a2 iw^2))]
+// (the reference's loop writes B[:, j_warp, i_warp] = A[:, j, i]: warped row index from the b pair, column from the a
+// pair).  Source indices are evaluated as numpy does -- un-fused f64 products and sum, rint, clamp -- so they are the
+// reference's integers; a gather commutes with the element-wise f64 -> f16 cast, so the warp runs on the fp16 planes.
+// ---------------------------------------------------------------------------------------------------------------
+struct WarpArgs {
+    const uint16_t *in;
+    uint16_t *out;
+    int n_planes, px;
+    double a1, a2, b1, b2;
+};
+
+__device__ __forceinline__ int warp_src(double c1, double c2, int k, int n)
+{
+    const double kd = (double)k;
+    double v = rint(c1 * kd + c2 * (kd * kd));
+    v = v < 0.0 ? 0.0 : (v > (double)(n - 1) ? (double)(n - 1) : v);      // NaN -> n - 1 never happens for finite c
+    return (int)v;
+}
+
+__global__ __launch_bounds__(256) void bev_warp(const WarpArgs a)
+{
+    const int iw = blockIdx.x * 256 + threadIdx.x, jw = blockIdx.y;
+    if (iw >= a.px) return;
+    const int i = warp_src(a.a1, a.a2, iw, a.px), j = warp_src(a.b1, a.b2, jw, a.px);
+    const size_t plane = (size_t)a.px * a.px;
+    for (int n = 0; n < a.n_planes; ++n) a.out[n * plane + (size_t)jw * a.px + iw] = a.in[n * plane + (size_t)j * a.px + i];
+}
+
+int pca_bev_warp(pca_ctx *ctx, const uint16_t *planes_f16, uint16_t *out_f16, int n_planes, int px, double a_1, double a_2,
+                 double b_1, double b_2, void *stream)
+{
+    if (!ctx) return -1;
+    if (!planes_f16 || !out_f16 || planes_f16 == out_f16 || n_planes < 1 || px < 1 || px > 65535) { ctx->err = "warp: bad arguments"; return -1; }
+    if (!(a_1 == a_1 && a_2 == a_2 && b_1 == b_1 && b_2 == b_2)) { ctx->err = "warp: NaN coefficient"; return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    WarpArgs a;
+    a.in = planes_f16; a.out = out_f16; a.n_planes = n_planes; a.px = px;
+    a.a1 = a_1; a.a2 = a_2; a.b1 = b_1; a.b2 = b_2;
+    hipLaunchKernelGGL(bev_warp, dim3((px + 255) / 256, px), dim3(256), 0, s, a);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }

@@ -7,7 +7,9 @@ points (K1, device, fused), evict frames beyond the path horizon.  Nothing is re
 
 Pose source: the reference calls Open3D point-to-plane ICP (an external C++ library that only FEEDS the
 hot path a 4x4 matrix).  ``pose_provider`` is the hook for that input: a callable ``pc (N,4) -> T_new_prev``.
-The default provider issues the same Open3D call when ``open3d`` is importable and raises otherwise.
+The default provider issues the same Open3D call; without ``open3d`` the first integrate() raises, unless a pose
+source is named (PCA_KITTI_T_FILE, PCA_POSE_PROVIDER=<module>:<callable>, or PCA_POSE_PROVIDER=gpu_icp for the device
+ICP of pca_amd/icp.py, which is NOT the reference's Open3D registration: parity with it is unpinned).
 """
 import numpy as np
 
@@ -30,9 +32,8 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
     # ---- pose input ----------------------------------------------------------------------------
     def _default_pose_provider(self):
         """Pose source without touching the driver: PCA_KITTI_T_FILE=<.npy of (F,4,4) T_new_prev, one per frame>,
-        PCA_POSE_PROVIDER=<module>:<callable(pc) -> 4x4>, or PCA_POSE_PROVIDER=gpu_icp / open3d; by default the
-        reference's Open3D ICP call when open3d imports, else the device ICP (pca_amd/icp.py; parity with Open3D
-        unpinned)."""
+        PCA_POSE_PROVIDER=<module>:<callable(pc) -> 4x4>, or PCA_POSE_PROVIDER=gpu_icp / open3d.  The default is the
+        reference's Open3D ICP call; the device ICP is opt-in only (its poses differ from Open3D's)."""
         import os
         path = os.environ.get('PCA_KITTI_T_FILE')
         if path:
@@ -47,10 +48,6 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
             import importlib
             mod, _, fn = spec.partition(':')
             return getattr(importlib.import_module(mod), fn)
-        try:
-            import open3d  # noqa: F401
-        except ImportError:
-            return self._gpu_icp_pose
         return self._icp_pose
 
     def _gpu_icp_pose(self, pc):
@@ -66,7 +63,13 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         return reg.transformation
 
     def _icp_pose(self, pc):
-        import open3d as o3d
+        try:
+            import open3d as o3d
+        except ImportError as e:
+            raise ImportError('the KITTI-360 flow takes its poses from Open3D ICP, as the reference does, and open3d is '
+                              'not importable; name another pose source: accumulator.pose_provider = callable, '
+                              'PCA_KITTI_T_FILE=<poses.npy>, PCA_POSE_PROVIDER=<module>:<callable> or '
+                              'PCA_POSE_PROVIDER=gpu_icp (device ICP, not bit-compatible with Open3D)') from e
         pcd_new = self.pc2pcd(pc)
         if self.pcd_prev is None:
             self.pcd_prev = pcd_new

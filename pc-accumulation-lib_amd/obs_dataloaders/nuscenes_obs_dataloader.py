@@ -5,39 +5,17 @@ unchanged.  What runs where:
 
   * lidar -> ego -> global -> 6 cameras, pinhole projection, "last camera wins" (reference :162-202): ONE device launch
     (`datasets.nuscenes_utils.project_to_cameras`, kernel K0n) instead of 2 + 6 numpy transforms and 6 projections;
-  * walking the dataset, merging sweeps and labelling points with their GT boxes (`inst_centric_get_sweeps`, ~200
-    lines of nuscenes-devkit bookkeeping and disk I/O, SURVEY.md scope table: out of the hot path) is NOT restated
-    here.  It is obtained from, in this order: `NuScenesDataloader.sweep_provider` (any callable with the signature of
-    the reference's function that returns its dict after `load_data_to_tensor`), or the reference's own
-    `datasets/nuscenes_utils.py` loaded from the checkout named by PCA_REFERENCE_ROOT.
+  * merging the lidar sweeps of a sample and labelling points with their GT boxes (the reference's
+    `inst_centric_get_sweeps`, datasets/nuscenes_utils.py:332-531) is done by `NuScenesDataloader.sweep_provider`, a
+    callable with that function's signature returning its dict; the default is this package's own
+    `datasets.nuscenes_sweeps.inst_centric_get_sweeps`.
 
 nuscenes-devkit / pyquaternion are only imported when a real dataset is walked.
 """
-import importlib.util
-import os
-
 import numpy as np
 
 from datasets.nuscenes_utils import NuScenesCamera, NuScenesLidar, project_to_cameras
 from obs_dataloaders.obs_dataloader import ObservationDataloader
-
-_REF = {}
-
-
-def _reference_utils():
-    """The reference's datasets/nuscenes_utils.py as a private module (dataset bookkeeping only)."""
-    if 'mod' not in _REF:
-        root = os.environ.get('PCA_REFERENCE_ROOT')
-        path = os.path.join(root, 'datasets', 'nuscenes_utils.py') if root else None
-        if not path or not os.path.isfile(path):
-            raise RuntimeError('NuScenesDataloader needs a sweep provider: set NuScenesDataloader.sweep_provider, or '
-                               'PCA_REFERENCE_ROOT=<checkout of the reference> (its inst_centric_get_sweeps is used)')
-        spec = importlib.util.spec_from_file_location('_pca_reference_nuscenes_utils', path)
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        _REF['mod'] = mod
-    return _REF['mod']
-
 
 class NuScenesDataloader(ObservationDataloader):
     sweep_provider = None       # callable(nusc, sample_token, **cfg) -> dict (points, instances_token, ...)
@@ -68,10 +46,8 @@ class NuScenesDataloader(ObservationDataloader):
     def _sweeps(self, sample_token, cfg):
         if self.sweep_provider is not None:
             return self.sweep_provider(self.nusc, sample_token, **cfg)
-        ref = _reference_utils()
-        out = ref.inst_centric_get_sweeps(self.nusc, sample_token, **cfg)
-        ref.load_data_to_tensor(out)
-        return out
+        from datasets.nuscenes_sweeps import inst_centric_get_sweeps
+        return inst_centric_get_sweeps(self.nusc, sample_token, **cfg)
 
     def _lidar(self, sample):
         return NuScenesLidar(self.nusc, self.nusc.get('sample_data', sample['data']['LIDAR_TOP']))

@@ -18,7 +18,7 @@ STATUS_LOOKBACK_TIMEOUT = 8
 EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error', 'pca_status',
            'pca_kitti_project_sample_filter',
            'pca_nusc_sample_filter_transform', 'pca_nusc_project_cams', 'pca_retransform', 'pca_mark_dynamic',
-           'pca_bev_workspace_bytes', 'pca_bev_generate', 'pca_bev_generate_ex', 'pca_voxel_dedup_workspace_bytes', 'pca_voxel_dedup', 'pca_icp_workspace_bytes', 'pca_icp_register', 'pca_host_ego_to_grid',
+           'pca_bev_workspace_bytes', 'pca_bev_generate', 'pca_bev_generate_ex', 'pca_bev_warp', 'pca_voxel_dedup_workspace_bytes', 'pca_voxel_dedup', 'pca_icp_workspace_bytes', 'pca_icp_register', 'pca_host_ego_to_grid',
            'pca_profile_enable', 'pca_profile_read')
 
 KERNEL_IDS = ('kitti_project_sample_filter', 'nusc_sample_filter_transform', 'nusc_project_cams', 'retransform',
@@ -104,6 +104,7 @@ def load():
         vp, C.POINTER(PcaStore), vp, vp, i32, i32, i32, i64, C.POINTER(PcaBevParams), C.POINTER(C.c_double), i32,
         vp, i64, vp, vp, vp, vp
     ]
+    lib.pca_bev_warp.argtypes = [vp, vp, vp, i32, i32, C.c_double, C.c_double, C.c_double, C.c_double, vp]
     lib.pca_voxel_dedup_workspace_bytes.restype = C.c_int64
     lib.pca_voxel_dedup_workspace_bytes.argtypes = [i64, i32]
     lib.pca_voxel_dedup.argtypes = [vp, C.POINTER(PcaStore), vp, i32, i32, C.c_double, i64, vp, i64, vp]

@@ -268,7 +268,6 @@ class DeviceStore:
         if self._pending is not None:
             if first_frame == 0 and self._pending[1] <= self.head + last_frame:
                 pend_T, pend_end = _lib.f64_array(self._pending[0], 16), self._pending[1]
-                self._pending = None
             else:
                 self.flush_pending()
         if extra is not None:
@@ -280,6 +279,8 @@ class DeviceStore:
                                           self._ws.data_ptr(), self._ws.numel(),
                                           None if p64 is None else p64.data_ptr(), p16.data_ptr(),
                                           None if extra is None else extra.data_ptr(), ctx.stream()))
+        if pend_T is not None:
+            self._pending = None               # only now: a failed call above leaves the owed re-transform owed
         return p16, p64
 
     # ---- host views (synchronise) -----------------------------------------------------------

@@ -5,16 +5,24 @@ The reference calls (kitti360_sem_pc_accum.py:115-127, sem_pc_accum.py:310-315)
     pcd.estimate_normals()                                   # 30 nearest neighbours
     registration_icp(pcd_prev, pcd_new, threshold, init, TransformationEstimationPointToPlane())
 
-and uses ``.transformation`` as T_new_prev.  `GpuIcp.register` runs the same algorithm (defaults of Open3D:
-at most 30 iterations, relative fitness / rmse 1e-6) in HIP kernels (csrc/pca_icp.hip).  Open3D is a third-party,
-unpinned dependency of the reference, so there is no golden vector: parity is UNPINNED and the tests check known
-motions and a k-d-tree CPU model instead.
+and uses ``.transformation`` as T_new_prev.  `GpuIcp.register` runs a point-to-plane ICP of the same shape (defaults of
+Open3D: at most 30 iterations, relative fitness / rmse 1e-6) in HIP kernels (csrc/pca_icp.hip), with two deliberate
+differences: correspondences are searched within min(threshold, MAX_CORR_DIST = 4 m) -- the reference passes 1e3, i.e.
+"every point has a partner" -- and target points outside +-128 m / +-16 m of the sensor are ignored.  So fitness / rmse
+and, within ICP's own tolerance, the pose differ from Open3D's; Open3D is a third-party, unpinned dependency of the
+reference, there is no golden vector: parity is UNPINNED and the tests check known motions and a k-d-tree CPU model.
+It is opt-in (PCA_POSE_PROVIDER=gpu_icp), never a silent fallback.
 """
+import warnings
 import ctypes as C
 
 import numpy as np
 
 from . import _lib
+
+
+MAX_CORR_DIST = 4.0      # csrc/pca_icp.hip ICP_MATCH_RINGS x cell size
+_warned = []
 
 
 class IcpResult:
@@ -53,6 +61,10 @@ class GpuIcp:
     def register(self, source, target, threshold, init=None):
         """T (4,4) with target ~= T source.  source / target: cuda float32 [N,4] (see to_device)."""
         import torch
+        if threshold > MAX_CORR_DIST and not _warned:
+            _warned.append(True)
+            warnings.warn(f'GpuIcp: correspondence distance {threshold} is capped at {MAX_CORR_DIST} m '
+                          '(Open3D would search the whole cloud); fitness / rmse are those of the capped search')
         ctx = _lib.Context.get()
         lib = ctx.lib
         need = lib.pca_icp_workspace_bytes(int(max(source.shape[0], target.shape[0])))

@@ -6,8 +6,10 @@ resident in HBM (the accumulators accept cuda tensors in place of numpy / PIL in
     for observations in loader:
         acc.integrate(observations)
 
-A reader thread fills pinned host buffers and enqueues the copies on a side stream; the consumer's stream waits on
-the copy event, never on the host."""
+A reader thread fills a ring of REUSED pinned host buffers and enqueues the copies on a side stream; the consumer's
+stream waits on the copy event, never on the host, and every handed-out device tensor is registered with the consumer's
+stream (`record_stream`), so the caching allocator cannot recycle its block for a later copy while kernels that read it
+are still queued."""
 import queue
 import threading
 
@@ -50,18 +52,40 @@ class PrefetchingLoader:
     def __len__(self):
         return len(self.loader)
 
+    def _staging(self, name, shape, dtype):
+        """Pinned buffer `name` of the current ring slot, grown on demand and reused from then on."""
+        import torch
+        slot = self._slot
+        n = int(np.prod(shape))
+        buf = slot.get(name)
+        if buf is None or buf.numel() < n or buf.dtype != dtype:
+            buf = slot[name] = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+        return buf[:n].view(*shape)
+
     def _to_device(self, obs):
         import torch
         img, pc, sem_gt = obs
-        host_img = np.ascontiguousarray(np.asarray(img), dtype=np.uint8)
-        pin = [torch.from_numpy(np.ascontiguousarray(pc, dtype=np.float32)).pin_memory(),
-               torch.from_numpy(host_img.copy()).pin_memory(),
-               torch.from_numpy(np.ascontiguousarray(np.asarray(sem_gt)[:, -1]).astype(np.uint8)).pin_memory()]
+        if not hasattr(self, '_ring'):
+            self._ring = [dict() for _ in range(self.depth + 2)]      # one more than can be in flight + being filled
+            self._ring_next = 0
+        self._slot = self._ring[self._ring_next % len(self._ring)]
+        self._ring_next += 1
+        if 'event' in self._slot:
+            self._slot['event'].synchronize()                           # the copy that last read this slot is done
+        host_img = np.array(np.asarray(img), dtype=np.uint8)            # own copy: kept by the accumulator (rgbs)
+        src = [np.ascontiguousarray(pc, dtype=np.float32), host_img,
+               np.ascontiguousarray(np.asarray(sem_gt)[:, -1]).astype(np.uint8)]
+        pin = []
+        for name, a in zip(('pc', 'img', 'sem'), src):
+            buf = self._staging(name, a.shape, torch.from_numpy(a).dtype)
+            buf.copy_(torch.from_numpy(a))
+            pin.append(buf)
         with torch.cuda.stream(self.stream):
             dev = [t.to(self.device, non_blocking=True) for t in pin]
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        return (DeviceImage(host_img, dev[1]), dev[0], dev[2]), ev, pin
+        self._slot['event'] = ev
+        return (DeviceImage(host_img, dev[1]), dev[0], dev[2]), ev, dev
 
     def _read(self, idx):
         """read_obs with the label remap done through the composed table (identical result, one pass)."""
@@ -109,7 +133,9 @@ class PrefetchingLoader:
                 return
             if isinstance(item, BaseException):
                 raise item
-            for _, ev, _ in item:
-                torch.cuda.current_stream(self.device).wait_event(ev)
-            self._keepalive = item               # pinned staging stays alive until the next batch is handed out
+            cur = torch.cuda.current_stream(self.device)
+            for _, ev, dev in item:
+                cur.wait_event(ev)
+                for t in dev:                    # allocated on the copy stream, used on the consumer's from here on
+                    t.record_stream(cur)
             yield [obs for obs, _, _ in item]

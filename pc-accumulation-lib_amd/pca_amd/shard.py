@@ -126,7 +126,9 @@ def gather_to_rank0(local, group=None, async_op=False, sizes=None):
         padded = torch.zeros((n_max, ) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         padded[:local.shape[0]] = local
     bufs = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
-    work = dist.gather(padded.contiguous(), bufs, dst=0, group=group, async_op=async_op)
+    # `rank` is the rank inside `group`; dist.gather wants the GLOBAL rank of the destination
+    dst = 0 if group is None else dist.get_global_rank(group, 0)
+    work = dist.gather(padded.contiguous(), bufs, dst=dst, group=group, async_op=async_op)
     if async_op:
         return _PendingGather(work, bufs, sizes)
     if rank != 0:

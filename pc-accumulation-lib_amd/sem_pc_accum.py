@@ -204,6 +204,34 @@ class SemanticPointCloudAccumulator:
         homo = np.concatenate((pc_velo, np.ones((pc_velo.shape[0], 1))), axis=1)
         return np.matmul(P_velo_frame, homo.T).T
 
+    def velo2img(self, pc_velo, P_velo_frame, img_h, img_w, max_depth=np.inf):
+        """(N,4) velodyne rows -> (M,6) rows [x, y, z, i, u, v] of the points that project inside the image (host
+        helper for direct callers, the reference's expressions: sem_pc_accum.py:367-402; integrate() runs K1)."""
+        frame = self.velo2frame(pc_velo[:, :3], P_velo_frame)
+        depth = frame[:, 2]
+        depth[depth == 0] = -1e-6
+        u = np.round(frame[:, 0] / np.abs(depth)).astype(int)
+        v = np.round(frame[:, 1] / np.abs(depth)).astype(int)
+        inside = (u >= 0) & (u < img_w) & (v >= 0) & (v < img_h) & (depth > 0) & (depth < max_depth)
+        return np.concatenate([pc_velo, u[:, None], v[:, None]], axis=1)[inside]
+
+    def viz_sem_vec_space(self):
+        """Open3D window with every stored point (host copy of the device store) and the ego path."""
+        self.viz_sem_pc(np.concatenate(self.sem_pcs, axis=0), self.poses)
+
+    @staticmethod
+    def viz_sem_pc(sem_pc: np.array, poses: list = []):
+        """sem_pc: (N,>=7) rows [x, y, z, intensity, r, g, b, ...]; poses: list of [x, y, z].  Needs open3d."""
+        import open3d as o3d
+        cloud = o3d.geometry.PointCloud()
+        cloud.points = o3d.utility.Vector3dVector(sem_pc[:, :3])
+        cloud.colors = o3d.utility.Vector3dVector(np.asarray(sem_pc[:, 4:7], dtype=np.float64) / 255.)
+        frame = o3d.geometry.TriangleMesh.create_coordinate_frame(size=1, origin=poses[0] if len(poses) else [0, 0, 0])
+        path = o3d.geometry.LineSet(points=o3d.utility.Vector3dVector(poses),
+                                    lines=o3d.utility.Vector2iVector([[k, k + 1] for k in range(len(poses) - 1)]))
+        path.colors = o3d.utility.Vector3dVector([[1, 0, 0]] * max(len(poses) - 1, 0))
+        o3d.visualization.draw_geometries([frame, path, cloud])
+
     # ---- BEV -------------------------------------------------------------------------------------
     def viz_bev(self, bev, file_path, rgbs: list = [], semsegs: list = []):
         self.sem_bev_generator.viz_bev(bev, file_path, rgbs, semsegs)
@@ -220,7 +248,8 @@ class SemanticPointCloudAccumulator:
             (present_idx if present_idx >= 0 else self.store.n_frames + present_idx)
         if split <= 0:
             raise ValueError('need at least one array to concatenate')     # np.concatenate([]) in the reference
-        win = DeviceWindow(self.store, split, origin)
+        all_sets = present_idx is None and gen_future        # the reference slices [:None] and [None:]: everything
+        win = DeviceWindow(self.store, split, origin, future_is_present=all_sets)
         pcs = {'pc_present': win.part('present')}
         rel = poses - origin
         trajs = {'ego_traj_present': rel[:present_idx]}
@@ -229,13 +258,14 @@ class SemanticPointCloudAccumulator:
         if gt_lanes is not None:
             trajs['gt_lanes'] = [lane - origin for lane in gt_lanes]
         if gen_future:
-            if split >= self.store.n_frames:
+            if split >= self.store.n_frames and not all_sets:
                 raise ValueError('need at least one array to concatenate')
             pcs['pc_future'] = win.part('future')
             pcs['pc_full'] = win.part('full')
             trajs['ego_traj_future'] = rel[present_idx:]
             trajs['ego_traj_full'] = rel
-            trajs['_ego_split'] = split
+            if not all_sets:
+                trajs['_ego_split'] = split
             trajs['other_trajs_future'] = [np.concatenate([t]) - origin for t in others[1]]
             trajs['other_trajs_full'] = [np.concatenate([t]) - origin for t in others[2]]
         else:

@@ -501,3 +501,140 @@ def test_nuscenes_dataloader_projection_chain_on_device(golden):
                         'ego_global_x', 'ego_global_y'}
     with pytest.raises(TypeError):
         NuScenesDataloader(FakeNusc())                       # scene_ids=None: range(list), as in the reference
+
+
+# ---------------------------------------------------------------------------------------------------------------
+#  round-2 additions: device warp, all-sets window, rotation check, pose source, velo2img
+# ---------------------------------------------------------------------------------------------------------------
+def _bev_e_inputs(g):
+    present, future = g['pc_present'], g['pc_future']
+    pcs = dict(pc_present=present.copy(), pc_future=future.copy(), pc_full=np.concatenate([present, future]))
+    trajs = {}
+    for k in ('ego_traj_present', 'ego_traj_future', 'ego_traj_full'):
+        trajs[k] = g['in_' + k].copy()
+    for k in ('other_trajs_present', 'other_trajs_future', 'other_trajs_full'):
+        trajs[k] = [g[f'in_{k}_{i}'].copy() for i in range(int(g[f'in_{k}_n']))]
+    return pcs, trajs
+
+
+def test_device_only_with_warp_is_warped_on_the_device(golden):
+    """device_only=True + do_warp=True: the planes that stay in HBM are the reference's warped planes (pca_bev_warp),
+    also when the caller names the output tensor; trajectories are warped too."""
+    import torch
+
+    from bev_generator.sem_bev import SemBEVGenerator
+    g = golden('bev_e')
+    for use_out in (False, True):
+        gen = SemBEVGenerator(SEM_IDXS, 20, 32, 0., 0., True, 20., 20., 0.5, None)
+        w = tuple(g['warp'])
+        gen.get_random_warp_params = lambda *a: w
+        pcs, trajs = _bev_e_inputs(g)
+        out = torch.zeros((21, 32, 32), dtype=torch.float16, device='cuda') if use_out else None
+        res = gen.generate(pcs, trajs, device_only=True, out=out)
+        p16 = res['planes_f16']
+        if use_out:
+            assert p16.data_ptr() == out.data_ptr()
+        bev = SemBEVGenerator.pack_bev(p16.cpu().numpy(), res['trajs_present'], res['trajs_future'], res['trajs_full'])
+        check_bev(bev, g)
+
+
+def test_warp_kernel_matches_numpy_gather(golden):
+    """pca_bev_warp on random planes and coefficient pairs against the vectorised numpy form (itself pinned on the
+    reference's loop by utils.npz: wp_in / wp_out)."""
+    import torch
+
+    from bev_generator.sem_bev import SemBEVGenerator
+    from pca_amd import host_logic as hl
+    rng = np.random.default_rng(4)
+    for px, iw, jw in ((32, 19.7, 13.8), (64, 25.0, 40.5), (256, 140.2, 111.9), (31, 12.2, 18.8)):
+        a1, a2 = hl.cal_warp_params(iw, int(px / 2), px - 1)
+        b1, b2 = hl.cal_warp_params(jw, int(px / 2), px - 1)
+        planes = rng.random((5, px, px))
+        want = hl.warp_dense_probmaps(planes, a1, a2, b1, b2).astype(np.float16)
+        got = SemBEVGenerator.warp_planes_device(torch.from_numpy(planes.astype(np.float16)).cuda(), a1, a2, b1, b2)
+        assert np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16)), px
+
+
+def test_bev_rejects_a_rotation_that_is_not_about_z():
+    import torch
+
+    from pca_amd import host_logic as hl
+    from pca_amd.device_store import DeviceStore, make_bev_params
+    st = DeviceStore(capacity=1024, max_frames=4)
+    rows = np.zeros((10, 10))
+    rows[:, :3] = np.random.default_rng(0).uniform(-5, 5, (10, 3))
+    st.load_rows([rows])
+    c, s = np.cos(0.3), np.sin(0.3)
+    tilt = np.array([[1, 0, 0], [0, c, -s], [0, s, c]]) @ hl.rotation_matrix_3d(0.2)
+    args = ([0., 0., 0.], tilt, 0., 0., 20., 16, None, 20., 20., 0.5, 0, [13], False)
+    with pytest.raises(RuntimeError, match='rotation about the z axis'):
+        st.bev(1, make_bev_params(*args))
+    args = ([0., 0., 0.], hl.rotation_matrix_3d(0.2), 0., 0., 20., 16, None, 20., 20., 0.5, 0, [13], False)
+    p16, _ = st.bev(1, make_bev_params(*args))
+    assert tuple(p16.shape) == (21, 16, 16) and torch.isfinite(p16.float()).all()
+
+
+def test_generate_bev_without_present_idx_uses_the_whole_window_for_every_set(golden):
+    """generate_bev(present_idx=None, gen_future=True): the reference slices [:None] and [None:], so present, future and
+    full are all the whole window (and all poses)."""
+    from PIL import Image
+
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    g = golden('kitti_gtsem')
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': g['P']}
+    acc = Kitti360SemanticPointCloudAccumulator(50., calib, 1e3, None, KITTI_FILTERS, SEM_IDXS, True, dict(BEV_KITTI))
+    queue = list(g['Ts'])
+    acc.pose_provider = lambda pc: queue.pop(0)
+    dummy = Image.fromarray(np.zeros((64, 96, 3), np.uint8))
+    for k in range(4):
+        acc.integrate([(dummy, g[f'pc_{k}'], g[f'sem_gt_{k}'])])
+    bev_all = acc.generate_bev(None, 1, gen_future=True)[0]
+    for key in ('road', 'intensity', 'rgb', 'dynamic', 'elevation'):
+        for s in ('present', 'future'):
+            assert np.array_equal(bev_all[f'{key}_{s}'].view(np.uint16), bev_all[f'{key}_full'].view(np.uint16)), (key, s)
+    assert (bev_all['road_full'] != np.float16(0.5)).sum() > 10          # the window is in view
+    n = len(acc.poses)
+    assert len(bev_all['trajs_present']) == len(bev_all['trajs_future']) == len(bev_all['trajs_full']) == 1
+    # 'full' of an ordinary call with the same origin and heading holds the same points: present_idx = -1 is not the
+    # same call (its present set ends one frame early), so the equality is checked against the host-array path
+    from bev_generator.sem_bev import SemBEVGenerator
+    rows = np.concatenate(acc.sem_pcs)
+    rows[:, :3] -= np.array(acc.poses[-1])
+    rel = np.array(acc.poses) - np.array(acc.poses[-1])
+    gen = SemBEVGenerator(SEM_IDXS, BEV_KITTI['view_size'], BEV_KITTI['pixel_size'], 0., 0., False,
+                          BEV_KITTI['int_scaler'], BEV_KITTI['int_sep_scaler'], BEV_KITTI['int_mid_threshold'],
+                          BEV_KITTI['height_filter'])
+    host = gen.generate(dict(pc_present=rows, pc_future=rows, pc_full=rows),
+                        dict(ego_traj_present=rel, ego_traj_future=rel, ego_traj_full=rel, other_trajs_present=[],
+                             other_trajs_future=[], other_trajs_full=[]))
+    for key in ('road', 'rgb', 'dynamic', 'elevation'):
+        assert np.array_equal(bev_all[f'{key}_full'].view(np.uint16), host[f'{key}_full'].view(np.uint16)), key
+    assert n == 4
+
+
+def test_default_pose_source_is_open3d_and_raises_without_it(monkeypatch):
+    import builtins
+
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    monkeypatch.delenv('PCA_POSE_PROVIDER', raising=False)
+    monkeypatch.delenv('PCA_KITTI_T_FILE', raising=False)
+    real_import = builtins.__import__
+
+    def no_open3d(name, *a, **k):
+        if name == 'open3d':
+            raise ImportError('no open3d')
+        return real_import(name, *a, **k)
+    monkeypatch.setattr(builtins, '__import__', no_open3d)
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': np.eye(4)[:3]}
+    acc = Kitti360SemanticPointCloudAccumulator(8., calib, 1e3, None, KITTI_FILTERS, SEM_IDXS, True, dict(BEV_KITTI))
+    with pytest.raises(ImportError, match='PCA_POSE_PROVIDER=gpu_icp'):
+        acc.pose_provider(np.zeros((10, 4), np.float32))
+
+
+def test_velo2img_matches_reference(golden):
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    g = golden('k1')
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': g['P']}
+    acc = Kitti360SemanticPointCloudAccumulator(8., calib, 1e3, None, KITTI_FILTERS, SEM_IDXS, True, dict(BEV_KITTI))
+    assert np.array_equal(acc.velo2img(g['pc'].copy(), g['P'], int(g['H']), int(g['W'])), g['velo2img'])
+    assert np.array_equal(acc.velo2img(g['pc2'].copy(), g['P2'], int(g['H']), int(g['W'])), g['velo2img2'])

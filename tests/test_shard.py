@@ -117,3 +117,39 @@ def test_gather_without_process_group_is_identity():
     t = torch.zeros((2, 21, 4, 4), dtype=torch.float16)
     assert shard.gather_to_rank0(t)[0] is t
     assert shard.gather_to_rank0(t, async_op=True).wait()[0].data_ptr() == t.data_ptr()
+
+
+def _worker_subgroup(rank, world, port, out):
+    """gather_to_rank0 inside a sub-group that does not contain global rank 0."""
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    group = dist.new_group([1, 2])                    # every rank has to make the call
+    ok = True
+    if rank in (1, 2):
+        local = torch.full((rank + 1, 21, 4, 4), float(rank), dtype=torch.float16)
+        got = shard.gather_to_rank0(local, group=group)
+        if rank == 1:                                 # group rank 0
+            ok = len(got) == 2 and got[0].shape[0] == 2 and got[1].shape[0] == 3 and float(got[1][0, 0, 0, 0]) == 2.0
+        else:
+            ok = got is None
+    out[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_to_rank0_in_a_subgroup_without_global_rank0():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as m:
+        out = m.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_subgroup, args=(r, 3, port, out)) for r in range(3)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        assert all(out[r] is True for r in range(3))

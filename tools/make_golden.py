@@ -637,6 +637,29 @@ def case_utils(ref, out_dir):
     print('utils written')
 
 
+def case_sweeps(ref, out_dir):
+    """The reference's inst_centric_get_sweeps + load_data_to_tensor on a fake dataset object (tests/fake_nuscenes.py):
+    inputs (the tables) and outputs (points, tokens, centres, last boxes, class indices)."""
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+    import fake_nuscenes as fk
+    ref.nu.Quaternion = fk.FakeQuaternion          # pyquaternion stand-in (textbook formula; third-party, unpinned)
+    tables = fk.synth_tables()
+    with tempfile.TemporaryDirectory() as tmp:
+        nusc = fk.FakeNuScenes(tables, tmp)
+        res = ref.nu.inst_centric_get_sweeps(nusc, 'sample0', **fk.SWEEP_CFG)
+        ref.nu.load_data_to_tensor(res)
+    out = {'in_' + k: np.asarray(v) for k, v in tables.items()}
+    out['points'] = res['points'].numpy()
+    out['instances_token'] = np.array(res['instances_token'])
+    out['instances_center'] = np.stack(res['instances_center'])
+    out['instances_last_box'] = res['instances_last_box'].numpy()
+    out['instances_name'] = res['instances_name'].numpy()
+    assert (out['points'][:, 6] >= 0).sum() > 50 and len(set(res['instances_token'])) >= 4
+    np.savez_compressed(os.path.join(out_dir, 'nusc_sweeps.npz'), **out)
+    print('nusc_sweeps written:', out['points'].shape, len(res['instances_token']), 'labelled boxes')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(
@@ -648,7 +671,7 @@ def main():
     np.random.seed(0)
     ref = import_reference()
     cases = dict(k1=case_k1, kitti=case_kitti_accum, bev=case_bev,
-                 nusc=case_nusc, utils=case_utils)
+                 nusc=case_nusc, utils=case_utils, sweeps=case_sweeps)
     for name, fn in cases.items():
         if args.only and name not in args.only.split(','):
             continue
