@@ -119,6 +119,13 @@ int pca_nusc_project_cams(pca_ctx *ctx, const double *pc_lidar, int32_t n, const
 int pca_retransform(pca_ctx *ctx, const pca_store *store, const int64_t *frame_off /*dev*/, int slot_begin,
                     int slot_end, const double *Ts, int n_T, void *stream);
 
+/* Batched integrate: k frames appended by ONE K1 call into slots first_slot .. first_slot+k-1, with the per-frame
+ * transforms Ts[0..k) (Ts[i] = T_new_prev of frame i).  Frame i still owes Ts[i+1] .. Ts[k-1] (the reference applies
+ * them one integrate() at a time, sem_pc_accum.py:167-183); this applies them, frame by frame, in ceil((k-1)/16)
+ * launches with the roundings of the step-by-step form.  (Frames stored BEFORE the batch owe all k: pca_retransform.) */
+int pca_retransform_batch_tail(pca_ctx *ctx, const pca_store *store, const int64_t *frame_off /*dev*/, int first_slot,
+                               int n_frames, const double *Ts, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K3  dyn[p] = 1 where inst[p] == inst_idx, for n_pairs (slot, inst_idx) pairs.
  *     Replaces nuscenes_oracle_sem_pc_accum.py:223-229, :243-250.

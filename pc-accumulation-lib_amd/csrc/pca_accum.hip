@@ -247,6 +247,35 @@ __global__ __launch_bounds__(SBLK) void k2_retransform(const K2Args a)
     }
 }
 
+// Batched integrate: frame i of a batch of k frames appended in one K1 call still owes the transforms of the frames
+// that came after it, T[i+1] .. T[k-1] (sem_pc_accum.py:167-183 applied step by step).  One launch per pass of
+// MAX_CHAIN transforms: blockIdx.y = frame of the batch, which applies the transforms t >= i + 1 of the pass.
+struct K2TailArgs {
+    double *x, *y, *z;
+    const int64_t *frame_off;
+    int first_slot;          // slot of frame 0 of the batch
+    int t_base, n_T;         // the pass holds transforms t_base .. t_base + n_T - 1
+    Mat34 T[MAX_CHAIN];
+};
+
+__global__ __launch_bounds__(SBLK) void k2_retransform_tail(const K2TailArgs a)
+{
+    const int i = blockIdx.y;
+    int t0 = i + 1 - a.t_base;                   // first transform of this pass that frame i owes
+    if (t0 < 0) t0 = 0;
+    if (t0 >= a.n_T) return;
+    const int64_t lo = a.frame_off[a.first_slot + i], hi = a.frame_off[a.first_slot + i + 1];
+    for (int64_t p = lo + (int64_t)blockIdx.x * SBLK + threadIdx.x; p < hi; p += (int64_t)gridDim.x * SBLK) {
+        double x = a.x[p], y = a.y[p], z = a.z[p];
+        for (int t = t0; t < a.n_T; ++t) {
+            const double *m = a.T[t].m;
+            const double nx = row4(m + 0, x, y, z), ny = row4(m + 4, x, y, z), nz = row4(m + 8, x, y, z);
+            x = nx; y = ny; z = nz;
+        }
+        a.x[p] = x; a.y[p] = y; a.z[p] = z;
+    }
+}
+
 // =============================================================================================
 // K3  flag points of an instance as dynamic
 // =============================================================================================
@@ -486,6 +515,30 @@ int pca_retransform(pca_ctx *ctx, const pca_store *store, const int64_t *frame_o
         for (int t = 0; t < a.n_T; ++t)
             for (int i = 0; i < 12; ++i) a.T[t].m[i] = Ts[(int64_t)(t0 + t) * 16 + i];
         PCA_LAUNCH(ctx, PCA_K_RETRANSFORM, k2_retransform, dim3(2048), dim3(SBLK), s, a);
+        PCA_CHECK(ctx, hipGetLastError());
+    }
+    return 0;
+}
+
+int pca_retransform_batch_tail(pca_ctx *ctx, const pca_store *store, const int64_t *frame_off, int first_slot, int n_frames,
+                               const double *Ts, void *stream)
+{
+    if (!ctx) return -1;
+    if (!store || !frame_off || !Ts || n_frames < 0 || n_frames > 65535) { ctx->err = "k2 tail: bad arguments"; return -1; }
+    if (n_frames < 2) return 0;                  // a single frame owes nothing
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    for (int t0 = 1; t0 < n_frames; t0 += MAX_CHAIN) {          // transform 0 is owed by nobody in the batch
+        K2TailArgs a;
+        a.x = store->x; a.y = store->y; a.z = store->z;
+        a.frame_off = frame_off; a.first_slot = first_slot;
+        a.t_base = t0;
+        a.n_T = (n_frames - t0) < MAX_CHAIN ? (n_frames - t0) : MAX_CHAIN;
+        for (int t = 0; t < a.n_T; ++t)
+            for (int i = 0; i < 12; ++i) a.T[t].m[i] = Ts[(int64_t)(t0 + t) * 16 + i];
+        // frames t0 + n_T - 1 and later owe nothing of this pass
+        const int rows = t0 + a.n_T - 1 < n_frames ? t0 + a.n_T - 1 : n_frames;
+        PCA_LAUNCH(ctx, PCA_K_RETRANSFORM, k2_retransform_tail, dim3(32, rows), dim3(SBLK), s, a);
         PCA_CHECK(ctx, hipGetLastError());
     }
     return 0;

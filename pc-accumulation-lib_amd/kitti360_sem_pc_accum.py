@@ -130,6 +130,58 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         self._after_integrate()
         return idx
 
+    def integrate_many(self, batch: list, max_frames_per_launch: int = 64):
+        """Extension (no reference counterpart): integrates a list of observation lists -- what integrate() would be
+        handed call by call -- with ONE fused K1 call per <= max_frames_per_launch frames and one re-transform pass for
+        the frames stored before, instead of a K1 + K2 pair per frame.  Stored points, poses, segment distances and
+        evictions are those of the call-by-call form, bit for bit (the transforms a point owes are applied in the same
+        order with the same roundings).  Returns the list of integrate()'s return values.  The sharded runner uses it for
+        the warm-up prefix of a chunk, where no BEV sample is taken between frames."""
+        if self.voxel_dedup:                           # the opt-in de-duplication runs between frames: keep that order
+            return [self.integrate(obs) for obs in batch]
+        out = []
+        for b0 in range(0, len(batch), max_frames_per_launch):
+            out += self._integrate_batch(batch[b0:b0 + max_frames_per_launch])
+        return out
+
+    def _integrate_batch(self, batch):
+        frames, Ts, shape = [], [], None
+        for observations in batch:
+            rgb, pc, sem_gt = observations[0]
+            if not self.use_gt_sem:
+                sem_gt = None
+            T_new_prev = np.asarray(self.pose_provider(pc), dtype=np.float64)
+            self.T_prev_origin = np.matmul(self.T_prev_origin, T_new_prev)
+            frame, semseg, H, W = self._frame_tensors(rgb, pc, sem_gt)
+            if shape not in (None, (H, W)):
+                raise ValueError('integrate_many: all images of a batch must have one size')
+            shape = (H, W)
+            frames.append(frame)
+            Ts.append(T_new_prev)
+            self.rgbs.append(rgb)
+            self.semsegs.append(semseg)
+        self.store.flush_pending()
+        self.store.append_kitti(frames, self.P_velo_frame, shape[0], shape[1], self.semseg_filters)
+        self.store.retransform_batch(np.stack(Ts), len(frames))
+        removed, total = [], 0
+        for T_new_prev in Ts:                           # host bookkeeping, frame by frame as integrate() does
+            if len(self._track) > 0:
+                self.update_poses(T_new_prev)
+            self._track.append([0., 0., 0.])
+            idx = 0
+            if len(self._track) > 1:
+                path_length = self._track.push_segment()
+                idx = self._track.evict_beyond(self.horizon_dist, path_length)
+                print(f'    #pc {len(self._track)} |', f'path length {path_length:.2f}')
+            removed.append(idx)
+            total += idx
+            self._integrated += 1
+        if total:
+            self.store.evict(total)
+            self.rgbs = self.rgbs[total:]
+            self.semsegs = self.semsegs[total:]
+        return removed
+
     def obs2sem_vec_space(self, rgb, pc, sem_gt=None) -> tuple:
         """Host-array form of one observation: ((M,10) rows, pose, semseg, T_new_prev).  integrate() does
         not go through here (it keeps the rows on the device)."""

@@ -17,7 +17,8 @@ STATUS_LOOKBACK_TIMEOUT = 8
 
 EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error', 'pca_status',
            'pca_kitti_project_sample_filter',
-           'pca_nusc_sample_filter_transform', 'pca_nusc_project_cams', 'pca_retransform', 'pca_mark_dynamic',
+           'pca_nusc_sample_filter_transform', 'pca_nusc_project_cams', 'pca_retransform', 'pca_retransform_batch_tail',
+           'pca_mark_dynamic',
            'pca_bev_workspace_bytes', 'pca_bev_generate', 'pca_bev_generate_ex', 'pca_bev_warp', 'pca_voxel_dedup_workspace_bytes', 'pca_voxel_dedup', 'pca_icp_workspace_bytes', 'pca_icp_register', 'pca_host_ego_to_grid',
            'pca_profile_enable', 'pca_profile_read')
 
@@ -93,6 +94,7 @@ def load():
         C.POINTER(C.c_double), C.POINTER(C.c_double), i32, vp, vp, vp, vp
     ]
     lib.pca_retransform.argtypes = [vp, C.POINTER(PcaStore), vp, i32, i32, C.POINTER(C.c_double), i32, vp]
+    lib.pca_retransform_batch_tail.argtypes = [vp, C.POINTER(PcaStore), vp, i32, i32, C.POINTER(C.c_double), vp]
     lib.pca_mark_dynamic.argtypes = [vp, C.POINTER(PcaStore), vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32, vp]
     lib.pca_bev_workspace_bytes.argtypes = [i64, i32]
     lib.pca_bev_workspace_bytes.restype = i64

@@ -208,6 +208,22 @@ class DeviceStore:
         ctx.check(ctx.lib.pca_retransform(ctx.h, C.byref(st), self.frame_off.data_ptr(), self.head, end_slot,
                                           _lib.f64_array(Ts, Ts.size), Ts.shape[0], ctx.stream()))
 
+    def retransform_batch(self, Ts, n_new):
+        """After append_kitti of `n_new` frames in one call: applies the per-frame transforms Ts (n_new,4,4) exactly as
+        n_new successive integrate() steps would have -- frames stored before the batch get all of them, frame i of the
+        batch gets Ts[i+1:] (nothing is ever transformed by its own frame's T)."""
+        Ts = np.ascontiguousarray(Ts, dtype=np.float64).reshape(-1, 16)
+        assert Ts.shape[0] == n_new
+        self.flush_pending()
+        first_new = self.tail - n_new
+        if first_new > self.head:
+            st, ctx = self.c_store(), self.ctx
+            ctx.check(ctx.lib.pca_retransform(ctx.h, C.byref(st), self.frame_off.data_ptr(), self.head, first_new,
+                                              _lib.f64_array(Ts, Ts.size), Ts.shape[0], ctx.stream()))
+        st, ctx = self.c_store(), self.ctx
+        ctx.check(ctx.lib.pca_retransform_batch_tail(ctx.h, C.byref(st), self.frame_off.data_ptr(), first_new, n_new,
+                                                     _lib.f64_array(Ts, Ts.size), ctx.stream()))
+
     def flush_pending(self):
         if self._pending is not None:
             T, end_slot = self._pending

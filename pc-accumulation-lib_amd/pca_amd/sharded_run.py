@@ -1,0 +1,122 @@
+"""Sharded KITTI-360 BEV generation: one process per GPU, sequences cut into chunks with a warm-up prefix, no
+collective during compute.
+
+The reference's driver (run_kitti360_bev_gen.py:156-280) walks the frames of a sequence, integrates each one and, when
+three pose-only conditions hold (:218-240), takes a BEV sample.  With the poses known up front (GT poses, or a file of
+T_new_prev matrices) that loop shards:
+
+  1. pose-only pass (`replay`): the sample jobs (frame, present frame) of every sequence -- the decisions of the
+     sequential run, replayed with its own host expressions, whatever the cut;
+  2. `plan`: sequences are cut BETWEEN frames into chunks balanced by frame count (`shard.plan_chunks`); a chunk's warm-up
+     starts just before the oldest frame the sequential run still holds when it reaches the chunk's first frame, so from
+     that frame on the chunk's accumulation window holds what the sequential one holds;
+  3. `run_chunk`: warm-up frames go through `integrate_many` (batched K1, no samples), the chunk's own frames through
+     `integrate` + `generate_bev` at the sample jobs; the stored points of a frame depend only on its own observation and
+     on the transforms applied since, so the BEVs are bit-identical to the sequential run's (tested);
+  4. every rank keeps / writes the BEVs it made (`AsyncBevWriter`, one file per sample as the reference) or streams them
+     to rank 0 in asynchronous batches (`shard.gather_to_rank0`, RCCL over xGMI).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import host_logic as hl
+from . import shard
+
+
+def replay(Ts, accum_horizon=200., bev_horizon=80., min_spacing=1.):
+    """Host replay of what the sequential run does with the poses: the accumulator's pose track (re-expression by every
+    T_new_prev, segment distances, horizon eviction: sem_pc_accum.py:156-228) and the driver's three sample conditions
+    (run_kitti360_bev_gen.py:218-240), with the very same numpy expressions -- so its decisions are the sequential run's,
+    ties included.  Ts: (F,4,4) T_new_prev per frame.
+    Returns (oldest, samples): oldest[f] = number of the oldest frame still stored after frame f was integrated;
+    samples = [(frame, present frame number)] -- frame NUMBERS, not window indices: they mean the same in any chunk."""
+    Ts = np.asarray(Ts, dtype=np.float64).reshape(-1, 4, 4)
+    track = hl.PoseTrack()
+    oldest, evicted, previous_idx, samples = [], 0, 0, []
+    for f in range(Ts.shape[0]):
+        if len(track) > 0:
+            track.apply_transform(Ts[f])
+        track.append([0., 0., 0.])
+        removed = 0
+        if len(track) > 1:
+            removed = track.evict_beyond(accum_horizon, track.push_segment())
+        evicted += removed
+        oldest.append(evicted)
+        previous_idx -= removed
+        if len(track) < 2:
+            continue
+        d = hl.incremental_path_dists(track.seg_array())
+        if d[-1] < bev_horizon:
+            continue
+        present_idx = int(((d - bev_horizon) > 0).argmax())
+        if d[-1] - d[present_idx] < bev_horizon:
+            continue
+        if hl.pose_dist(track.pose(previous_idx), track.pose(present_idx)) < min_spacing:
+            continue
+        previous_idx = present_idx
+        samples.append((f, evicted + present_idx))
+    return oldest, samples
+
+
+@dataclass
+class ChunkJob:
+    seq: int
+    warm_start: int     # first frame integrated; frames before `start` emit no samples
+    start: int
+    end: int
+    samples: list = field(default_factory=list)      # (frame, present frame number) with start <= frame < end
+
+    @property
+    def cost(self):
+        return self.end - self.warm_start
+
+
+def plan(seq_Ts, n_ranks, accum_horizon=200., bev_horizon=80., min_spacing=1., max_imbalance=1.05):
+    """seq_Ts: per sequence the (F,4,4) T_new_prev.  Returns (jobs per rank, load per rank [frames incl. warm-up],
+    sample jobs per sequence).  A chunk's warm-up starts one frame before the oldest frame the sequential run still
+    stores when it integrates the chunk's first frame: from `start` on the chunk then holds every frame the sequential
+    run holds (a frame at exactly one horizon's distance may be kept by one and dropped by the other -- it lies 120 m
+    or more outside any BEV view)."""
+    lengths = [int(np.asarray(T).reshape(-1, 16).shape[0]) for T in seq_Ts]
+    rep = [replay(T, accum_horizon, bev_horizon, min_spacing) for T in seq_Ts]
+    per_rank, _ = shard.plan_chunks(lengths, n_ranks, warmup_frames=0, max_imbalance=max_imbalance)
+    jobs = []
+    for c in (c for r in per_rank for c in r):
+        oldest, samples = rep[c.seq]
+        warm = 0 if c.start == 0 else max(0, oldest[c.start] - 1)
+        jobs.append(ChunkJob(c.seq, warm, c.start, c.end, [(f, p) for f, p in samples if c.start <= f < c.end]))
+    items, loads = shard.lpt_assign([j.cost for j in jobs], n_ranks)       # re-balance with the real warm-up cost
+    out = [sorted((jobs[i] for i in it), key=lambda j: (j.seq, j.start)) for it in items]
+    return out, loads, [r[1] for r in rep]
+
+
+def run_chunk(acc, get_obs, job, on_sample, warm_batch=64):
+    """Runs one chunk on a FRESH accumulator.  get_obs(frame) -> the observations list integrate() takes;
+    on_sample(frame, present_idx) is called right after `frame` was integrated, present_idx being the index of the
+    job's present frame in the accumulator's live window.  Returns the number of samples taken."""
+    frames = list(range(job.warm_start, job.start))
+    for b0 in range(0, len(frames), warm_batch):
+        acc.integrate_many([get_obs(f) for f in frames[b0:b0 + warm_batch]])
+    todo = dict(job.samples)
+    taken = 0
+    for f in range(job.start, job.end):
+        acc.integrate(get_obs(f))
+        if f in todo:
+            oldest_here = f + 1 - len(acc.poses)          # number of the oldest frame this accumulator holds
+            on_sample(f, todo[f] - oldest_here)
+            taken += 1
+    return taken
+
+
+def run_rank(rank_jobs, make_accumulator, get_obs_for, on_bev, warm_batch=64, bev_num=1):
+    """All chunks of one rank.  make_accumulator(seq) -> fresh accumulator; get_obs_for(seq) -> get_obs callable;
+    on_bev(seq, frame, bevs) receives generate_bev's list.  Returns the number of samples."""
+    n = 0
+    for job in rank_jobs:
+        acc = make_accumulator(job.seq)
+
+        def on_sample(f, present_idx, acc=acc, job=job):
+            on_bev(job.seq, f, acc.generate_bev(present_idx, bev_num, gen_future=True))
+        n += run_chunk(acc, get_obs_for(job.seq), job, on_sample, warm_batch)
+    return n
