@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mpoints/s projected+accumulated and BEV frames/s @256x256 (BASELINE.json).
 
-Workload (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): KITTI-360-shaped synthetic frames
-(120 000 points f32, 376x1408 RGB + semseg), 200 m accumulation horizon at 1 m / frame (~200 live
-frames, ~5 M stored points), one 256x256 x 21-plane BEV per integrated frame.
+Workload at every N (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): KITTI-360-shaped synthetic frames (120 000 points
+f32, 376x1408 RGB + semseg), 200 m accumulation horizon at 1 m / frame (~200 live frames, ~5 M stored points), one
+256x256 x 21-plane BEV per integrated frame; every rank runs its own sequence (weak scaling, no data-path collective).
 
-One STEP = integrate one frame  (K2 re-transform of every stored point + K1 fused project / sample /
-filter / append + horizon eviction)  +  generate one BEV sample (bin, scan, scatter, per-cell reduce).
-Inputs (point clouds, images, semseg maps) are resident in HBM before the timed region; BEV tensors
-stay in HBM on the rank that made them (multi-GPU: no data-path collective; --gather streams them to rank 0 over RCCL
-inside the timed region, chunk by chunk, overlapped with compute).
+One STEP = integrate one frame (K1 fused project / sample / filter / append + the re-transform of every stored point +
+horizon eviction) + generate one BEV sample (bin, scan, scatter, per-cell reduce).  Inputs (point clouds, images, semseg
+maps) are resident in HBM before the timed region; BEV tensors stay in HBM on the rank that made them.  The K-step timed
+region is repeated REPEATS times; `value` / `ms_per_step` are the MEDIAN repeat (min / max beside it).
+
+Beside `value` the JSON line carries (rank 0): per-kernel HIP-event times and the roofline of the dominant unit; the
+batched K1 (the north-star kernel) on 64 frames per call; the same step on ring-model (skewed) frames; BASELINE configs[2]
+(NuScenes kernels at full size), configs[3] (1 M points / frame, 512^2 grid, scaled frame count) and configs[4] (the nine
+KITTI-360 sequences cut into warm-up-prefixed chunks over the ranks -- a STRONG-scaling job whose wall time is reported
+at every N); the PCIe-inclusive step; the CPU baselines (C port and numpy-shaped restatement of the reference).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 8                      # starts its own ranks (torch.distributed.run, RCCL); so does the driver's
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --workload config5 --gpus N   # the sharded nine-sequence job as the headline value (strong scaling)
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,9 +42,12 @@ N_PTS, IMG_H, IMG_W = 120_000, 376, 1408
 HORIZON_M, BEV_HORIZON_M, VIEW_M, PX = 200.0, 80, 80, 256
 FILTERS = [10, 11, 12, 16, 18, 255]
 SEM_IDXS = {'road': 0, 'car': 13, 'truck': 14, 'bus': 15, 'motorcycle': 17}
-POOL = 8                                  # distinct synthetic frames cycled through
+POOL = 8                                  # distinct synthetic frames cycled through by the step loop
+REPEATS = 5                               # repetitions of the K-step timed region (median reported)
 GATHER_CHUNK = 16                         # multi-GPU: BEV samples per asynchronous gather to rank 0
 HBM_PEAK_GBS = 8000.0                     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PROFILE_TAG = 'r02'                       # profiles/<tag>_pmc_traffic.json: rocprofv3 PMC passes of THESE kernels
+KITTI360_LENGTHS = [11270, 14384, 730, 11440, 6610, 9578, 2960, 13855, 3540]   # run_kitti360_bev_gen.py:172-173, end - start
 
 CAM_TO_VELO = np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418],
                         [-0.999004371, 0.007784614041, 0.04392796942, 0.2993489574],
@@ -140,62 +152,86 @@ def present_index(acc):
     return idx
 
 
-def make_accumulator(frame_fn, seq):
-    """Drop-in accumulator over a pool of synthetic frames resident in HBM."""
+def device_pool(frame_fn, seq, n, model=None):
     import torch
+    pool = []
+    for k in range(n):
+        pc, img, sem = frame_fn(seq, k)
+        f = (torch.from_numpy(img).cuda(), torch.from_numpy(pc).cuda(), torch.from_numpy(sem).cuda())
+        if model is not None:
+            model.by_ptr[f[0].data_ptr()] = f[2]
+        pool.append(f)
+    return pool
+
+
+def new_accumulator(model, T=None, bev_px=PX, view=VIEW_M):
+    """Drop-in KITTI accumulator over frames resident in HBM (poses: the synthetic curve)."""
     import sem_pc_accum
     from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
-    model = ResidentSemSeg()
     sem_pc_accum.SemSegONNX = lambda path: model
-    bev_params = dict(type='sem', view_size=VIEW_M, pixel_size=PX, max_trans_radius=0., zoom_thresh=0., do_warp=False,
+    bev_params = dict(type='sem', view_size=view, pixel_size=bev_px, max_trans_radius=0., zoom_thresh=0., do_warp=False,
                       int_scaler=20., int_sep_scaler=20., int_mid_threshold=0.5, height_filter=None)
     calib = {'h_velo_cam': np.linalg.inv(CAM_TO_VELO), 'p_cam_frame': P_RECT, 'p_velo_frame': P_VELO_FRAME}
     acc = Kitti360SemanticPointCloudAccumulator(HORIZON_M, calib, 1e3, 'resident', FILTERS, SEM_IDXS, False, bev_params)
     acc._store_args = dict(capacity=1 << 26, max_frames=1 << 14)
-    T = t_new_prev()
+    T = t_new_prev() if T is None else T
     acc.pose_provider = lambda pc: T
-    pool = []
-    for k in range(POOL):
-        pc, img, sem = frame_fn(seq, k)
-        f = (torch.from_numpy(img).cuda(), torch.from_numpy(pc).cuda(), torch.from_numpy(sem).cuda())
-        model.by_ptr[f[0].data_ptr()] = f[2]
-        pool.append(f)
-    return acc, pool, model
+    return acc
 
 
-def ring_model_pass(steps, frame_fn=None):
-    """The same step on ring-model frames (rank 0 only, after the headline measurement): steady-state time per
-    step and per-kernel HIP-event times.  Reported beside the headline number, never as `value`."""
+def make_accumulator(frame_fn, seq):
+    model = ResidentSemSeg()
+    pool = device_pool(frame_fn, seq, POOL, model)
+    return new_accumulator(model), pool, model
+
+
+class Stepper:
+    """The benchmark step on one accumulator."""
+
+    def __init__(self, acc, pool):
+        self.acc, self.pool, self.n = acc, pool, 0
+
+    def integrate(self):
+        rgb, pc, _ = self.pool[self.n % len(self.pool)]
+        self.n += 1
+        self.acc.integrate([(rgb, pc, None)])
+
+    def step(self, out=None):
+        self.integrate()
+        idx = present_index(self.acc)
+        if idx is None:
+            return None
+        pcs, trajs = self.acc._window_inputs(idx, True)
+        return self.acc.sem_bev_generator.generate(pcs, trajs, device_only=True, out=out)
+
+    def fill(self):
+        while present_index(self.acc) is None or len(self.acc.poses) < 195:
+            self.integrate()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+#  side measurements (rank 0, after the headline; reported beside, never as, `value`)
+# --------------------------------------------------------------------------------------------------------------------
+def ring_model_pass(steps):
+    """The same step on ring-model frames: steady-state time per step and per-kernel HIP-event times."""
     import torch
     from pca_amd import _lib
-    acc, pool, _ = make_accumulator(frame_fn or ring_frame, 0)
-    n = [0]
-
-    def step(out=None):
-        rgb, pc, _ = pool[n[0] % POOL]
-        n[0] += 1
-        acc.integrate([(rgb, pc, None)])
-        idx = present_index(acc)
-        if idx is None:
-            return
-        pcs, trajs = acc._window_inputs(idx, True)
-        acc.sem_bev_generator.generate(pcs, trajs, device_only=True, out=out)
-
-    while present_index(acc) is None or len(acc.poses) < 195:
-        step()
+    acc, pool, _ = make_accumulator(ring_frame, 0)
+    st = Stepper(acc, pool)
+    st.fill()
     out = torch.empty((21, PX, PX), dtype=torch.float16, device='cuda')
     for _ in range(5):
-        step(out)
+        st.step(out)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step(out)
+        st.step(out)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ctx = _lib.Context.get()
     ctx.profile(True)
     for _ in range(steps):
-        step(out)
+        st.step(out)
     prof = ctx.profile_read()
     ctx.profile(False)
     acc.store.check_status()
@@ -208,11 +244,195 @@ def ring_model_pass(steps, frame_fn=None):
             'note': '64 beams x 1875 azimuths over a ground plane with boxes; density ~1/r^2 (contention case)'}
 
 
+def k1_batched_pass(pool_frames, n_distinct, batch=64, reps=20):
+    """K1 alone on `batch` frames per call (7.68 M points): the shape in which the fused project+sample+filter kernel is
+    throughput- rather than launch-latency-bound.  Wall clock over `reps` back-to-back C calls on prebuilt descriptors
+    (the GPU stays busy: launch gaps of the unit are included, host preparation is not), HIP events beside it."""
+    import torch
+    from pca_amd import _lib
+    from pca_amd.device_store import DeviceStore
+    ctx = _lib.Context.get()
+    tmp = DeviceStore(capacity=batch * N_PTS, max_frames=batch + 1)
+    frames = [dict(pts=pool_frames[k % n_distinct][1], rgb=pool_frames[k % n_distinct][0], sem=pool_frames[k % n_distinct][2])
+              for k in range(batch)]
+    descs = DeviceStore.kitti_descs(frames)
+
+    def call():
+        tmp.clear()
+        tmp.append_kitti(frames, P_VELO_FRAME, IMG_H, IMG_W, FILTERS, descs=descs)
+    for _ in range(3):
+        call()
+    kept = int(tmp.offsets()[-1])
+    torch.cuda.synchronize()
+    ctx.profile(True)
+    for _ in range(5):
+        call()
+    ev = ctx.profile_read()['kitti_project_sample_filter']
+    ctx.profile(False)
+    # back-to-back: frame_off[0] stays 0, every call rewrites the same slots -- no host work between calls but ctypes
+    import ctypes as C
+    lib = ctx.lib
+    st = tmp.c_store()
+    Pc, fm = _lib.f64_array(P_VELO_FRAME, 12), _lib.class_mask(FILTERS)
+    tmp.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.check(lib.pca_kitti_project_sample_filter(ctx.h, descs, batch, Pc, IMG_H, IMG_W, fm, C.byref(st),
+                                                      tmp.frame_off.data_ptr(), 0, ctx.stream()))
+    torch.cuda.synchronize()
+    us = 1e6 * (time.perf_counter() - t0) / reps
+    tmp.check_status()
+    alg = 16.0 * N_PTS * batch + 4.0 * (kept * 19.0 / 14.0 / 0.99) + 40.0 * kept
+    return {'frames_per_call': batch, 'distinct_frames': n_distinct, 'points_per_call': N_PTS * batch, 'kept': kept,
+            'us_per_call_wall_back_to_back': us, 'us_per_call_hip_events': 1e3 * ev[0] / ev[1],
+            'alg_bytes': alg, 'GBps': alg / us / 1e3, 'frac': alg / us / 1e3 / HBM_PEAK_GBS,
+            'Mpoints_per_s': N_PTS * batch / us,
+            'input_MB': n_distinct * (N_PTS * 16 + IMG_H * IMG_W * 4) / 1e6}
+
+
+def nuscenes_pass(frames=40, reps=10):
+    """BASELINE configs[2]: NuScenes kernels at full size -- 34 720 points, 6 x 900x1600 images,
+    40 frames per scene, 256^2 BEV at view 51.2 m with height filter 3 m.  K0n / K1n / K3 / BEV times (HIP events)."""
+    import torch
+    from pca_amd import _lib
+    from pca_amd.device_store import DeviceStore, make_bev_params
+    import ctypes as C
+    ctx = _lib.Context.get()
+    lib = ctx.lib
+    n, ncam, H, W = 34_720, 6, 900, 1600
+    g = torch.Generator(device='cuda').manual_seed(3)
+    imgs = torch.randint(0, 256, (ncam, H, W, 3), device='cuda', dtype=torch.uint8, generator=g)
+    sems = torch.randint(0, 19, (ncam, H, W), device='cuda', dtype=torch.uint8, generator=g)
+    rng = np.random.default_rng(3)
+    pc = np.stack([rng.uniform(-50, 50, n), rng.uniform(-50, 50, n), rng.uniform(-2, 4, n),
+                   rng.integers(0, 256, n).astype(float), rng.uniform(1.01, W - 1.01, n), rng.uniform(1.01, H - 1.01, n),
+                   rng.integers(-1, 5, n).astype(float)], 1)
+    cam = rng.integers(-1, ncam, n)
+    pc_d, cam_d = torch.from_numpy(pc).cuda(), torch.from_numpy(cam).cuda()
+    st = DeviceStore(capacity=(frames + 2) * n, max_frames=frames + 4, intensity_div255=True)
+    filters = [10, 11, 12, 16, 18]
+
+    def T_of(k):
+        a = 0.002 * k
+        T = np.eye(4)
+        T[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        T[0, 3] = 1.0 * k
+        return T
+    for k in range(frames):
+        st.append_nusc(pc_d, cam_d, imgs, sems, T_of(k), filters)
+    st.mark_dynamic([(f, 0) for f in range(min(frames, 16))])
+    prm = make_bev_params(T_of(frames // 2)[:3, 3], np.eye(3), 0., 0., 51.2, 256, 3., 1., 30., 0.12, 0, [13, 14, 15, 17], True)
+    out = torch.empty((21, 256, 256), dtype=torch.float16, device='cuda')
+    st.bev(frames // 2, prm, out16=out)
+    # K0n inputs: lidar points + 2 + 6 rigid transforms, intrinsics
+    pts = torch.from_numpy(np.ascontiguousarray(pc[:, :3])).cuda()
+    Tl, Tg = _lib.f64_array(np.eye(4), 16), _lib.f64_array(T_of(3), 16)
+    Tc = _lib.f64_array(np.stack([np.linalg.inv(T_of(3)) for _ in range(ncam)]), 16 * ncam)
+    K = np.array([[1266., 0, 816.], [0, 1266., 491.], [0, 0, 1.]])
+    Kc, whc = _lib.f64_array(np.stack([K] * ncam), 9 * ncam), _lib.f64_array(np.tile([W, H], ncam).astype(float), 2 * ncam)
+    ego = torch.empty((n, 3), dtype=torch.float64, device='cuda')
+    uv = torch.empty((n, 2), dtype=torch.float64, device='cuda')
+    ci = torch.empty(n, dtype=torch.int64, device='cuda')
+    torch.cuda.synchronize()
+    ctx.profile(True)
+    for r in range(reps):
+        st.evict(1)
+        st.append_nusc(pc_d, cam_d, imgs, sems, T_of(frames + r), filters)
+        st.mark_dynamic([(f, 0) for f in range(16)])
+        ctx.check(lib.pca_nusc_project_cams(ctx.h, pts.data_ptr(), n, Tl, Tg, Tc, Kc, whc, ncam, ego.data_ptr(),
+                                            uv.data_ptr(), ci.data_ptr(), ctx.stream()))
+        st.bev(frames // 2, prm, out16=out)
+    prof = {k: 1e3 * v[0] / v[1] for k, v in ctx.profile_read().items() if v[1]}
+    ctx.profile(False)
+    st.check_status()
+    sizes = st.sizes()
+    m_kept = float(sizes[-1])
+    m_on_cam = float((cam >= 0).sum())
+    alg_k1n = 56.0 * n + 4.0 * m_on_cam + 40.0 * m_kept
+    alg_k0n = 24.0 * n + 48.0 * n
+    stored = int(sizes.sum())
+    bev_us = sum(v for k, v in prof.items() if k.startswith('bev_'))
+    alg_bev = 40.0 * stored + 21.0 * 256 * 256 * 4.0
+    return {'workload': 'NuScenes-shape: %d pts x 7 f64, 6 x 900x1600 images, %d frames (%d stored pts), 256^2 BEV, view '
+                        '51.2 m, height filter 3 m, (1, 30, 0.12)' % (n, frames, stored),
+            'kernels_avg_us': prof,
+            'k1n': {'us': prof.get('nusc_sample_filter_transform'), 'alg_bytes': alg_k1n,
+                    'frac': alg_k1n / prof['nusc_sample_filter_transform'] / 1e3 / HBM_PEAK_GBS},
+            'k0n': {'us': prof.get('nusc_project_cams'), 'alg_bytes': alg_k0n,
+                    'frac': alg_k0n / prof['nusc_project_cams'] / 1e3 / HBM_PEAK_GBS},
+            'k3_us': prof.get('mark_dynamic'),
+            'bev_unit': {'us_sum_of_kernels': bev_us, 'alg_bytes': alg_bev, 'frac': alg_bev / bev_us / 1e3 / HBM_PEAK_GBS},
+            'note': 'single small launches: latency-, not bandwidth-bound at 35 k points per frame'}
+
+
+def config4_pass(frames=100, n=1_000_000, px=512, view=160.0):
+    """BASELINE configs[3] with the frame count scaled to the bench's time budget: `frames` x 1 M
+    points, every point kept, 512^2 grid, view 160 m.  One steady-state step = evict + owed re-transform fused into the
+    BEV + append of 1 M points + BEV over the whole window.  (Full size, 1000 frames = 1e9 points = 37 GB:
+    tests/test_gpu_kernels.py and tools/experiments/config4_time.py.)"""
+    import torch as T
+    from pca_amd import _lib
+    from pca_amd.device_store import DeviceStore, make_bev_params
+    st = DeviceStore(capacity=(frames + 40) * n, max_frames=frames + 64)     # room for every step below: no slide
+    g = T.Generator(device='cuda').manual_seed(4)
+    classes = T.tensor([0, 1, 2, 8, 9, 13, 14], device='cuda', dtype=T.uint8)
+    P = np.eye(4)[:3]
+
+    def frame():
+        pts = T.empty((n, 4), device='cuda', dtype=T.float32)
+        pts[:, :2] = (T.rand((n, 2), device='cuda', generator=g) * 160 - 80).float()
+        pts[:, 2] = (T.rand(n, device='cuda', generator=g) * 5 - 2).float()
+        pts[:, 3] = T.rand(n, device='cuda', generator=g).float()
+        return dict(pts=pts.contiguous(), sem_gt=classes[T.randint(0, 7, (n, ), device='cuda', generator=g)])
+    Tm = np.eye(4)
+    Tm[0, 3] = -0.03125
+    pool = [frame() for _ in range(4)]
+    for k in range(frames):
+        if k:
+            st.retransform(Tm)
+        st.append_kitti([pool[k % 4]], P, 1, 1, [255])
+    prm = make_bev_params((0.25, -0.5, 0.0), np.eye(3), 0., 0., view, px, None, 20., 20., 0.5, 0, [13, 14, 15, 17], False)
+    out = T.empty((21, px, px), dtype=T.float16, device='cuda')
+    ctx = _lib.Context.get()
+
+    def step(k):
+        st.evict(1)
+        st.retransform(Tm, defer=True)
+        st.append_kitti([pool[k % 4]], P, 1, 1, [255])
+        st.bev(st.n_frames // 2, prm, out16=out)
+    for k in range(3):
+        step(k)
+    T.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for k in range(reps):
+        step(k)
+    T.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ctx.profile(1)
+    for k in range(5):
+        step(k)
+    prof = {k: 1e3 * v[0] / v[1] for k, v in ctx.profile_read().items() if v[1]}
+    ctx.profile(0)
+    st.check_status()
+    stored = int(st.offsets()[-1] - st.offsets()[0])
+    alg = 40.0 * stored + 21 * px * px * 4 + 48.0 * (stored - n)
+    unit = sum(v for k, v in prof.items() if k.startswith('bev_'))
+    return {'workload': '%d frames x %d points (all kept), %d^2 grid, view %.0f m; %d stored points = %.1f GB'
+                        % (frames, n, px, view, stored, stored * 37 / 1e9),
+            'ms_per_step': 1e3 * dt, 'Mpoints_per_s': n / dt / 1e6, 'bev_frames_per_s': 1 / dt,
+            'kernels_avg_us': prof,
+            'roofline_bev_unit': {'us_sum_of_kernels': unit, 'alg_bytes': alg, 'GBps': alg / unit / 1e3,
+                                  'frac': alg / unit / 1e3 / HBM_PEAK_GBS}}
+
+
 def extras_pass(acc):
-    """Timings of the opt-in / next-row pieces on the benchmark's own data (rank 0, after the headline measurement;
-    reported beside, never as, `value`): voxel de-duplication of the full window and the device ICP on two frames."""
+    """Timings of the opt-in / next-row pieces on the benchmark's own data: voxel de-duplication of the full window and
+    the device ICP on two frames."""
     import torch
     from pca_amd.icp import GpuIcp
+    import warnings
     out = {}
     st = acc.store
     before = int(st.offsets()[-1] - st.offsets()[0])
@@ -226,17 +446,134 @@ def extras_pass(acc):
                           'ms_second_pass_over_%d_pts' % mid: 1e3 * (time.perf_counter() - t0)}
     a, b = GpuIcp.to_device(ring_frame(0, 3)[0]), GpuIcp.to_device(ring_frame(0, 4)[0])
     icp = GpuIcp()
-    icp.register(a, b, 1e3, np.eye(4))
-    t0 = time.perf_counter()
-    r = icp.register(a, b, 1e3, np.eye(4))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        icp.register(a, b, 1e3, np.eye(4))
+        t0 = time.perf_counter()
+        r = icp.register(a, b, 1e3, np.eye(4))
     out['device_icp'] = {'ms_per_registration': 1e3 * (time.perf_counter() - t0), 'points': N_PTS,
                          'iterations': r.iterations, 'scene': 'two consecutive ring-model frames'}
     return out
 
 
+def pcie_inclusive_pass(acc, pool, n_steps):
+    """The step as the UNCHANGED drivers run it: host numpy inputs (PIL-like image, (N,4) f32 points) and a host fp16 BEV
+    dict out, per step 4 MB H2D + 2.75 MB D2H."""
+    import torch
+    host_pool = [(f[0].cpu().numpy(), f[1].cpu().numpy(), f[2].cpu().numpy()) for f in pool]
+    host_sem = {id(h[0]): h[2] for h in host_pool}
+
+    class HostSemSeg:
+        def pred(self, rgb):
+            return host_sem[id(rgb)][None, None]
+    model = acc.semseg_model
+    acc.semseg_model = HostSemSeg()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bevs = None
+    for k in range(n_steps):
+        rgb_h, pc_h, _ = host_pool[k % len(host_pool)]
+        acc.integrate([(rgb_h, pc_h, None)])
+        bevs = acc.generate_bev(present_index(acc), 1, gen_future=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert bevs[0]['rgb_full'].shape == (3, PX, PX)
+    acc.semseg_model = model
+    return {'Mpoints_per_s': N_PTS * n_steps / dt / 1e6, 'bev_frames_per_s': n_steps / dt, 'ms_per_step': 1e3 * dt / n_steps,
+            'steps': n_steps, 'H2D_MB_per_step': (N_PTS * 16 + IMG_H * IMG_W * 4) / 1e6, 'D2H_MB_per_step': 21 * PX * PX * 2 / 1e6,
+            'note': 'host numpy inputs and host fp16 BEV dict per step, as the unchanged drivers call it'}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+#  BASELINE configs[4]: the nine KITTI-360 sequences sharded over the ranks (strong scaling)
+# --------------------------------------------------------------------------------------------------------------------
+def config5_pass(rank, world, scale, barrier, allmax, coll_dev, dist):
+    """Every rank plans the whole job (host replay of the sample trigger, identical everywhere), runs its own chunks --
+    warm-up prefix through integrate_many, then integrate + BEV at the sample jobs -- and keeps its BEVs in HBM; the last
+    GATHER_CHUNK samples of every rank go to rank 0 as a content check (checksums compared).  Timed: barrier .. barrier
+    around the compute of all ranks."""
+    import torch
+    from pca_amd import sharded_run as sr
+    from pca_amd import shard
+    lengths = [max(int(round(n * scale)), 2) for n in KITTI360_LENGTHS]
+    T = t_new_prev()
+    seq_Ts = [np.tile(T, (n, 1, 1)) for n in lengths]
+    t0 = time.perf_counter()
+    jobs, loads, samples = sr.plan(seq_Ts, world, HORIZON_M, float(BEV_HORIZON_M), 1.0)
+    plan_s = time.perf_counter() - t0
+    model = ResidentSemSeg()
+    pools = {}
+
+    def pool_of(seq):
+        if seq not in pools:
+            pools[seq] = device_pool(synth_frame, 100 + seq, POOL, model)
+        return pools[seq]
+    for j in jobs[rank]:
+        pool_of(j.seq)
+    ring = torch.empty((GATHER_CHUNK, 21, PX, PX), dtype=torch.float16, device='cuda')
+    state = {'n': 0}
+
+    def run():
+        for job in jobs[rank]:
+            acc = new_accumulator(model, T)
+            pool = pool_of(job.seq)
+
+            def get_obs(f):
+                rgb, pc, _ = pool[f % POOL]
+                return [(rgb, pc, None)]
+
+            def on_sample(f, present_idx, acc=acc):
+                pcs, trajs = acc._window_inputs(present_idx, True)
+                acc.sem_bev_generator.generate(pcs, trajs, device_only=True, out=ring[state['n'] % GATHER_CHUNK])
+                state['n'] += 1
+            sr.run_chunk(acc, get_obs, job, on_sample, warm_batch=64)
+            acc.store.check_status()
+    import builtins
+    real_print, builtins.print = builtins.print, (lambda *a, **k: None)
+    try:
+        barrier()
+        t0 = time.perf_counter()
+        run()
+        barrier()
+        elapsed = allmax(time.perf_counter() - t0)
+    finally:
+        builtins.print = real_print
+    total_frames, total_samples = sum(lengths), sum(len(s) for s in samples)
+    my_frames = sum(j.cost for j in jobs[rank])
+    out = {'workload': 'nine KITTI-360 sequence lengths x %.3g = %s frames of 120k points, sample trigger of the driver '
+                       '(80 m / 80 m / 1 m), cut into chunks with a warm-up prefix' % (scale, lengths),
+           'scaling': 'strong', 'n_gpus': world, 'frames': total_frames, 'bev_samples': total_samples,
+           'seconds': elapsed, 'Mpoints_per_s': total_frames * N_PTS / elapsed / 1e6,
+           'bev_frames_per_s': total_samples / elapsed,
+           'frames_incl_warmup_per_rank': loads, 'plan_seconds_host': plan_s,
+           'ideal_speedup_of_this_plan': float(total_frames) / max(loads)}
+    # content check: the last chunk of every rank -> rank 0, checksums compared
+    mine = ring.view(torch.int16).to(torch.int64).sum().reshape(1)
+    if world > 1:
+        sums = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(sums, mine.to(coll_dev))
+        t0 = time.perf_counter()
+        got = shard.gather_to_rank0(ring if coll_dev == 'cuda' else ring.cpu(), sizes=[GATHER_CHUNK] * world)
+        barrier()
+        tg = time.perf_counter() - t0
+        if rank == 0:
+            ok = all(int(g.view(torch.int16).to(torch.int64).sum().item()) == int(s.item()) for g, s in zip(got, sums))
+            mb = (world - 1) * GATHER_CHUNK * 21 * PX * PX * 2 / 1e6
+            out['gather_check'] = {'samples_per_rank': GATHER_CHUNK, 'MB_into_rank0': mb, 'ms': 1e3 * tg,
+                                   'GBps': mb / 1e3 / tg, 'checksums_match': bool(ok)}
+            assert ok, 'gathered BEV tensors differ from what the ranks produced'
+    out['frames_this_rank_incl_warmup'] = my_frames
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+#  CPU baselines
+# --------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(steps=20):
-    """Oracle (scalar C port of the reference algorithm, 1 core) on a bounded sample of the same workload:
-    fill the 200-frame window, then time `steps` full steps (re-transform + integrate + BEV)."""
+    """(1) the C oracle (scalar port of the reference algorithm, 1 core) on a bounded sample of the same workload: fill the
+    200-frame window, then time `steps` full steps; (2) the numpy-shaped restatement (oracle/numpy_shape.py: the
+    reference's own algorithmic shape, all host cores through BLAS where numpy uses it) on the same window."""
+    from oracle import numpy_shape as ns
     from oracle import oracle as orc
     from pca_amd import host_logic as hl
     T = t_new_prev()
@@ -245,6 +582,7 @@ def cpu_baseline(steps=20):
     track = hl.PoseTrack()
     sizes = []
     lo = 0
+    last = {}
 
     def step(k, do_bev):
         nonlocal lo, sizes
@@ -270,6 +608,7 @@ def cpu_baseline(steps=20):
                 setattr(sub, name, getattr(st, name)[lo:st.n])
             sub.n = sub.cap = st.n - lo
             orc.bev(sub, int(np.sum(sizes[:idx])), prm)
+            last.update(idx=idx, origin=origin, R=R)
 
     for k in range(205):
         step(k, False)
@@ -277,11 +616,75 @@ def cpu_baseline(steps=20):
     for k in range(steps):
         step(205 + k, True)
     dt = time.perf_counter() - t0
-    return {'value': N_PTS * steps / dt / 1e6, 'unit': 'Mpoints/s', 'bev_frames_per_s': steps / dt, 'cores': 1,
-            'kind': 'port',
-            'sample': f'oracle/pca_oracle.c (scalar C port), 205-frame window fill untimed, then {steps} full steps '
-                      f'(retransform ~{st.n - lo} stored pts + integrate 120k pts + one 256x256 BEV) in {dt:.1f} s',
-            'host_cpus': os.cpu_count()}
+    out = {'value': N_PTS * steps / dt / 1e6, 'unit': 'Mpoints/s', 'bev_frames_per_s': steps / dt, 'cores': 1,
+           'kind': 'port',
+           'sample': f'oracle/pca_oracle.c (scalar C restatement of the reference algorithm, ONE core; not the '
+                     f'numpy-shaped form, which is reported under numpy_shape), 205-frame window fill untimed, then {steps} '
+                     f'full steps (retransform ~{st.n - lo} stored pts + integrate 120k pts + one 256x256 BEV) in {dt:.1f} s',
+           'host_cpus': os.cpu_count()}
+    # ---- numpy-shaped: same window as a list of (M,10) frames -------------------------------------------------------
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [{'api': p.get('internal_api'), 'threads': p.get('num_threads')} for p in threadpool_info()]
+    except Exception:
+        blas = None
+    rows = st.rows(lo, st.n)
+    edges = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    window = [rows[a:b].copy() for a, b in zip(edges[:-1], edges[1:])]
+    pc, img, sem = frames[0]
+    n_steps = 2
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        ns.retransform(window, T)
+        window.append(ns.integrate_frame(pc.astype(np.float64), P_VELO_FRAME, img, sem, FILTERS))
+        window.pop(0)
+        ns.bev(window, last['idx'], last['origin'], last['R'], VIEW_M, PX, 0, [13, 14, 15, 17], (20., 20., 0.5))
+    dtn = (time.perf_counter() - t0) / n_steps
+    # the reference's own loop shape for the two per-cell reductions, on every 8th point of the window (bounded sample)
+    sub = np.concatenate(window)[::8].copy()
+    sub[:, :3] -= last['origin']
+    g = ns._prep(sub, last['R'], VIEW_M, PX)
+    t0 = time.perf_counter()
+    ns._min_z_loops(g, PX)
+    ns._median_loops(g, PX, 4)
+    dtl = time.perf_counter() - t0
+    out['numpy_shape'] = {
+        'value': N_PTS / dtn / 1e6, 'unit': 'Mpoints/s', 'bev_frames_per_s': 1.0 / dtn, 'seconds_per_step': dtn,
+        'cores': os.cpu_count(), 'blas': blas, 'kind': 'port',
+        'sample': f'oracle/numpy_shape.py, vectorised reductions (np.lexsort medians / minima): {n_steps} full steps on the '
+                  f'filled {len(window)}-frame window',
+        'reference_loop_shape': {
+            'seconds_measured': dtl, 'points': int(g.shape[0]),
+            'what': 'the per-point min-z loop and the per-cell np.median loop of ONE colour channel of ONE point set, on '
+                    'every 8th in-view point of the window',
+            'seconds_per_bev_extrapolated': dtl * 8 * (1 + 3 * 3) / 2.0,
+            'note': 'x8 points, (1 min-z + 3 channels) x 3 sets relative to the (1 + 1) x 1 measured'}}
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start N ranks (torch.distributed.run, one per GPU) BEFORE this process touches
+    the GPU, relay rank 0's JSON line, exit with the job's status."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line)
+    if p.returncode != 0 or line is None:
+        sys.stderr.write(p.stdout[-4000:])
+        sys.exit(p.returncode or 1)
+    sys.exit(0)
 
 
 def main():
@@ -289,13 +692,20 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', choices=['config2', 'config5'], default='config2',
+                    help='config2 = the per-frame step on one sequence per rank (headline, weak scaling); config5 = the nine '
+                         'KITTI-360 sequences sharded over the ranks as the headline value (strong scaling)')
+    ap.add_argument('--config5-scale', type=float, default=0.1, help='fraction of the nine sequence lengths (1 = 74 367 frames)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--scene', choices=['uniform', 'ring'], default='uniform',
                     help='uniform = SURVEY 8d K-shape frame (headline); ring = 64-beam ring model')
     ap.add_argument('--no-ring', action='store_true', help='skip the additional ring-model pass')
+    ap.add_argument('--no-extras', action='store_true', help='skip the side measurements (K1 batches, NuScenes, config 4/5, ...)')
     ap.add_argument('--gather', action='store_true',
                     help='multi-GPU: also stream every finished BEV tensor to rank 0 inside the timed region')
     args = ap.parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -314,44 +724,55 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    coll_dev = 'cuda' if backend == 'nccl' else 'cpu'
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def allmax(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     from pca_amd import _lib
     frame_fn = ring_frame if args.scene == 'ring' else synth_frame
-    # ---- inputs resident in HBM: every rank works on its own sequence (scene shard) ----
-    acc, pool, model = make_accumulator(frame_fn, rank)
-
     import builtins
     real_print = builtins.print
-    builtins.print = lambda *a, **k: None           # the accumulator prints one line per frame, as the reference
+    quiet = lambda *a, **k: None                      # the accumulator prints one line per frame, as the reference
 
-    frame_no = [0]
+    if args.workload == 'config5':
+        c5 = config5_pass(rank, world, args.config5_scale, barrier, allmax, coll_dev, dist)
+        if rank == 0:
+            out = {'metric': 'Mpoints/s projected+accumulated and BEV frames/s @256x256; 1/2/4/8 GPU',
+                   'value': c5['Mpoints_per_s'], 'unit': 'Mpoints/s', 'bev_frames_per_s': c5['bev_frames_per_s'],
+                   'n_gpus': world, 'steps': c5['frames'], 'warmup': 0, 'ms_per_step': 1e3 * c5['seconds'] / c5['frames'],
+                   'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                   'config': {'workload': c5['workload'], 'points_per_frame': N_PTS, 'image': [IMG_H, IMG_W], 'bev_px': PX},
+                   'config5': c5, 'roofline': None, 'cpu_baseline': None}
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
-    def step(bev_out=None, slot=0):
-        rgb, pc, _ = pool[frame_no[0] % POOL]
-        frame_no[0] += 1
-        acc.integrate([(rgb, pc, None)])
-        idx = present_index(acc)
-        if idx is None:
-            return None
-        pcs, trajs = acc._window_inputs(idx, True)
-        gen = acc.sem_bev_generator
-        return gen.generate(pcs, trajs, device_only=True, out=None if bev_out is None else bev_out[slot])
-
+    # ---- inputs resident in HBM: every rank works on its own sequence (scene shard) ----
+    acc, pool, model = make_accumulator(frame_fn, rank)
+    builtins.print = quiet
+    st = Stepper(acc, pool)
     # ---- untimed: fill the accumulation window, then W warm-up steps ----
-    while present_index(acc) is None or len(acc.poses) < 195:
-        rgb, pc, _ = pool[frame_no[0] % POOL]
-        frame_no[0] += 1
-        acc.integrate([(rgb, pc, None)])
+    st.fill()
     for _ in range(args.warmup):
-        step()
+        st.step()
     acc.store.check_status()
     bev_buf = torch.empty((args.steps, 21, PX, PX), dtype=torch.float16, device='cuda')
-    # Every rank produces the BEVs of its own sequences and keeps them (a per-rank writer stores them, as the
+    # Every rank produces the BEVs of its own sequence and keeps them (a per-rank writer stores them, as the
     # reference's one-file-per-sample output allows): the step is the same at every N and the timed region holds no
     # data-path collective.  --gather additionally streams the finished tensors to rank 0 INSIDE the timed region, in
     # chunks of GATHER_CHUNK samples with async_op=True (RCCL's own stream: one chunk travels while the next is
     # computed).  Without it one chunk is gathered after the timed region as a check of the RCCL path.
-    coll_dev = 'cuda' if backend == 'nccl' else 'cpu'
     chunks = [(lo, min(lo + GATHER_CHUNK, args.steps)) for lo in range(0, args.steps, GATHER_CHUNK)]
 
     def recv_bufs(lo, hi):
@@ -362,46 +783,42 @@ def main():
         return bev_buf[lo:hi] if backend == 'nccl' else bev_buf[lo:hi].cpu()
     gathered = [recv_bufs(lo, hi) for lo, hi in chunks] if (world > 1 and args.gather) else None
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- timed region: exactly K steps ----
-    barrier()
-    t0 = time.perf_counter()
-    pending = []
-    ci = 0
-    for k in range(args.steps):
-        step(bev_buf, k)
-        if gathered is not None and k + 1 == chunks[ci][1]:
-            pending.append(dist.gather(chunk_of(*chunks[ci]), gathered[ci], dst=0, async_op=True))
-            ci += 1
-    for h in pending:
-        h.wait()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # ---- timed region: exactly K steps, repeated REPEATS times ----
+    times = []
+    for rep in range(REPEATS):
+        barrier()
+        t0 = time.perf_counter()
+        pending = []
+        ci = 0
+        for k in range(args.steps):
+            st.step(bev_buf[k])
+            if gathered is not None and k + 1 == chunks[ci][1]:
+                pending.append(dist.gather(chunk_of(*chunks[ci]), gathered[ci], dst=0, async_op=True))
+                ci += 1
+        for h in pending:
+            h.wait()
+        barrier()
+        times.append(allmax(time.perf_counter() - t0))
+    elapsed = float(np.median(times))
     gather_check = None
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        # the last chunk of every rank -> rank 0 (untimed unless --gather already did it): content check + link rate
+        # the last chunk of every rank -> rank 0 (untimed unless --gather already did it): checksums + link rate
         lo, hi = chunks[-1]
+        mine = bev_buf[lo:hi].view(torch.int16).to(torch.int64).sum().reshape(1).to(coll_dev)
+        sums = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(sums, mine)
         last = gathered[-1] if gathered is not None else recv_bufs(lo, hi)
         barrier()
         tg = time.perf_counter()
-        if gathered is None:
-            dist.gather(chunk_of(lo, hi), last, dst=0)
+        dist.gather(chunk_of(lo, hi), last, dst=0)
         barrier()
         tg = time.perf_counter() - tg
-        if rank == 0:                                 # every rank's last BEV arrived and is a plausible probability map
-            for g in last:
-                assert float(g[-1, 0].float().min()) > 0.0 and float(g[-1, 0].float().max()) < 1.0
+        if rank == 0:
+            ok = all(int(g.view(torch.int16).to(torch.int64).sum().item()) == int(s.item()) for g, s in zip(last, sums))
+            assert ok, 'gathered BEV tensors differ from what the ranks produced'
             mb = (world - 1) * (hi - lo) * 21 * PX * PX * 2 / 1e6
             gather_check = {'in_timed_region': gathered is not None, 'samples_per_rank': hi - lo, 'MB_into_rank0': mb,
-                            'ms': None if gathered is not None else 1e3 * tg,
-                            'GBps': None if gathered is not None else mb / 1e3 / tg}
+                            'ms': 1e3 * tg, 'GBps': mb / 1e3 / tg, 'checksums_match': True}
     acc.store.check_status()
     stored = int(acc.store.offsets()[-1] - acc.store.offsets()[0])
     n_live = acc.store.n_frames
@@ -411,70 +828,47 @@ def main():
     ctx = _lib.Context.get()
     ctx.profile(True)
     for k in range(args.steps):
-        step(bev_buf, k)
+        st.step(bev_buf[k])
     prof = ctx.profile_read()
     ctx.profile(False)
-    # ---- third pass: the BEV unit (its five kernels back to back) bracketed by ONE event pair per call, so that the
+    # ---- third pass: the BEV unit (its kernels back to back) bracketed by ONE event pair per call, so that the
     #      unit's duration carries its launch gaps but not the per-kernel events of the pass above ----
     ctx.profile(2)
     for k in range(args.steps):
-        step(bev_buf, k)
+        st.step(bev_buf[k])
     unit = ctx.profile_read()['bev_unit']
     ctx.profile(False)
-
-    # ---- PCIe-inclusive variant of the step (host numpy inputs as the unchanged drivers pass them, BEV dict of
-    #      host fp16 arrays out): reported beside, never as, `value` ----
-    host_pool = [(f[0].cpu().numpy(), f[1].cpu().numpy(), f[2].cpu().numpy()) for f in pool]
-
-    class HostSemSeg:
-        def pred(self, rgb):
-            return host_sem[id(rgb)][None, None]
-    host_sem = {id(h[0]): h[2] for h in host_pool}
-    acc.semseg_model = HostSemSeg()
-    n_host = min(args.steps, 30)
-    torch.cuda.synchronize()
-    th0 = time.perf_counter()
-    for k in range(n_host):
-        rgb_h, pc_h, _ = host_pool[k % POOL]
-        acc.integrate([(rgb_h, pc_h, None)])
-        idx = present_index(acc)
-        bevs = acc.generate_bev(idx, 1, gen_future=True)
-    torch.cuda.synchronize()
-    host_elapsed = time.perf_counter() - th0
-    assert bevs[0]['rgb_full'].shape == (3, PX, PX)
-    acc.semseg_model = model
-
-    # ---- K1 alone, batched: 64 frames (7.68 M points) per launch -- the shape in which the fused
-    #      project+sample+filter kernel is throughput- rather than launch-latency-bound ----
-    from pca_amd.device_store import DeviceStore
-    k1_batch = 64
-    tmp = DeviceStore(capacity=k1_batch * N_PTS, max_frames=k1_batch + 1)
-    frames = [dict(pts=pool[k % POOL][1], rgb=pool[k % POOL][0], sem=pool[k % POOL][2]) for k in range(k1_batch)]
-    tmp.append_kitti(frames, P_VELO_FRAME, IMG_H, IMG_W, FILTERS)           # warm-up
-    torch.cuda.synchronize()
-    ctx.profile(True)
-    for _ in range(5):
-        tmp.clear()
-        tmp.append_kitti(frames, P_VELO_FRAME, IMG_H, IMG_W, FILTERS)
-    k1b = ctx.profile_read()['kitti_project_sample_filter']
-    ctx.profile(False)
-    k1b_kept = int(tmp.offsets()[-1])
-    del tmp
-    ring, extras = None, None
-    if rank == 0 and world == 1 and not args.no_ring and args.scene == 'uniform':
-        ring = ring_model_pass(min(args.steps, 50))
-        extras = extras_pass(acc)                          # mutates the store: last use of `acc`
     builtins.print = real_print
+
+    # ---- BASELINE configs[4] at this N: every rank takes part (strong-scaling job, reported beside `value`) ----
+    c5 = None
+    if not args.no_extras:
+        c5 = config5_pass(rank, world, args.config5_scale, barrier, allmax, coll_dev, dist)
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    side = {}
+    if world == 1 and not args.no_extras:
+        builtins.print = quiet
+        side['pcie_inclusive'] = pcie_inclusive_pass(acc, pool, min(args.steps, 30))
+        side['k1_batched'] = k1_batched_pass(pool, POOL)
+        big = device_pool(synth_frame, 7, 64)
+        side['k1_batched_distinct'] = k1_batched_pass(big, 64)
+        del big
+        side['nuscenes'] = nuscenes_pass()
+        side['config4'] = config4_pass()
+        if not args.no_ring and args.scene == 'uniform':
+            side['ring_model'] = ring_model_pass(min(args.steps, 50))
+        side['extras'] = extras_pass(acc)                  # mutates the store: last use of `acc`
+        builtins.print = real_print
+
     kern = {k: {'ms_total': v[0], 'launches': v[1], 'avg_us': 1e3 * v[0] / v[1]} for k, v in prof.items() if v[1]}
     # Algorithmic bytes per launch (SURVEY.md 8d / DESIGN.md):
     #   K2 retransform: 48 B per stored point;  K1: 16 N + 4 M_proj + 40 M_kept;
-    #   BEV (hist+scan+scatter+cells as one unit): 40 B per window point + 21 px^2 4 B.
+    #   BEV (its kernels as one unit): 40 B per window point + 21 px^2 4 B.
     # In steady state the owed re-transform of a step is applied by the BEV's first pass (it reads every
     # coordinate anyway): the BEV unit then also does K2's work, so its algorithmic bytes include K2's.
     m_kept = float(np.mean(sizes))
@@ -485,25 +879,24 @@ def main():
         'bev': 40.0 * stored + 21.0 * PX * PX * 4.0 + (48.0 * (stored - sizes[-1]) if k2_fused else 0.0),
     }
     bev_us = 1e3 * unit[0] / unit[1]                    # one event pair around the unit (see above)
-    bev_us_sum = sum(kern[k]['avg_us'] for k in ('bev_bin', 'bev_scan', 'bev_scatter', 'bev_cells', 'bev_cells_heavy')
-                     if k in kern)
+    bev_names = ('bev_bin', 'bev_scan', 'bev_scatter', 'bev_cells', 'bev_cells_heavy')
+    bev_us_sum = sum(kern[k]['avg_us'] for k in bev_names if k in kern)
     units = {'kitti_project_sample_filter': kern['kitti_project_sample_filter']['avg_us'], 'bev': bev_us}
     if not k2_fused:
         alg['retransform'] = 48.0 * stored
         units['retransform'] = kern['retransform']['avg_us']
     dominant = max(units, key=lambda k: units[k])
     achieved = alg[dominant] / (units[dominant] * 1e-6) / 1e9
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate passes,
-    # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); bench.py cannot run the profiler itself
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of THESE kernels (FETCH_SIZE / WRITE_SIZE in
+    # separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); bench.py cannot run the profiler
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, 'profiles', 'r01_e_pmc_traffic.json')
+    pmc_path = os.path.join(ROOT, 'profiles', PROFILE_TAG + '_pmc_traffic.json')
     if os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))['kernels']
-        names = {'bev': ('bev_tile_hist', 'bev_tile_scan', 'bev_tile_scatter<false>', 'bev_tile_cells<false>',
-                         'bev_tile_cells_heavy<false>')}
-        if dominant in names and all(k in pmc for k in names[dominant]):
-            traffic = sum(2.0 * pmc[k]['FETCH_SIZE_KB'] + pmc[k]['WRITE_SIZE_KB'] for k in names[dominant]) * 1024.0
-            traffic_src = 'profiles/r01_e_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, summed over the unit\'s kernels)'
+        names = [k for k in pmc if k.startswith('bev_tile')]
+        if dominant == 'bev' and names:
+            traffic = sum(2.0 * pmc[k]['FETCH_SIZE_KB'] + pmc[k]['WRITE_SIZE_KB'] for k in names) * 1024.0
+            traffic_src = 'profiles/%s_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, summed over the unit\'s kernels)' % PROFILE_TAG
     roofline = {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_bytes_per_launch': alg[dominant], 'avg_launch_us': units[dominant],
@@ -512,12 +905,9 @@ def main():
                             'GBps': alg[k] / (units[k] * 1e-6) / 1e9,
                             'frac': alg[k] / (units[k] * 1e-6) / 1e9 / HBM_PEAK_GBS} for k in units},
                 'kernels': kern}
-    k1b_us = 1e3 * k1b[0] / k1b[1]
-    k1b_bytes = 16.0 * N_PTS * k1_batch + 4.0 * (k1b_kept * 19.0 / 14.0 / 0.99) + 40.0 * k1b_kept
-    roofline['k1_batched'] = {'frames_per_launch': k1_batch, 'points_per_launch': N_PTS * k1_batch, 'kept': k1b_kept,
-                              'avg_launch_us': k1b_us, 'alg_bytes': k1b_bytes, 'GBps': k1b_bytes / (k1b_us * 1e-6) / 1e9,
-                              'frac': k1b_bytes / (k1b_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                              'Mpoints_per_s': N_PTS * k1_batch / k1b_us}
+    for k in ('k1_batched', 'k1_batched_distinct'):
+        if k in side:
+            roofline[k] = side.pop(k)
 
     out = {
         'metric': 'Mpoints/s projected+accumulated and BEV frames/s @256x256; 1/2/4/8 GPU',
@@ -528,6 +918,10 @@ def main():
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps,
+        'repeats': {'n': REPEATS, 'statistic': 'median', 'ms_per_step_min': 1e3 * min(times) / args.steps,
+                    'ms_per_step_max': 1e3 * max(times) / args.steps,
+                    'value_min': world * N_PTS * args.steps / max(times) / 1e6,
+                    'value_max': world * N_PTS * args.steps / min(times) / 1e6},
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
@@ -539,15 +933,12 @@ def main():
                    'sharding': 'one independent sequence per GPU, no data-path collective'
                                + ('; BEV tensors streamed to rank 0 (RCCL, overlapped)' if args.gather else '')},
         'roofline': roofline,
-        'pcie_inclusive': {'Mpoints_per_s': N_PTS * n_host / host_elapsed / 1e6, 'bev_frames_per_s': n_host / host_elapsed,
-                           'ms_per_step': 1e3 * host_elapsed / n_host, 'steps': n_host,
-                           'note': 'host numpy inputs (4 MB H2D per frame) and host fp16 BEV dict (2.75 MB D2H) per step'},
     }
+    if c5 is not None:
+        out['config5'] = c5
     if gather_check is not None:
         out['gather_check'] = gather_check
-    if ring is not None:
-        out['ring_model'] = ring
-        out['extras'] = extras
+    out.update(side)
     if not args.no_cpu_baseline and world == 1:           # reported at N = 1 only
         out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))

@@ -1,5 +1,6 @@
 """bench.py end to end on the GPU box: the one-line JSON contract at N = 1, and the multi-rank control flow rehearsed
-with two gloo ranks sharing the one GPU (PCA_BENCH_BACKEND=gloo; the real multi-GPU run uses nccl = RCCL)."""
+with two gloo ranks sharing the one GPU (PCA_BENCH_BACKEND=gloo; the real multi-GPU run uses nccl = RCCL) -- started by
+bench.py itself (`--gpus 2` with no launcher) and by torch.distributed.run as the driver does."""
 import json
 import os
 import subprocess
@@ -22,19 +23,36 @@ def last_json(out):
 
 
 def test_bench_single_gpu_contract():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '1', '--no-ring'],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '1', '--no-ring',
+                        '--config5-scale', '0.02'], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     d = last_json(r.stdout)
     assert REQUIRED <= set(d) and 'cpu_baseline' in d
     assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['vs_baseline'] is None
     assert d['unit'] == 'Mpoints/s' and d['value'] > 50 and d['higher_is_better'] is True and d['dtype'] == 'f64'
+    assert d['repeats']['n'] >= 5 and d['repeats']['value_min'] <= d['value'] <= d['repeats']['value_max']
     assert 'workload' in d['config'] and 'model' not in d['config']
     rf = d['roofline']
     assert rf['bound'] == 'hbm' and rf['unit'] == 'GB/s' and rf['peak'] == 8000.0
     assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12 and 0.05 < rf['frac'] < 1.0
+    for k in ('k1_batched', 'k1_batched_distinct'):
+        assert rf[k]['frames_per_call'] == 64 and 0.05 < rf[k]['frac'] < 1.0
+    assert rf['k1_batched_distinct']['distinct_frames'] == 64
     cb = d['cpu_baseline']
     assert cb['kind'] == 'port' and cb['cores'] == 1 and cb['value'] > 0 and 'sample' in cb
+    assert cb['numpy_shape']['value'] > 0 and cb['numpy_shape']['cores'] == os.cpu_count()
+    assert d['config5']['scaling'] == 'strong' and d['config5']['bev_samples'] > 0 and d['config5']['seconds'] > 0
+    assert d['nuscenes']['k1n']['us'] > 0 and d['config4']['ms_per_step'] > 0
+    assert d['pcie_inclusive']['Mpoints_per_s'] > 10
+
+
+def _check_two_ranks(d, gathered):
+    assert d['n_gpus'] == 2 and d['steps'] == 20 and d['value'] > 10
+    gc = d['gather_check']
+    assert gc['in_timed_region'] is gathered and gc['samples_per_rank'] == 4 and gc['checksums_match'] is True
+    assert 'cpu_baseline' not in d and 'ring_model' not in d            # reported at N = 1 only
+    c5 = d['config5']
+    assert c5['n_gpus'] == 2 and c5['gather_check']['checksums_match'] is True and len(c5['frames_incl_warmup_per_rank']) == 2
 
 
 def test_bench_two_ranks_gloo_rehearsal():
@@ -42,10 +60,26 @@ def test_bench_two_ranks_gloo_rehearsal():
     for extra in ([], ['--gather']):
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                '127.0.0.1', '--master-port', '29541', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20',
-               '--warmup', '1'] + extra
+               '--warmup', '1', '--config5-scale', '0.02'] + extra
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
         assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-        d = last_json(r.stdout)
-        assert d['n_gpus'] == 2 and d['steps'] == 20 and d['value'] > 10
-        assert d['gather_check']['in_timed_region'] is bool(extra) and d['gather_check']['samples_per_rank'] == 4
-        assert 'cpu_baseline' not in d and 'ring_model' not in d            # reported at N = 1 only
+        _check_two_ranks(last_json(r.stdout), bool(extra))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: bench.py spawns the ranks itself and relays rank 0's line."""
+    env = dict(os.environ, PCA_BENCH_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '1',
+                        '--config5-scale', '0.02'], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    _check_two_ranks(last_json(r.stdout), False)
+
+
+def test_bench_config5_as_headline_workload():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', 'config5', '--config5-scale', '0.02'],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    d = last_json(r.stdout)
+    assert d['scaling'] == 'strong' and d['n_gpus'] == 1 and d['value'] > 10 and d['config5']['frames'] == d['steps']

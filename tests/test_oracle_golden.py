@@ -170,3 +170,43 @@ def test_rgb_bev_medians(golden):
     prm = orc.make_bev_params([0, 0, 0], np.eye(3), 0, 0, view, px, None, 1, 1, 0.5, 0, DYNOBJ, False, rgb_fill=7.)
     out = orc.bev(st, st.n, prm)
     assert np.array_equal(out['planes'][2:5] * 255., g['rg_out'])
+
+
+def test_numpy_shape_matches_c_oracle():
+    """oracle/numpy_shape.py (the numpy-shaped CPU baseline bench.py times) against the C oracle: integrate rows equal,
+    BEV planes equal in both reduction forms (vectorised / the reference's Python loops)."""
+    from oracle import numpy_shape as ns
+    from oracle import oracle as orc
+    rng = np.random.default_rng(12)
+    H, W, n = 48, 80, 4000
+    cam_to_velo = np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418],
+                            [-0.999004371, 0.007784614041, 0.04392796942, 0.2993489574],
+                            [-0.01162548558, -0.9960641394, -0.08786966659, -0.1770225824], [0, 0, 0, 1]])
+    P = np.array([[40., 0, W / 2, 0], [0, 40., H / 2, 0], [0, 0, 1, 0]]) @ np.linalg.inv(cam_to_velo)
+    filters = [10, 11, 12, 16, 18, 255]
+    frames, st, sizes = [], orc.Store(4 * n), []
+    T = np.eye(4)
+    T[:3, :3] = [[np.cos(0.01), -np.sin(0.01), 0], [np.sin(0.01), np.cos(0.01), 0], [0, 0, 1]]
+    T[0, 3] = -1.0
+    for k in range(4):
+        pc = np.stack([rng.uniform(-20, 20, n), rng.uniform(-20, 20, n), rng.uniform(-2, 3, n), rng.uniform(0, 1, n)],
+                      1).astype(np.float32)
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        sem = rng.integers(0, 19, (H, W)).astype(np.uint8)
+        if k:
+            ns.retransform(frames, T)
+            orc.retransform(st, T)
+        frames.append(ns.integrate_frame(pc.astype(np.float64), P, img, sem, filters))
+        sizes.append(orc.kitti_project_sample_filter(st, pc, P, img, sem, None, H, W, filters))
+    assert np.array_equal(np.concatenate(frames), st.rows())
+    R = np.array([[np.cos(0.4), -np.sin(0.4), 0], [np.sin(0.4), np.cos(0.4), 0], [0, 0, 1.]])
+    origin = np.array([0.5, -0.25, 0.1])
+    ref = orc.bev(st, sizes[0] + sizes[1], orc.make_bev_params(origin, R, 0., 0., 30., 32, None, 20., 20., 0.5, 0,
+                                                               [13, 14, 15, 17], False))
+    for loops in (False, True):
+        got = ns.bev([f.copy() for f in frames], 2, origin, R, 30., 32, 0, [13, 14, 15, 17], (20., 20., 0.5), loops)
+        d = np.abs(got.view(np.uint16).astype(int) - ref['f16'].view(np.uint16).astype(int))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-3, loops          # intensity plane: summation order, 1 fp16 ulp
+        for s in range(3):
+            for k in (0, 2, 3, 4, 5, 6):
+                assert np.array_equal(got[7 * s + k].view(np.uint16), ref['f16'][7 * s + k].view(np.uint16))
