@@ -86,6 +86,18 @@ int pca_kitti_project_sample_filter(pca_ctx *ctx, const pca_kitti_frame *frames,
                                     int H, int W, const uint64_t filter_mask[4], const pca_store *store,
                                     int64_t *frame_off /*dev*/, int first_slot, void *stream);
 
+/* Sample modes of K1 / K1n.  NEAREST is what the reference's callers use (sem_pc_accum.py:338-341 rounds the pixel,
+ * nuscenes_oracle_sem_pc_accum.py:466-469 passes 'nearest').  BILINEAR is opt-in (the reference has the branch,
+ * datasets/nuscenes_utils.py:197-210, but no caller): r, g, b = round-half-even of the bilinear mix of the four
+ * neighbours, weights exactly as that branch computes them (pinned through pca_sample_bilinear), neighbours clamped to
+ * the image, an integer coordinate takes floor + 1 as its upper neighbour (weight 0) instead of the reference's 0 / 0;
+ * the class is always the nearest pixel's. */
+#define PCA_SAMPLE_NEAREST 0
+#define PCA_SAMPLE_BILINEAR 1
+int pca_kitti_project_sample_filter_ex(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames, const double P[12],
+                                       int H, int W, const uint64_t filter_mask[4], const pca_store *store,
+                                       int64_t *frame_off /*dev*/, int first_slot, int sample_mode, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K1n NuScenes (oracle pose)  nearest sample from 6 camera images -> invalid / class filter ->
  *     stable compaction -> ego->world transform -> append.
@@ -97,6 +109,16 @@ int pca_nusc_sample_filter_transform(pca_ctx *ctx, const double *pc, const int64
                                      const uint8_t *imgs, const uint8_t *sems, int ncam, int H, int W,
                                      const double T[16], const uint64_t filter_mask[4], const pca_store *store,
                                      int64_t *frame_off /*dev*/, int slot, void *stream);
+int pca_nusc_sample_filter_transform_ex(pca_ctx *ctx, const double *pc, const int64_t *cam_idx, int32_t n,
+                                        const uint8_t *imgs, const uint8_t *sems, int ncam, int H, int W,
+                                        const double T[16], const uint64_t filter_mask[4], const pca_store *store,
+                                        int64_t *frame_off /*dev*/, int slot, int sample_mode, void *stream);
+
+/* pts_feat_from_img(pts_uv, img, method='bilinear') of the reference for a 2-D feature map (its bilinear branch only
+ * works for those): datasets/nuscenes_utils.py:181-210, the arithmetic to the letter.  map: dev [H,W] f64; uv: dev [n,2]
+ * f64 (u along x); out: dev [n] f64.  Raises PCA_STATUS_UV_OUT_OF_IMAGE where the reference's assert fails. */
+int pca_sample_bilinear(pca_ctx *ctx, const double *map /*dev*/, int H, int W, const double *uv /*dev*/, int32_t n,
+                        double *out /*dev*/, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K0n NuScenes lidar -> ego -> global -> N cameras, pinhole projection, last camera wins.

@@ -109,6 +109,23 @@ class Store:
         return st
 
 
+def set_sample_mode(mode):
+    """0 nearest (the reference), 1 bilinear rgb (the opt-in mode of K1 / K1n)."""
+    lib().orc_set_sample_mode(int(mode))
+
+
+def sample_bilinear(feat_map, uv):
+    """pts_feat_from_img(uv, feat_map, 'bilinear') for a 2-D map."""
+    feat_map = np.ascontiguousarray(feat_map, np.float64)
+    uv = np.ascontiguousarray(uv, np.float64)
+    out = np.empty(uv.shape[0])
+    rc = lib().orc_sample_bilinear(_p(feat_map), int(feat_map.shape[0]), int(feat_map.shape[1]), _p(uv),
+                                   C.c_int64(uv.shape[0]), _p(out))
+    if rc:
+        raise AssertionError('pts_uv must be all inside image')
+    return out
+
+
 def kitti_project_sample_filter(st, pts, P, rgb, sem, sem_gt, H, W, filters, want_uv=False):
     pts = np.ascontiguousarray(pts, np.float32)
     n = pts.shape[0]

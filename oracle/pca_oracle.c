@@ -52,6 +52,58 @@ static inline double row4(const double *r, double x, double y, double z)
  * Per input point (optional, may be NULL): mask_out[n] (in-frustum), u_out[n], v_out[n] (int64 as numpy).
  * Appends kept records to `st` starting at index `base`; returns the number kept.  inst = 0, dyn = 0.
  * ------------------------------------------------------------------------------------------- */
+/* Bilinear weights of pts_feat_from_img(..., 'bilinear'), datasets/nuscenes_utils.py:197-210: neighbours floor / ceil,
+ * un-fused f64, fourth weight = 1 - (sum of the others), value = w_ff a(v0,u0) + w_cc a(v1,u1) + w_cf a(v1,u0) + w_fc a(v0,u1).
+ * strict = the reference to the letter; else (opt-in sample mode of K1 / K1n, no reference caller) the upper neighbour is
+ * floor + 1, so an integer coordinate gives weight 0 instead of 0 / 0. */
+typedef struct { double u0, u1, v0, v1, w_ff, w_cc, w_cf, w_fc; } orc_bilin;
+static orc_bilin bilin_weights(double u, double v, int strict)
+{
+    orc_bilin b;
+    b.u0 = floor(u); b.v0 = floor(v);
+    b.u1 = strict ? ceil(u) : b.u0 + 1.0;
+    b.v1 = strict ? ceil(v) : b.v0 + 1.0;
+    double area = (b.u1 - b.u0) * (b.v1 - b.v0);
+    b.w_ff = (b.u1 - u) * (b.v1 - v) / area;
+    b.w_cc = (u - b.u0) * (v - b.v0) / area;
+    b.w_fc = (u - b.u0) * (b.v1 - v) / area;
+    b.w_cf = 1.0 - (b.w_ff + b.w_cc + b.w_fc);
+    return b;
+}
+static double bilin_value(const orc_bilin *b, double a_ff, double a_cc, double a_cf, double a_fc)
+{
+    return b->w_ff * a_ff + b->w_cc * a_cc + b->w_cf * a_cf + b->w_fc * a_fc;
+}
+static uint32_t bilin_rgb(const orc_bilin *b, const uint8_t *ff, const uint8_t *cc, const uint8_t *cf, const uint8_t *fc)
+{
+    uint32_t out = 0;
+    for (int ch = 0; ch < 3; ++ch) {
+        double v = rint(bilin_value(b, (double)ff[ch], (double)cc[ch], (double)cf[ch], (double)fc[ch]));
+        v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+        out |= (uint32_t)v << (8 * ch);
+    }
+    return out;
+}
+static int clampi(double v, int n) { return (int)(v < 0.0 ? 0.0 : (v > (double)(n - 1) ? (double)(n - 1) : v)); }
+
+/* pts_feat_from_img(uv, map, 'bilinear') for a 2-D map (the only shape the reference's branch supports); -1 if the
+ * reference's assert would fail. */
+ORC_API int orc_sample_bilinear(const double *map, int H, int W, const double *uv, int64_t n, double *out)
+{
+    for (int64_t p = 0; p < n; ++p) {
+        double u = uv[2 * p], v = uv[2 * p + 1];
+        if (!(u > 1.0 && u < (double)W - 1.0 && v > 1.0 && v < (double)H - 1.0)) return -1;
+        orc_bilin b = bilin_weights(u, v, 1);
+        int u0 = (int)b.u0, u1 = (int)b.u1, v0 = (int)b.v0, v1 = (int)b.v1;
+        out[p] = bilin_value(&b, map[(int64_t)v0 * W + u0], map[(int64_t)v1 * W + u1], map[(int64_t)v1 * W + u0],
+                             map[(int64_t)v0 * W + u1]);
+    }
+    return 0;
+}
+
+static int orc_sample_mode = 0;    /* 0 nearest (the reference), 1 bilinear rgb: set by the tests of the opt-in mode */
+ORC_API void orc_set_sample_mode(int mode) { orc_sample_mode = mode; }
+
 ORC_API int64_t orc_kitti_project_sample_filter(const float *pts, int64_t n, const double *P, const uint8_t *rgb,
                                                 const uint8_t *sem, const uint8_t *sem_gt, int H, int W,
                                                 const uint64_t *filter_mask, orc_store *st, int64_t base,
@@ -85,6 +137,12 @@ ORC_API int64_t orc_kitti_project_sample_filter(const float *pts, int64_t n, con
             if (in_mask(filter_mask, c)) continue;         /* :317-321 */
             const uint8_t *px = rgb + ((int64_t)v * W + u) * 3;
             packed = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)c << 24);
+            if (orc_sample_mode) {                         /* opt-in: bilinear colour, neighbours clamped to the image */
+                orc_bilin b = bilin_weights(fx / fabs(d), fy / fabs(d), 0);
+                int u0 = clampi(b.u0, W), u1 = clampi(b.u1, W), v0 = clampi(b.v0, H), v1 = clampi(b.v1, H);
+                packed = bilin_rgb(&b, rgb + ((int64_t)v0 * W + u0) * 3, rgb + ((int64_t)v1 * W + u1) * 3,
+                                   rgb + ((int64_t)v1 * W + u0) * 3, rgb + ((int64_t)v0 * W + u1) * 3) | ((uint32_t)c << 24);
+            }
         }
         int64_t o = base + m++;
         st->x[o] = x; st->y[o] = y; st->z[o] = z;
@@ -149,6 +207,13 @@ ORC_API int64_t orc_nusc_sample_filter_transform(const double *pc, const int64_t
         st->z[o] = row4(T + 8, q[0], q[1], q[2]);
         st->intensity[o] = (float)q[3];
         st->rgbs[o] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)s << 24);
+        if (orc_sample_mode) {                                 /* opt-in: bilinear colour (all four neighbours are inside) */
+            orc_bilin b = bilin_weights(u, v, 0);
+            const uint8_t *img = imgs + (int64_t)c * H * W * 3;
+            int u0 = (int)b.u0, u1 = (int)b.u1, v0 = (int)b.v0, v1 = (int)b.v1;
+            st->rgbs[o] = bilin_rgb(&b, img + ((int64_t)v0 * W + u0) * 3, img + ((int64_t)v1 * W + u1) * 3,
+                                    img + ((int64_t)v1 * W + u0) * 3, img + ((int64_t)v0 * W + u1) * 3) | ((uint32_t)s << 24);
+        }
         st->inst[o] = (int32_t)q[6];
         st->dyn[o] = 0;
     }

@@ -35,43 +35,45 @@ __device__ __forceinline__ float4 ldg4(const float *p)      // one 16-byte globa
 // k-major, then thread), returns the position of each kept point among the tile's kept points and
 // the global exclusive prefix of the tile obtained by decoupled look-back.
 // ---------------------------------------------------------------------------------------------
-struct TileScan {
-    uint32_t local[PPT];   // rank of the point inside the tile (valid where keep)
+template <int NP>
+struct TileScanT {
+    uint32_t local[NP];    // rank of the point inside the tile (valid where keep)
     uint32_t total;        // kept points of the tile
     uint64_t excl;         // kept points of all earlier tiles of the launch
 };
+typedef TileScanT<PPT> TileScan;
 
-template <int BLK>
-__device__ __forceinline__ TileScan tile_compact(const bool keep[PPT], uint64_t *state, int tile, uint32_t epoch,
-                                                 uint32_t *status)
+template <int BLK, int NP = PPT>
+__device__ __forceinline__ TileScanT<NP> tile_compact(const bool keep[NP], uint64_t *state, int tile, uint32_t epoch,
+                                                      uint32_t *status)
 {
     constexpr int NW = BLK / PCA_WAVE;
-    static_assert(PPT * NW <= 64, "the per-(row, wave) totals are scanned by one wave");
-    __shared__ uint32_t s_wtot[PPT * NW];      // kept points per (row k, wave), k-major = point order
-    __shared__ uint32_t s_woff[PPT * NW + 1];  // exclusive prefix of s_wtot, [PPT*NW] = tile total
+    static_assert(NP * NW <= 64, "the per-(row, wave) totals are scanned by one wave");
+    __shared__ uint32_t s_wtot[NP * NW];       // kept points per (row k, wave), k-major = point order
+    __shared__ uint32_t s_woff[NP * NW + 1];   // exclusive prefix of s_wtot, [NP*NW] = tile total
     __shared__ uint64_t s_excl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    TileScan r;
+    TileScanT<NP> r;
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
+    for (int k = 0; k < NP; ++k) {
         const uint64_t b = __ballot(keep[k]);
         r.local[k] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
         if (lane == 0) s_wtot[k * NW + wave] = (uint32_t)__popcll(b);
     }
     __syncthreads();
     if (wave == 0) {
-        const uint32_t v = lane < PPT * NW ? s_wtot[lane] : 0u;
+        const uint32_t v = lane < NP * NW ? s_wtot[lane] : 0u;
         const uint32_t inc = wave_incl_scan_add(v);
-        if (lane < PPT * NW) s_woff[lane] = inc - v;
+        if (lane < NP * NW) s_woff[lane] = inc - v;
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        if (lane == 0) s_woff[PPT * NW] = total;
+        if (lane == 0) s_woff[NP * NW] = total;
         const uint64_t e = lb_exclusive_prefix(state, tile, (uint64_t)total, epoch, status);
         if (lane == 0) s_excl = e;
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) r.local[k] += s_woff[k * NW + wave];
-    r.total = s_woff[PPT * NW];
+    for (int k = 0; k < NP; ++k) r.local[k] += s_woff[k * NW + wave];
+    r.total = s_woff[NP * NW];
     r.excl = s_excl;
     return r;
 }
@@ -98,6 +100,8 @@ struct K1nArgs {
     const uint8_t *imgs;       // [ncam,H,W,3]
     const uint8_t *sems;       // [ncam,H,W]
     int ncam, H, W;
+    int sample_mode;           // 0 nearest (the reference); 1 bilinear rgb (opt-in), class stays nearest
+    int static_tiles;          // grid <= CUs: every workgroup is resident, tile = blockIdx (no ticket)
     Mat44 T;
     ClassMask filt;
     pca_store st;
@@ -108,56 +112,101 @@ struct K1nArgs {
     uint32_t epoch;
 };
 
-template <int BLK>
-__global__ __launch_bounds__(BLK) void k1n_nusc(const K1nArgs a)
+#define K1N_BLK 256
+#define K1N_PPT 2            // 512-point tiles: a 35 k-point sweep spreads over 68 CUs; the kernel is a latency chain
+
+__global__ __launch_bounds__(K1N_BLK) void k1n_nusc(const K1nArgs a)
 {
-    constexpr int TILE_PTS = PPT * BLK;
-    const int tile = draw_tile(a.ticket, a.total_tiles);
+    constexpr int TILE_PTS = K1N_PPT * K1N_BLK;
+    const int tile = a.static_tiles ? (int)blockIdx.x : draw_tile(a.ticket, a.total_tiles);
     const int64_t base_pt = (int64_t)tile * TILE_PTS;
-    bool keep[PPT];
-    uint32_t packed[PPT];
-    bool bad_uv = false;
+    // every load that does not depend on another goes out first: camera index and the whole 7 x f64 row
+    int64_t cam[K1N_PPT];
+    double row[K1N_PPT][7];
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int64_t p = base_pt + k * BLK + threadIdx.x;
-        keep[k] = false;
-        packed[k] = 0;
-        if (p >= a.n) continue;
-        const int64_t c = a.cam_idx[p];
-        if (c < 0 || c >= a.ncam) continue;                // features stay -1 -> invalid
-        const double u = a.pc[p * 7 + 4], v = a.pc[p * 7 + 5];
-        if (!(u > 1.0 && u < (double)a.W - 1.0 && v > 1.0 && v < (double)a.H - 1.0)) { bad_uv = true; continue; }
-        const int ui = (int)rint(u), vi = (int)rint(v);
-        const int64_t pix = ((int64_t)c * a.H + vi) * a.W + ui;
-        const unsigned s = a.sems[pix];
-        if (in_mask(a.filt, s)) continue;
-        const uint8_t *px = a.imgs + pix * 3;
-        packed[k] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)s << 24);
-        keep[k] = true;
+    for (int k = 0; k < K1N_PPT; ++k) {
+        const int64_t p = base_pt + k * K1N_BLK + threadIdx.x;
+        cam[k] = -1;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) row[k][i] = 0.0;
+        if (p < a.n) {
+            cam[k] = ldg(a.cam_idx + p);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) row[k][i] = ldg(a.pc + p * 7 + i);
+        }
+    }
+    bool valid[K1N_PPT], keep[K1N_PPT];
+    uint32_t packed[K1N_PPT];
+    unsigned cls[K1N_PPT];
+    bool bad_uv = false;
+    const int64_t last = (int64_t)a.ncam * a.H * a.W * 3 - 4;           // last legal 4-byte window of the images
+    auto rgb_at = [&](int64_t pix) -> uint32_t {
+        int64_t off = pix * 3;
+        const int sh = off > last ? (int)(off - last) * 8 : 0;
+        off = off > last ? last : off;
+        return (ldg_u32_unaligned(a.imgs + off) >> sh) & 0xffffffu;
+    };
+#pragma unroll
+    for (int k = 0; k < K1N_PPT; ++k) {
+        const int64_t c = cam[k];
+        const double u = row[k][4], v = row[k][5];
+        valid[k] = c >= 0 && c < a.ncam;                   // else: features stay -1 -> invalid
+        if (valid[k] && !(u > 1.0 && u < (double)a.W - 1.0 && v > 1.0 && v < (double)a.H - 1.0)) { bad_uv = true; valid[k] = false; }
+        const int ui = valid[k] ? (int)rint(u) : 0, vi = valid[k] ? (int)rint(v) : 0;
+        const int64_t img0 = (valid[k] ? c : 0) * a.H;
+        const int64_t pix = (img0 + vi) * a.W + ui;        // pixel 0 of camera 0 for invalid points: a legal address
+        cls[k] = ldg(a.sems + pix);
+        if (!a.sample_mode) {
+            packed[k] = rgb_at(pix);
+        } else {
+            const Bilin b = bilin_weights<false>(valid[k] ? u : 0.0, valid[k] ? v : 0.0);
+            const int u0 = (int)b.u0, u1 = (int)b.u1, v0 = (int)b.v0, v1 = (int)b.v1;   // inside the image: 1 < u < W-1
+            auto at = [&](int vv, int uu) { return rgb_at(valid[k] ? (img0 + vv) * a.W + uu : 0); };   // never out of the stack
+            packed[k] = bilin_rgb(b, at(v0, u0), at(v1, u1), at(v1, u0), at(v0, u1));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K1N_PPT; ++k) {
+        keep[k] = valid[k] && !in_mask(a.filt, cls[k]);
+        packed[k] |= cls[k] << 24;
     }
     if (bad_uv) atomicOr(a.ticket + 1, PCA_STATUS_UV_OUT_OF_IMAGE);
 
-    const TileScan sc = tile_compact<BLK>(keep, a.state, tile, a.epoch, a.ticket + 1);
+    const TileScanT<K1N_PPT> sc = tile_compact<K1N_BLK, K1N_PPT>(keep, a.state, tile, a.epoch, a.ticket + 1);
     const int64_t tile_base = a.frame_off[a.slot] + (int64_t)sc.excl;
     bool overflow = false;
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
+    for (int k = 0; k < K1N_PPT; ++k) {
         if (!keep[k]) continue;
-        const int64_t p = base_pt + k * BLK + threadIdx.x;
         const int64_t o = tile_base + sc.local[k];
         if (o >= a.st.capacity) { overflow = true; continue; }
-        const double *row = a.pc + p * 7;
-        const double x = row[0], y = row[1], z = row[2];
+        const double x = row[k][0], y = row[k][1], z = row[k][2];
         a.st.x[o] = row4(a.T.m + 0, x, y, z);
         a.st.y[o] = row4(a.T.m + 4, x, y, z);
         a.st.z[o] = row4(a.T.m + 8, x, y, z);
-        a.st.intensity[o] = (float)row[3];
+        a.st.intensity[o] = (float)row[k][3];
         a.st.rgbs[o] = packed[k];
-        a.st.inst[o] = (int32_t)row[6];
+        a.st.inst[o] = (int32_t)row[k][6];
         a.st.dyn[o] = 0;
     }
     if (overflow) atomicOr(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
     if (threadIdx.x == 0 && tile == a.total_tiles - 1) a.frame_off[a.slot + 1] = tile_base + sc.total;
+}
+
+// pts_feat_from_img(pts_uv, img, 'bilinear') of the reference (datasets/nuscenes_utils.py:181-210) for a 2-D map:
+// the reference's arithmetic to the letter (bilin_weights<true>); raises the UV status bit where the reference asserts.
+struct BilinArgs { const double *map; int H, W; const double *uv; int n; double *out; uint32_t *status; };
+
+__global__ __launch_bounds__(SBLK) void sample_bilinear(const BilinArgs a)
+{
+    const int p = blockIdx.x * SBLK + threadIdx.x;
+    if (p >= a.n) return;
+    const double u = a.uv[2 * p], v = a.uv[2 * p + 1];
+    if (!(u > 1.0 && u < (double)a.W - 1.0 && v > 1.0 && v < (double)a.H - 1.0)) { atomicOr(a.status, PCA_STATUS_UV_OUT_OF_IMAGE); a.out[p] = 0.0; return; }
+    const Bilin b = bilin_weights<true>(u, v);
+    const int u0 = (int)b.u0, u1 = (int)b.u1, v0 = (int)b.v0, v1 = (int)b.v1;
+    a.out[p] = bilin_value(b, a.map[(int64_t)v0 * a.W + u0], a.map[(int64_t)v1 * a.W + u1], a.map[(int64_t)v1 * a.W + u0],
+                           a.map[(int64_t)v0 * a.W + u1]);
 }
 
 // =============================================================================================
@@ -456,13 +505,40 @@ int pca_nusc_sample_filter_transform(pca_ctx *ctx, const double *pc, const int64
                                      const double T[16], const uint64_t filter_mask[4], const pca_store *store,
                                      int64_t *frame_off, int slot, void *stream)
 {
+    return pca_nusc_sample_filter_transform_ex(ctx, pc, cam_idx, n, imgs, sems, ncam, H, W, T, filter_mask, store, frame_off,
+                                               slot, PCA_SAMPLE_NEAREST, stream);
+}
+
+int pca_sample_bilinear(pca_ctx *ctx, const double *map, int H, int W, const double *uv, int32_t n, double *out, void *stream)
+{
     if (!ctx) return -1;
+    if (n < 0 || (n > 0 && (!map || !uv || !out)) || H < 1 || W < 1) { ctx->err = "bilinear: bad arguments"; return -1; }
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    BilinArgs a;
+    a.map = map; a.H = H; a.W = W; a.uv = uv; a.n = n; a.out = out; a.status = ctx->ticket + 1;
+    hipLaunchKernelGGL(sample_bilinear, dim3((n + SBLK - 1) / SBLK), dim3(SBLK), 0, s, a);
+    PCA_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+int pca_nusc_sample_filter_transform_ex(pca_ctx *ctx, const double *pc, const int64_t *cam_idx, int32_t n,
+                                        const uint8_t *imgs, const uint8_t *sems, int ncam, int H, int W,
+                                        const double T[16], const uint64_t filter_mask[4], const pca_store *store,
+                                        int64_t *frame_off, int slot, int sample_mode, void *stream)
+{
+    if (!ctx) return -1;
+    if (sample_mode != PCA_SAMPLE_NEAREST && sample_mode != PCA_SAMPLE_BILINEAR) { ctx->err = "k1n: unknown sample_mode"; return -1; }
+    if (ncam < 1 || H < 1 || W < 1 || (int64_t)ncam * H * W * 3 < 4) { ctx->err = "k1n: bad image stack"; return -1; }
     if (n < 0 || (n > 0 && (!pc || !cam_idx || !imgs || !sems)) || !store || !frame_off) { ctx->err = "k1n: bad arguments"; return -1; }
     hipStream_t s = (hipStream_t)stream;
     PCA_CHECK(ctx, hipSetDevice(ctx->device));
-    const int total = n > 0 ? (n + PPT * CBLK - 1) / (PPT * CBLK) : 1;
+    const int total = n > 0 ? (n + K1N_PPT * K1N_BLK - 1) / (K1N_PPT * K1N_BLK) : 1;
     if (pca_ctx_reserve_tiles(ctx, total, s)) return -1;
     K1nArgs a;
+    a.sample_mode = sample_mode;
+    a.static_tiles = total <= ctx->n_cu;
     a.pc = pc; a.cam_idx = cam_idx; a.n = n; a.total_tiles = total;
     a.imgs = imgs; a.sems = sems; a.ncam = ncam; a.H = H; a.W = W;
     for (int i = 0; i < 16; ++i) a.T.m[i] = T[i];
@@ -470,7 +546,7 @@ int pca_nusc_sample_filter_transform(pca_ctx *ctx, const double *pc, const int64
     a.st = *store; a.frame_off = frame_off; a.slot = slot;
     a.state = ctx->tile_state; a.ticket = ctx->ticket;
     a.epoch = pca_ctx_next_epoch(ctx, s);
-    PCA_LAUNCH(ctx, PCA_K_NUSC, k1n_nusc<CBLK>, dim3(total), dim3(CBLK), s, a);
+    PCA_LAUNCH(ctx, PCA_K_NUSC, k1n_nusc, dim3(total), dim3(K1N_BLK), s, a);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }

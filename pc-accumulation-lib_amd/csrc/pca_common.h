@@ -96,6 +96,45 @@ __device__ __forceinline__ double row4(const double *r, double x, double y, doub
     return a;
 }
 
+// Bilinear sampling weights of pts_feat_from_img(..., 'bilinear') (datasets/nuscenes_utils.py:197-210 of the
+// reference): neighbours floor / ceil, weights as un-fused f64 expressions, the fourth weight as 1 - (sum of the others),
+// value = ((w_ff a(v0,u0) + w_cc a(v1,u1)) + w_cf a(v1,u0)) + w_fc a(v0,u1).
+// STRICT = the reference's arithmetic to the letter (an integer coordinate makes floor == ceil, area 0, NaN);
+// otherwise the opt-in sample mode of K1 / K1n: the upper neighbour is floor + 1 (its weight is then exactly 0).
+struct Bilin { double u0, u1, v0, v1, w_ff, w_cc, w_cf, w_fc; };
+template <bool STRICT>
+__device__ __forceinline__ Bilin bilin_weights(double u, double v)
+{
+    Bilin b;
+    b.u0 = floor(u); b.v0 = floor(v);
+    b.u1 = STRICT ? ceil(u) : b.u0 + 1.0;
+    b.v1 = STRICT ? ceil(v) : b.v0 + 1.0;
+    const double area = (b.u1 - b.u0) * (b.v1 - b.v0);
+    b.w_ff = (b.u1 - u) * (b.v1 - v) / area;
+    b.w_cc = (u - b.u0) * (v - b.v0) / area;
+    b.w_fc = (u - b.u0) * (b.v1 - v) / area;
+    b.w_cf = 1.0 - (b.w_ff + b.w_cc + b.w_fc);
+    return b;
+}
+__device__ __forceinline__ double bilin_value(const Bilin &b, double a_ff, double a_cc, double a_cf, double a_fc)
+{
+    return b.w_ff * a_ff + b.w_cc * a_cc + b.w_cf * a_cf + b.w_fc * a_fc;
+}
+// r,g,b of four corner pixels (packed r | g<<8 | b<<16) -> packed bilinear colour, every channel rounded half-to-even
+__device__ __forceinline__ uint32_t bilin_rgb(const Bilin &b, uint32_t c_ff, uint32_t c_cc, uint32_t c_cf, uint32_t c_fc)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const int sh = 8 * ch;
+        double v = rint(bilin_value(b, (double)((c_ff >> sh) & 255u), (double)((c_cc >> sh) & 255u),
+                                    (double)((c_cf >> sh) & 255u), (double)((c_fc >> sh) & 255u)));
+        v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+        out |= (uint32_t)v << sh;
+    }
+    return out;
+}
+
 // f64 -> f16 bits, round-to-nearest-even straight from the double (numpy astype(np.float16)).
 // Shipped form: f64 -> f32 with round-to-ODD (truncate, then set the last bit if anything was lost: the sticky bit
 // survives), then the hardware's f32 -> f16 round-to-nearest-even.  Rounding to odd into a format with more than

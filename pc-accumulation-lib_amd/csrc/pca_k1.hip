@@ -81,6 +81,7 @@ struct K1Args {
     uint64_t *state;
     uint32_t *status;
     uint32_t epoch;
+    int sample_mode;                    // 0 nearest (the reference); 1 bilinear rgb (opt-in), class stays nearest
     int tpf;                            // tiles per frame if every frame of the launch has the same, else 0
     float4 *rec_p;                      // SPLIT: [tiles][TILE] kept records: x, y, z, intensity (f32, as loaded)
     uint32_t *rec_c;                    // SPLIT: [tiles][TILE]               rgb | class << 24
@@ -94,7 +95,8 @@ struct K1Args {
 
 // velo2frame + velo2img of one point: pixel index v*W+u, or -1 if outside the frustum (sem_pc_accum.py:347-394).
 // P rows as fma chains in k order (= the dgemm numpy runs), IEEE f64 divide, np.round = rint.
-__device__ __forceinline__ int k1_project_pixel(const Mat34 &P, float xf, float yf, float zf, int W, int H)
+__device__ __forceinline__ int k1_project_pixel(const Mat34 &P, float xf, float yf, float zf, int W, int H,
+                                                double *uq = nullptr, double *vq = nullptr)
 {
     const double x = (double)xf, y = (double)yf, z = (double)zf;
     const double fx = row4(P.m + 0, x, y, z);
@@ -102,8 +104,10 @@ __device__ __forceinline__ int k1_project_pixel(const Mat34 &P, float xf, float 
     double d = row4(P.m + 8, x, y, z);
     if (d == 0.0) d = -1e-6;
     const double ad = fabs(d);
-    const double uf = rint(fx / ad);
-    const double vf = rint(fy / ad);
+    const double qu = fx / ad, qv = fy / ad;
+    const double uf = rint(qu);
+    const double vf = rint(qv);
+    if (uq) { *uq = qu; *vq = qv; }
     const bool ok = (uf >= 0.0) && (uf < (double)W) && (vf >= 0.0) && (vf < (double)H) && (d > 0.0) && (d < __builtin_huge_val());
     return ok ? (int)vf * W + (int)uf : -1;
 }
@@ -147,7 +151,7 @@ __device__ __forceinline__ K1Frame k1_find_frame(const K1Frame *frames, int f_lo
 }
 static_assert(sizeof(K1Frame) == 48, "k1_find_frame reads a descriptor as three 16-byte words");
 
-template <int BLK, int PPT, bool SPLIT>
+template <int BLK, int PPT, bool SPLIT, bool BILIN>
 __global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a)
 {
     constexpr int TILE = BLK * PPT, NW = BLK / PCA_WAVE, NC = PPT * NW;
@@ -280,24 +284,35 @@ __global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a)
         unsigned cls[PPT], rgb[PPT];
         bool ok[PPT];
         const int last = a.H * a.W * 3 - 4;                               // last legal 4-byte window of the image
+        auto rgb_at = [&](int pix) -> uint32_t {                          // r | g<<8 | b<<16 of one pixel: ONE unaligned dword
+            int off = pix * 3;
+            if (last >= 0) {
+                const int sh = off > last ? (off - last) * 8 : 0;
+                off = off > last ? last : off;
+                return (k1_ldg_u32_unaligned(fr.rgb + off) >> sh) & 0xffffffu;
+            }                                                              // image smaller than four bytes
+            return (uint32_t)k1_ldg(fr.rgb + off) | ((uint32_t)k1_ldg(fr.rgb + off + 1) << 8) |
+                   ((uint32_t)k1_ldg(fr.rgb + off + 2) << 16);
+        };
 #pragma unroll
         for (int r = 0; r < PPT; ++r) {
             ok[r] = false; cls[r] = 0; rgb[r] = 0;
             if ((uint32_t)(r * BLK) < ncand) {
                 const uint32_t j = (uint32_t)(r * BLK) + threadIdx.x;
-                const int px = k1_project_pixel(a.P, p[r].x, p[r].y, p[r].z, a.W, a.H);
+                double qu = 0.0, qv = 0.0;
+                const int px = BILIN ? k1_project_pixel(a.P, p[r].x, p[r].y, p[r].z, a.W, a.H, &qu, &qv)
+                                     : k1_project_pixel(a.P, p[r].x, p[r].y, p[r].z, a.W, a.H);
                 ok[r] = j < ncand && px >= 0;
                 const int pix = ok[r] ? px : 0;                           // pixel 0 is always a valid address
                 // two gathers per point: the class byte and ONE unaligned dword holding r,g,b
                 cls[r] = k1_ldg(fr.sem + pix);
-                int off = pix * 3;
-                if (last >= 0) {
-                    const int sh = off > last ? (off - last) * 8 : 0;
-                    off = off > last ? last : off;
-                    rgb[r] = k1_ldg_u32_unaligned(fr.rgb + off) >> sh;
-                } else {                                                   // image smaller than four bytes
-                    rgb[r] = (uint32_t)k1_ldg(fr.rgb + off) | ((uint32_t)k1_ldg(fr.rgb + off + 1) << 8) |
-                             ((uint32_t)k1_ldg(fr.rgb + off + 2) << 16);
+                if (!BILIN) {
+                    rgb[r] = rgb_at(pix);
+                } else {                                                   // opt-in: bilinear colour, neighbours clamped to the image
+                    const Bilin b = bilin_weights<false>(ok[r] ? qu : 0.0, ok[r] ? qv : 0.0);
+                    auto cl = [](double v, int n) { return (int)(v < 0.0 ? 0.0 : (v > (double)(n - 1) ? (double)(n - 1) : v)); };
+                    const int u0 = cl(b.u0, a.W), u1 = cl(b.u1, a.W), v0 = cl(b.v0, a.H), v1 = cl(b.v1, a.H);
+                    rgb[r] = bilin_rgb(b, rgb_at(v0 * a.W + u0), rgb_at(v1 * a.W + u1), rgb_at(v1 * a.W + u0), rgb_at(v0 * a.W + u1));
                 }
             }
         }
@@ -483,7 +498,7 @@ struct K1Plan {
 static int k1_prepare(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames, const double P[12], int H, int W,
                       const uint64_t filter_mask[4], const pca_store *store, int64_t *frame_off, int first_slot,
                       bool fused, int blk, int ppt, int ws_slot, K1Frame *hf, const K1Frame *dev_frames, K1Plan *plan,
-                      hipStream_t s)
+                      int sample_mode, hipStream_t s)
 {
     const int tile_pts = blk * ppt;
     auto tiles_of = [&](int n) { return n > 0 ? (n + tile_pts - 1) / tile_pts : 1; };
@@ -521,6 +536,7 @@ static int k1_prepare(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames,
     a.n_queues = Q;
     a.n_frames = n_frames;
     a.tpf = equal ? tiles_of(frames[0].n) : 0;
+    a.sample_mode = sample_mode;
     a.frames = n_frames > 1 ? dev_frames : nullptr;
     a.one = hf[0];
     for (int i = 0; i < 12; ++i) a.P.m[i] = P[i];
@@ -582,8 +598,11 @@ static int k1_prepare(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames,
 static int k1_launch_split(pca_ctx *ctx, int blk, int ppt, const K1Plan *plan, hipStream_t s)
 {
     bool launched = false;
-#define K1_CASE(B, Pp) if (blk == B && ppt == Pp) { hipLaunchKernelGGL((k1_kitti<B, Pp, true>), plan->grid_front, dim3(B), 0, s, plan->fa); launched = true; }
-    K1_CASE(256, 4) K1_CASE(512, 4) K1_CASE(1024, 4) K1_CASE(128, 4) K1_CASE(256, 2) K1_CASE(512, 2)
+#define K1_CASE(B, Pp) if (blk == B && ppt == Pp) { \
+        if (plan->fa.sample_mode) hipLaunchKernelGGL((k1_kitti<B, Pp, true, true>), plan->grid_front, dim3(B), 0, s, plan->fa); \
+        else hipLaunchKernelGGL((k1_kitti<B, Pp, true, false>), plan->grid_front, dim3(B), 0, s, plan->fa); \
+        launched = true; }
+    K1_CASE(256, 4) K1_CASE(512, 4) K1_CASE(1024, 4)
 #undef K1_CASE
     if (!launched) { ctx->err = "k1: unsupported PCA_K1_CFG"; return -1; }
     hipLaunchKernelGGL(k1_append, dim3(plan->tiles), dim3(K1_APPEND_BLK), 0, s, plan->pa);
@@ -595,7 +614,16 @@ int pca_kitti_project_sample_filter(pca_ctx *ctx, const pca_kitti_frame *frames,
                                     int H, int W, const uint64_t filter_mask[4], const pca_store *store,
                                     int64_t *frame_off, int first_slot, void *stream)
 {
+    return pca_kitti_project_sample_filter_ex(ctx, frames, n_frames, P, H, W, filter_mask, store, frame_off, first_slot,
+                                              PCA_SAMPLE_NEAREST, stream);
+}
+
+int pca_kitti_project_sample_filter_ex(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames, const double P[12],
+                                       int H, int W, const uint64_t filter_mask[4], const pca_store *store,
+                                       int64_t *frame_off, int first_slot, int sample_mode, void *stream)
+{
     if (!ctx) return -1;
+    if (sample_mode != PCA_SAMPLE_NEAREST && sample_mode != PCA_SAMPLE_BILINEAR) { ctx->err = "k1: unknown sample_mode"; return -1; }
     if (!frames || n_frames <= 0 || !store || !frame_off || !P) { ctx->err = "k1: bad arguments"; return -1; }
     if (H < 0 || W < 0 || (int64_t)H * W * 3 >= (1ll << 31)) { ctx->err = "k1: image too large"; return -1; }
     hipStream_t s = (hipStream_t)stream;
@@ -639,10 +667,11 @@ int pca_kitti_project_sample_filter(pca_ctx *ctx, const pca_kitti_frame *frames,
     int rc = 0;
     if (fused) {
         K1Plan plan;
-        rc = k1_prepare(ctx, frames, n_frames, P, H, W, filter_mask, store, frame_off, first_slot, true, K1_FUSED_BLK, K1_FUSED_PPT, 0, hf, df, &plan, s);
+        rc = k1_prepare(ctx, frames, n_frames, P, H, W, filter_mask, store, frame_off, first_slot, true, K1_FUSED_BLK, K1_FUSED_PPT, 0, hf, df, &plan, sample_mode, s);
         if (rc == 0) rc = upload();
         if (rc == 0) {
-            hipLaunchKernelGGL((k1_kitti<K1_FUSED_BLK, K1_FUSED_PPT, false>), plan.grid_front, dim3(K1_FUSED_BLK), 0, s, plan.fa);
+            if (sample_mode) hipLaunchKernelGGL((k1_kitti<K1_FUSED_BLK, K1_FUSED_PPT, false, true>), plan.grid_front, dim3(K1_FUSED_BLK), 0, s, plan.fa);
+            else hipLaunchKernelGGL((k1_kitti<K1_FUSED_BLK, K1_FUSED_PPT, false, false>), plan.grid_front, dim3(K1_FUSED_BLK), 0, s, plan.fa);
             if (hipGetLastError() != hipSuccess) { ctx->err = "k1: launch failed"; rc = -1; }
         }
     } else {
@@ -661,7 +690,7 @@ int pca_kitti_project_sample_filter(pca_ctx *ctx, const pca_kitti_frame *frames,
             }
             plans.emplace_back();
             rc = k1_prepare(ctx, frames + k0, k1 - k0, P, H, W, filter_mask, store, frame_off, first_slot + k0, false, blk, ppt,
-                            0, hf + k0, df + k0, &plans.back(), s);
+                            0, hf + k0, df + k0, &plans.back(), sample_mode, s);
             k0 = k1;
         }
         if (rc == 0) rc = upload();

@@ -4,8 +4,9 @@ Hot-path pieces and where they run:
   homo_transform (:46-60)           host numpy here for tiny inputs (instance centres, lane poses); per-point
                                      transforms run in the K1n / K0n device kernels
   pts_feat_from_img (:181-214)      'nearest' is fused into K1n on the device; the numpy form here serves
-                                     direct callers (and the opt-in 'bilinear' mode, 2-D feature maps only,
-                                     as in the reference)
+                                     direct callers.  'bilinear' (2-D feature maps only, as in the reference) runs
+                                     on the device: pca_sample_bilinear; the same weights drive the opt-in
+                                     sample_mode='bilinear' of K1 / K1n
   NuScenesCamera.project_pts3d      device kernel K0n via ``project_to_cameras`` (all cameras in one launch)
 nuscenes-devkit / pyquaternion are imported lazily: everything that does not touch the dataset works
 without them.
@@ -33,15 +34,27 @@ def pts_feat_from_img(pts_uv, img, method='bilinear'):
     if method == 'nearest':
         uv = np.round(pts_uv).astype(int)
         return img[uv[:, 1], uv[:, 0]]
-    u, v = pts_uv[:, 0], pts_uv[:, 1]
-    u0, u1, v0, v1 = np.floor(u), np.ceil(u), np.floor(v), np.ceil(v)
-    area = (u1 - u0) * (v1 - v0)
-    w_ff = (u1 - u) * (v1 - v) / area
-    w_cc = (u - u0) * (v - v0) / area
-    w_fc = (u - u0) * (v1 - v) / area
-    w_cf = 1. - (w_ff + w_cc + w_fc)
-    u0, u1, v0, v1 = u0.astype(int), u1.astype(int), v0.astype(int), v1.astype(int)
-    return w_ff * img[v0, u0] + w_cc * img[v1, u1] + w_cf * img[v1, u0] + w_fc * img[v0, u1]
+    if img.ndim != 2:
+        # the reference's branch multiplies (N,) weights with (N,C) features: it only broadcasts for 2-D maps
+        raise ValueError(f'operands could not be broadcast together with shapes ({pts_uv.shape[0]},) {img[0, [0]].shape}')
+    return sample_bilinear_device(pts_uv, img)
+
+
+def sample_bilinear_device(pts_uv, feat_map):
+    """(N,2) float pixel coordinates, (H,W) map -> (N,) f64 bilinear samples on the device (pca_sample_bilinear: floor /
+    ceil neighbours, un-fused f64 weights, the fourth as 1 - (sum of the others) -- the reference's arithmetic)."""
+    import torch
+    from pca_amd import _lib
+    ctx = _lib.Context.get()
+    dev = torch.device('cuda', ctx.device_index)
+    m = torch.from_numpy(np.ascontiguousarray(feat_map, dtype=np.float64)).to(dev)
+    uv = torch.from_numpy(np.ascontiguousarray(pts_uv, dtype=np.float64)).to(dev)
+    out = torch.empty(uv.shape[0], dtype=torch.float64, device=dev)
+    ctx.check(ctx.lib.pca_sample_bilinear(ctx.h, m.data_ptr(), int(m.shape[0]), int(m.shape[1]), uv.data_ptr(),
+                                          int(uv.shape[0]), out.data_ptr(), ctx.stream()))
+    if ctx.status() & _lib.STATUS_UV_OUT_OF_IMAGE:
+        raise AssertionError('pts_uv must be all inside image')
+    return out.cpu().numpy()
 
 
 def project_to_cameras(pc_lidar, ego_from_lidar, glob_from_ego, cams_glob_from_self, cams_K, cams_wh):

@@ -118,7 +118,7 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         if len(self._track) > 0:          # move everything stored so far into the new ego frame
             self.update_poses(T_new_prev)
             self.update_sem_pcs(T_new_prev)
-        self.store.append_kitti([frame], self.P_velo_frame, H, W, self.semseg_filters)
+        self.store.append_kitti([frame], self.P_velo_frame, H, W, self.semseg_filters, sample_mode=self.sample_mode)
         self._track.append([0., 0., 0.])
         self.rgbs.append(rgb)
         self.semsegs.append(semseg)
@@ -161,7 +161,8 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
             self.rgbs.append(rgb)
             self.semsegs.append(semseg)
         self.store.flush_pending()
-        self.store.append_kitti(frames, self.P_velo_frame, shape[0], shape[1], self.semseg_filters)
+        self.store.append_kitti(frames, self.P_velo_frame, shape[0], shape[1], self.semseg_filters,
+                                sample_mode=self.sample_mode)
         self.store.retransform_batch(np.stack(Ts), len(frames))
         removed, total = [], 0
         for T_new_prev in Ts:                           # host bookkeeping, frame by frame as integrate() does

@@ -117,7 +117,7 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
         else:
             sems = up(np.stack(semsegs), np.uint8, torch.uint8)
         self.store.append_nusc(up(pc, np.float64, torch.float64), up(pc_cam_idx, np.int64, torch.int64), imgs, sems,
-                               T_ego_world, self.semseg_filters)
+                               T_ego_world, self.semseg_filters, sample_mode=self.sample_mode)
         return pose, semsegs
 
     def obs2sem_vec_space(self, rgbs, pc, pc_cam_idx, T_ego_global, ego_pose_z: float = 0) -> tuple:

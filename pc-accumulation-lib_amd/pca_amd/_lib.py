@@ -14,10 +14,11 @@ STATUS_STORE_OVERFLOW = 1
 STATUS_UV_OUT_OF_IMAGE = 2
 STATUS_NEGATIVE_INTENSITY = 4
 STATUS_LOOKBACK_TIMEOUT = 8
+SAMPLE_MODES = {'nearest': 0, 'bilinear': 1}
 
 EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error', 'pca_status',
-           'pca_kitti_project_sample_filter',
-           'pca_nusc_sample_filter_transform', 'pca_nusc_project_cams', 'pca_retransform', 'pca_retransform_batch_tail',
+           'pca_kitti_project_sample_filter', 'pca_kitti_project_sample_filter_ex',
+           'pca_nusc_sample_filter_transform', 'pca_nusc_sample_filter_transform_ex', 'pca_sample_bilinear', 'pca_nusc_project_cams', 'pca_retransform', 'pca_retransform_batch_tail',
            'pca_mark_dynamic',
            'pca_bev_workspace_bytes', 'pca_bev_generate', 'pca_bev_generate_ex', 'pca_bev_warp', 'pca_voxel_dedup_workspace_bytes', 'pca_voxel_dedup', 'pca_icp_workspace_bytes', 'pca_icp_register', 'pca_host_ego_to_grid',
            'pca_profile_enable', 'pca_profile_read')
@@ -85,6 +86,15 @@ def load():
         vp, C.POINTER(PcaKittiFrame), i32, C.POINTER(C.c_double), i32, i32, C.POINTER(C.c_uint64),
         C.POINTER(PcaStore), vp, i32, vp
     ]
+    lib.pca_kitti_project_sample_filter_ex.argtypes = [
+        vp, C.POINTER(PcaKittiFrame), i32, C.POINTER(C.c_double), i32, i32, C.POINTER(C.c_uint64),
+        C.POINTER(PcaStore), vp, i32, i32, vp
+    ]
+    lib.pca_nusc_sample_filter_transform_ex.argtypes = [
+        vp, vp, vp, C.c_int32, vp, vp, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+        C.POINTER(PcaStore), vp, i32, i32, vp
+    ]
+    lib.pca_sample_bilinear.argtypes = [vp, vp, i32, i32, vp, C.c_int32, vp, vp]
     lib.pca_nusc_sample_filter_transform.argtypes = [
         vp, vp, vp, C.c_int32, vp, vp, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
         C.POINTER(PcaStore), vp, i32, vp

@@ -147,10 +147,11 @@ class DeviceStore:
             descs[k].n = n
         return descs
 
-    def append_kitti(self, frames, P, H, W, filters, descs=None):
+    def append_kitti(self, frames, P, H, W, filters, descs=None, sample_mode='nearest'):
         """frames: list of dicts {pts (n,4) f32 cuda, rgb (H,W,3) u8 cuda | None, sem (H,W) u8 cuda | None,
         sem_gt (n,) u8 cuda | None}.  One call appends all of them (stable order) as new slots.
-        descs: kitti_descs(frames) built earlier (a caller that replays the same batch)."""
+        descs: kitti_descs(frames) built earlier (a caller that replays the same batch).
+        sample_mode: 'nearest' (the reference) or 'bilinear' (opt-in: bilinear rgb, class of the nearest pixel)."""
         lib, ctx = self.ctx.lib, self.ctx
         n_in = sum(int(f['pts'].shape[0]) for f in frames)
         self.reserve(n_in, len(frames))
@@ -162,26 +163,26 @@ class DeviceStore:
         if self._k1_cache is None or self._k1_cache[0] != key:
             self._k1_cache = (key, _lib.f64_array(P, 12), _lib.class_mask(filters))
         Pc, fmask = self._k1_cache[1], self._k1_cache[2]
-        ctx.check(lib.pca_kitti_project_sample_filter(ctx.h, descs, len(frames), Pc, int(H), int(W),
-                                                      fmask, C.byref(st),
-                                                      self.frame_off.data_ptr(), self.tail, ctx.stream()))
+        ctx.check(lib.pca_kitti_project_sample_filter_ex(ctx.h, descs, len(frames), Pc, int(H), int(W),
+                                                         fmask, C.byref(st), self.frame_off.data_ptr(), self.tail,
+                                                         _lib.SAMPLE_MODES[sample_mode], ctx.stream()))
         self.tail += len(frames)
         self.ub_tail += n_in
         self._ub += [int(f['pts'].shape[0]) for f in frames]
         self._ub_sum += n_in
 
     # ---- K1n: NuScenes --------------------------------------------------------------------
-    def append_nusc(self, pc, cam_idx, imgs, sems, T, filters):
+    def append_nusc(self, pc, cam_idx, imgs, sems, T, filters, sample_mode='nearest'):
         lib, ctx = self.ctx.lib, self.ctx
         n = int(pc.shape[0])
         self.reserve(n)
         ncam, H, W = sems.shape
         st = self.c_store()
-        ctx.check(lib.pca_nusc_sample_filter_transform(ctx.h, pc.data_ptr(), cam_idx.data_ptr(), n, imgs.data_ptr(),
-                                                       sems.data_ptr(), int(ncam), int(H), int(W),
-                                                       _lib.f64_array(T, 16), _lib.class_mask(filters),
-                                                       C.byref(st), self.frame_off.data_ptr(), self.tail,
-                                                       ctx.stream()))
+        ctx.check(lib.pca_nusc_sample_filter_transform_ex(ctx.h, pc.data_ptr(), cam_idx.data_ptr(), n, imgs.data_ptr(),
+                                                          sems.data_ptr(), int(ncam), int(H), int(W),
+                                                          _lib.f64_array(T, 16), _lib.class_mask(filters),
+                                                          C.byref(st), self.frame_off.data_ptr(), self.tail,
+                                                          _lib.SAMPLE_MODES[sample_mode], ctx.stream()))
         self.tail += 1
         self.ub_tail += n
         self._ub.append(n)

@@ -46,6 +46,9 @@ class SemanticPointCloudAccumulator:
         self.voxel_dedup = float(env) if env else None
         self.voxel_dedup_every = int(os.environ.get('PCA_VOXEL_DEDUP_EVERY', '1'))
         self._integrated = 0
+        # opt-in sample mode of the projection kernels (extension, default = the reference's nearest pixel):
+        # 'bilinear' mixes r, g, b of the four neighbours (PCA_SAMPLE_MODE=bilinear), the class stays the nearest pixel's
+        self.sample_mode = os.environ.get('PCA_SAMPLE_MODE', 'nearest')
 
         self.sem_bev_generator = None
         if bev_params['type'] == 'sem':

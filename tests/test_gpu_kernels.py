@@ -722,3 +722,80 @@ def test_nuscenes_kernels_randomised_match_oracle(T, orc, seed):
     for f, i in pairs:
         orc.mark_dynamic(ost, offs[f], offs[f + 1], i)
     assert np.array_equal(st.rows(), ost.rows())
+
+
+# ------------------------------------------------------------------------------------------- opt-in bilinear sampling
+def test_bilinear_sampler_matches_reference_fixture(T, golden):
+    """pts_feat_from_img(..., 'bilinear') runs on the device (pca_sample_bilinear) and reproduces the reference's own
+    output bit for bit; errors as the reference: AssertionError outside the image, ValueError for multi-channel maps."""
+    from datasets.nuscenes_utils import pts_feat_from_img
+    g = golden('utils')
+    got = pts_feat_from_img(g['pf_uv_bil'], g['pf_img'][..., 0], 'bilinear')
+    assert got.dtype == np.float64 and np.array_equal(got, g['pf_bilinear'])
+    with pytest.raises(AssertionError):
+        pts_feat_from_img(np.array([[0.5, 5.0]]), g['pf_img'][..., 0], 'bilinear')
+    with pytest.raises(ValueError):
+        pts_feat_from_img(g['pf_uv_bil'], g['pf_img'], 'bilinear')
+
+
+@pytest.mark.parametrize('seed', [0, 1])
+def test_k1_bilinear_mode_matches_oracle(T, orc, seed):
+    """sample_mode='bilinear' of K1 (fused and split launch forms) against the oracle's restatement of the mode; the
+    default mode is untouched (the other K1 tests)."""
+    rng = np.random.default_rng(100 + seed)
+    H, W = (94, 352) if seed == 0 else (376, 1408)
+    frames, host = [], []
+    for n in ([30000, 5] if seed == 0 else [120000] * 3):
+        pc, img, sem = kitti_frame(rng, n, H, W)
+        host.append((pc, img, sem))
+        frames.append(dict(pts=cu(T, pc), rgb=cu(T, img), sem=cu(T, sem)))
+    Pm = P_KITTI if seed else np.array([[138., 0, 176, 0], [0, 138., 47, 0], [0, 0, 1, 0]]) @ np.linalg.inv(
+        np.vstack([np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418],
+                             [-0.999004371, 0.007784614041, 0.04392796942, 0.2993489574],
+                             [-0.01162548558, -0.9960641394, -0.08786966659, -0.1770225824]]), [0, 0, 0, 1]]))
+    st = dev_store(capacity=400000, max_frames=8)
+    st.append_kitti(frames, Pm, H, W, KITTI_FILTERS, sample_mode='bilinear')
+    got = st.frame_rows()
+    st.check_status()
+    orc.set_sample_mode(1)
+    try:
+        differs = 0
+        for (pc, img, sem), rows in zip(host, got):
+            ost = orc.Store(max(pc.shape[0], 1))
+            orc.kitti_project_sample_filter(ost, pc, Pm, img, sem, None, H, W, KITTI_FILTERS)
+            assert np.array_equal(rows, ost.rows())
+            orc.set_sample_mode(0)
+            near = orc.Store(max(pc.shape[0], 1))
+            orc.kitti_project_sample_filter(near, pc, Pm, img, sem, None, H, W, KITTI_FILTERS)
+            orc.set_sample_mode(1)
+            assert np.array_equal(near.rows()[:, [0, 1, 2, 3, 7]], rows[:, [0, 1, 2, 3, 7]])     # same points, same class
+            differs += int((near.rows()[:, 4:7] != rows[:, 4:7]).any(axis=1).sum())
+        assert differs > 100                                                                      # the colours do differ
+    finally:
+        orc.set_sample_mode(0)
+
+
+def test_k1n_bilinear_mode_matches_oracle(T, orc):
+    rng = np.random.default_rng(77)
+    n, ncam, H, W = 9000, 3, 60, 100
+    pc = np.stack([rng.uniform(-30, 30, n), rng.uniform(-30, 30, n), rng.uniform(-2, 4, n),
+                   rng.integers(0, 256, n).astype(float), rng.uniform(1.01, W - 1.01, n), rng.uniform(1.01, H - 1.01, n),
+                   rng.integers(-1, 4, n).astype(float)], 1)
+    pc[:50, 4] = np.floor(pc[:50, 4])                       # integer coordinates: the upper neighbour has weight 0
+    pc[:50, 4] = np.clip(pc[:50, 4], 2, W - 2)
+    cam = rng.integers(-1, ncam, n)
+    imgs = rng.integers(0, 256, (ncam, H, W, 3), dtype=np.uint8)
+    sems = rng.integers(0, 19, (ncam, H, W)).astype(np.uint8)
+    Tm = np.eye(4)
+    Tm[:3, 3] = [5., -2., 0.5]
+    filters = [10, 11, 12, 16, 18]
+    st = dev_store(capacity=n, max_frames=4, intensity_div255=True)
+    st.append_nusc(cu(T, pc), cu(T, cam), cu(T, imgs), cu(T, sems), Tm, filters, sample_mode='bilinear')
+    st.check_status()
+    orc.set_sample_mode(1)
+    try:
+        ost = orc.Store(n, intensity_div255=True)
+        orc.nusc_sample_filter_transform(ost, pc, cam, imgs, sems, Tm, filters)
+    finally:
+        orc.set_sample_mode(0)
+    assert np.array_equal(st.rows(0), ost.rows()) and ost.n > 1000

@@ -186,10 +186,14 @@ def test_ego_split_transform_equals_three_separate_transforms():
 
 def test_pts_feat_from_img_nearest_and_optin_bilinear(golden):
     """datasets/nuscenes_utils.py:181-214: 'nearest' is what every caller uses (and what K1n fuses); 'bilinear' is
-    the reference's unused branch (2-D maps only), kept as an opt-in and pinned on its own output."""
+    the reference's unused branch (2-D maps only), kept as an opt-in and pinned on its own output: here the oracle's
+    restatement, in tests/test_gpu_kernels.py the device kernel (pca_sample_bilinear) against the same fixture."""
     from datasets.nuscenes_utils import pts_feat_from_img
+    from oracle import oracle as orc
     g = golden('utils')
     assert np.array_equal(pts_feat_from_img(g['pf_uv'], g['pf_img'], 'nearest'), g['pf_nearest'])
-    assert np.array_equal(pts_feat_from_img(g['pf_uv_bil'], g['pf_img'][..., 0], 'bilinear'), g['pf_bilinear'])
+    assert np.array_equal(orc.sample_bilinear(g['pf_img'][..., 0], g['pf_uv_bil']), g['pf_bilinear'])
+    with pytest.raises(AssertionError):
+        orc.sample_bilinear(g['pf_img'][..., 0], np.array([[0.5, 5.0]]))
     with pytest.raises(AssertionError):
         pts_feat_from_img(np.array([[0.5, 5.0]]), g['pf_img'], 'nearest')
