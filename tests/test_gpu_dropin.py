@@ -638,3 +638,77 @@ def test_velo2img_matches_reference(golden):
     acc = Kitti360SemanticPointCloudAccumulator(8., calib, 1e3, None, KITTI_FILTERS, SEM_IDXS, True, dict(BEV_KITTI))
     assert np.array_equal(acc.velo2img(g['pc'].copy(), g['P'], int(g['H']), int(g['W'])), g['velo2img'])
     assert np.array_equal(acc.velo2img(g['pc2'].copy(), g['P2'], int(g['H']), int(g['W'])), g['velo2img2'])
+
+
+def test_nuscenes_full_size_scene_matches_oracle_pipeline():
+    """BASELINE configs[2] at full size: 40 frames x 34 720 points, 6 x 900x1600 images, two GT
+    instances (one moving 0.5 m / frame: retroactive dynamic marking), 256^2 BEV at view 51.2 m with height filter 3 m
+    and the NuScenes intensity transform -- the drop-in accumulator against the CPU oracle pipeline."""
+    from PIL import Image
+
+    from nuscenes_oracle_sem_pc_accum import NuScenesOracleSemanticPointCloudAccumulator
+    from oracle import oracle as orc
+    from pca_amd import host_logic as hl
+    from pca_amd.tracker import InstanceTracker
+    F, n, ncam, H, W = 40, 34_720, 6, 900, 1600
+    rng = np.random.default_rng(2024)
+    fake = FakeSemSeg()
+    img_sets = [rng.integers(0, 256, (ncam, H, W, 3), dtype=np.uint8) for _ in range(2)]
+    sem_sets = [np.stack([fake.pred(im)[0, 0] for im in s]).astype(np.uint8) for s in img_sets]
+    pil_sets = [[Image.fromarray(im) for im in s] for s in img_sets]
+    bev_params = dict(type='sem', view_size=51.2, pixel_size=256, max_trans_radius=0., zoom_thresh=0., do_warp=False,
+                      int_scaler=1., int_sep_scaler=30., int_mid_threshold=0.12, height_filter=3.)
+    acc = NuScenesOracleSemanticPointCloudAccumulator('fake.onnx', NUSC_FILTERS, SEM_IDXS, False, bev_params, 'boston',
+                                                      False, None)
+    st = orc.Store(F * n, intensity_div255=True)
+    track, tracker, offs, T_global_world = hl.PoseTrack(), InstanceTracker(), [0], None
+    for k in range(F):
+        a = 0.002 * k
+        T = np.eye(4)
+        T[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        T[:3, 3] = [1000. + 1.0 * k, 500., 0.]
+        pc = np.stack([rng.uniform(-50, 50, n), rng.uniform(-50, 50, n), rng.uniform(-2, 4, n),
+                       rng.integers(0, 256, n).astype(float), rng.uniform(1.01, W - 1.01, n),
+                       rng.uniform(1.01, H - 1.01, n), rng.integers(-1, 5, n).astype(float)], 1)
+        cam = rng.integers(-1, ncam, n)
+        tokens, cls = ['parked', 'moving'], [0, 0]
+        centers = [np.array([1010., 505., 0.5]), np.array([1005. + 0.5 * k, 495., 0.5])]
+        obs = dict(images=pil_sets[k % 2], pc=pc, pc_cam_idx=cam, ego_at_lidar_ts=T, ego_global_x=T[0, 3],
+                   ego_global_y=T[1, 3], inst_tokens=tokens, inst_cls=cls, inst_center=centers)
+        assert acc.integrate([obs]) is None
+        # ---- the oracle pipeline, as tests/test_pipeline_golden.py::test_nuscenes_oracle_integrate_tracker_and_bev ----
+        if T_global_world is None:
+            T_global_world = np.linalg.inv(T)
+        T_ego_world = T_global_world @ T
+        pose = T_ego_world[:3, -1].tolist()
+        pose[2] += 1.
+        m = orc.nusc_sample_filter_transform(st, pc, cam, img_sets[k % 2], sem_sets[k % 2], T_ego_world, NUSC_FILTERS)
+        offs.append(offs[-1] + m)
+        track.append(pose)
+        for ts, inst_idx in tracker.observe(k, tokens, cls, [orc.homo_transform(T_global_world, c[None])[0] for c in centers]):
+            orc.mark_dynamic(st, offs[ts], offs[ts + 1], inst_idx)
+        if len(track.poses) > 1:
+            track.push_segment()
+    acc.store.check_status()
+    sizes = np.diff(offs)
+    assert np.array_equal(acc.store.sizes(), sizes) and 20_000 < sizes.mean() < 27_000
+    rows = acc.store.rows()
+    assert np.array_equal(rows, st.rows())
+    assert rows[:, 9].sum() > 1000 and tracker.dynamic == acc.dyn_instances == ['moving']     # earlier frames marked too
+    assert np.array_equal(np.array(acc.poses), np.array(track.poses))
+    pi = 20
+    bev = acc.generate_bev(pi, 1, gen_future=True)[0]
+    origin = np.array(track.poses[pi])
+    poses = np.array(track.poses)
+    R = hl.rotation_matrix_3d(hl.heading_rot_ang(poses[:pi] - origin))
+    prm = orc.make_bev_params(origin, R, 0., 0., 51.2, 256, 3., 1., 30., 0.12, 0, [13, 14, 15, 17], True)
+    ref = orc.bev(st, int(sizes[:pi].sum()), prm)['f16']
+    for s, name in enumerate(('present', 'future', 'full')):
+        for k, key in ((0, 'road'), (5, 'dynamic'), (6, 'elevation')):
+            assert np.array_equal(bev[f'{key}_{name}'].view(np.uint16), ref[7 * s + k].view(np.uint16)), (key, name)
+        assert np.array_equal(bev[f'rgb_{name}'].view(np.uint16), ref[7 * s + 2:7 * s + 5].view(np.uint16)), name
+        d = np.abs(bev[f'intensity_{name}'].view(np.uint16).astype(int) - ref[7 * s + 1].view(np.uint16).astype(int))
+        assert d.max() <= 1
+    assert (bev['road_full'] != np.float16(0.5)).mean() > 0.9                          # the view is covered
+    others = tracker.split_trajectories(pi)
+    assert len(bev['trajs_full']) == 1 + len(others[2])
