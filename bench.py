@@ -457,31 +457,47 @@ def extras_pass(acc):
 
 
 def pcie_inclusive_pass(acc, pool, n_steps):
-    """The step as the UNCHANGED drivers run it: host numpy inputs (PIL-like image, (N,4) f32 points) and a host fp16 BEV
-    dict out, per step 4 MB H2D + 2.75 MB D2H."""
+    """The step as the UNCHANGED drivers run it: observations start as host arrays (PIL-like image, (N,4) f32 points) and
+    every BEV sample ends as a host fp16 dict -- per step 4 MB H2D + 2.75 MB D2H.  Two forms:
+      plain     integrate(host arrays) + generate_bev(), every sample's planes awaited before the next step;
+      deferred  the same calls, but a sample's planes (they leave on a side stream into pinned memory: LazyBev) are only
+                touched one step later -- what the driver gets when it hands the dict to write_compressed_pickle, whose
+                background writer collects it then (no disk, no gzip in this number).
+    Both are bound by the host: ~0.25 ms of Python + ctypes per step through the drop-in classes, plus the staging copies."""
     import torch
     host_pool = [(f[0].cpu().numpy(), f[1].cpu().numpy(), f[2].cpu().numpy()) for f in pool]
-    host_sem = {id(h[0]): h[2] for h in host_pool}
+    cur = {'k': 0}
 
-    class HostSemSeg:
+    class HostSemSeg:                       # stand-in for the CNN: hands back the host map of the current frame
         def pred(self, rgb):
-            return host_sem[id(rgb)][None, None]
+            return host_pool[cur['k'] % len(pool)][2][None, None]
     model = acc.semseg_model
     acc.semseg_model = HostSemSeg()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    bevs = None
-    for k in range(n_steps):
-        rgb_h, pc_h, _ = host_pool[k % len(host_pool)]
-        acc.integrate([(rgb_h, pc_h, None)])
-        bevs = acc.generate_bev(present_index(acc), 1, gen_future=True)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert bevs[0]['rgb_full'].shape == (3, PX, PX)
+    out = {'H2D_MB_per_step': (N_PTS * 16 + IMG_H * IMG_W * 4) / 1e6, 'D2H_MB_per_step': 21 * PX * PX * 2 / 1e6}
+    for name in ('plain', 'deferred'):
+        for rep in range(2):                # the first repetition warms the pinned ring of the copies
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            parked = None
+            for k in range(n_steps):
+                rgb_h, pc_h, _ = host_pool[k % len(host_pool)]
+                cur['k'] = k
+                acc.integrate([(rgb_h, pc_h, None)])
+                bev = acc.generate_bev(present_index(acc), 1, gen_future=True)[0]
+                if name == 'deferred':
+                    bev, parked = parked, bev
+                if bev is not None:
+                    assert bev['rgb_full'].shape == (3, PX, PX)            # waits for that sample's planes
+            if parked is not None:
+                assert parked['rgb_full'].shape == (3, PX, PX)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        out[name] = {'Mpoints_per_s': N_PTS * n_steps / dt / 1e6, 'bev_frames_per_s': n_steps / dt, 'ms_per_step': 1e3 * dt / n_steps}
     acc.semseg_model = model
-    return {'Mpoints_per_s': N_PTS * n_steps / dt / 1e6, 'bev_frames_per_s': n_steps / dt, 'ms_per_step': 1e3 * dt / n_steps,
-            'steps': n_steps, 'H2D_MB_per_step': (N_PTS * 16 + IMG_H * IMG_W * 4) / 1e6, 'D2H_MB_per_step': 21 * PX * PX * 2 / 1e6,
-            'note': 'host numpy inputs and host fp16 BEV dict per step, as the unchanged drivers call it'}
+    out.update(Mpoints_per_s=out['deferred']['Mpoints_per_s'], bev_frames_per_s=out['deferred']['bev_frames_per_s'],
+               ms_per_step=out['deferred']['ms_per_step'], steps=n_steps,
+               note='headline of this block = the deferred form; host-bound (Python), not PCIe-bound')
+    return out
 
 
 # --------------------------------------------------------------------------------------------------------------------

@@ -238,6 +238,15 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
                         uint16_t *planes_f16 /*dev*/, double *extra_planes /*dev, may be NULL*/, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Input normalisation of the semseg CNN on the device.  Replaces utils/onnx_utils.py:26-29, :35-36
+ *     (torchvision ToTensor + Normalize on the host): out[c][y][x] = (rgb[y][x][c] / 255 - mean[c]) / std[c] in IEEE f32.
+ *     rgb: dev [H,W,3] u8; out: dev [3,H,W] f32.  The CNN itself is an external ONNX file (utils/onnx_utils.py binds this
+ *     buffer and the class-map output to an onnxruntime session, so neither visits the host).
+ * ------------------------------------------------------------------------------------------------ */
+int pca_image_to_nchw_f32(pca_ctx *ctx, const uint8_t *rgb /*dev*/, int H, int W, const float mean[3], const float std[3],
+                          float *out /*dev*/, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Polynomial warp of finished fp16 planes (--bev_do_warp augmentation).  Replaces
  *       bev_generator/bev_generator.py:482-525 (warp_dense_probmaps: a Python loop over px^2 cells).
  *     out[n][jw][iw] = in[n][clamp(rint(b_1 jw + b_2 jw^2))][clamp(rint(a_1 iw + a_2 iw^2))], the index expressions

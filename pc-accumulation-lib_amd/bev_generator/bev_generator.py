@@ -212,7 +212,7 @@ class BEVGenerator(ABC):
             pc = pc[pc[:, 2] < self.height_filter]
         return self.pos2grid(pc, aug_view_size), out_trajs
 
-    def generate_rand_aug(self, pcs: dict, trajs: dict, do_warping: bool = True):
+    def generate_rand_aug(self, pcs: dict, trajs: dict, do_warping: bool = True, device_only: bool = False, out=None):
         np.random.seed((os.getpid() * int(time.time())) % 123456789)
         rot_ang = 2 * np.pi * np.random.random()
         trans_r = self.max_trans_radius * np.random.random()
@@ -221,13 +221,13 @@ class BEVGenerator(ABC):
         trans_dy = trans_r * np.sin(trans_ang)
         zoom_scalar = np.random.normal(0, 0.1)
         zoom_scalar = 1 + min(max(zoom_scalar, -self.zoom_thresh), self.zoom_thresh)
-        return self.generate(pcs, trajs, rot_ang, trans_dx, trans_dy, zoom_scalar, do_warping)
+        return self.generate(pcs, trajs, rot_ang, trans_dx, trans_dy, zoom_scalar, do_warping, device_only, out)
 
-    def generate_multiproc(self, bev_gen_inputs):
+    def generate_multiproc(self, bev_gen_inputs, device_only: bool = False, out=None):
         pcs, trajs = bev_gen_inputs
         if self.do_aug:
-            return self.generate_rand_aug(pcs, trajs)
-        return self.generate(pcs, trajs)
+            return self.generate_rand_aug(pcs, trajs, device_only=device_only, out=out)
+        return self.generate(pcs, trajs, device_only=device_only, out=out)
 
     def generate_rand_aug_multiproc(self, bev_gen_inputs):
         pcs, trajs = bev_gen_inputs

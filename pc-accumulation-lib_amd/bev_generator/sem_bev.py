@@ -10,6 +10,52 @@ import numpy as np
 from .bev_generator import PLANES, SETS, BEVGenerator, WindowPart
 
 
+class LazyBev(dict):
+    """The reference's BEV dict whose plane arrays are still on their way from the device: the fp16 D2H copy was
+    enqueued on a side stream into pinned memory; the first access waits for THAT copy only and fills the dict in.
+    A consumer that hands the dict to a background writer (write_compressed_pickle does) never waits at all."""
+
+    def __init__(self, host, index, event, trajs, gt_lanes=None):
+        super().__init__()
+        self._pending = (host, index, event, trajs, gt_lanes)
+
+    def _fill(self):
+        if self._pending is not None:
+            host, index, event, trajs, gt_lanes = self._pending
+            self._pending = None
+            event.synchronize()
+            # own copy: the pinned block belongs to a ring and is reused for a later sample
+            dict.update(self, SemBEVGenerator.pack_bev(np.array(host[index].numpy()), trajs[0], trajs[1], trajs[2], gt_lanes))
+        return self
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self._fill(), k)
+
+    def __contains__(self, k):
+        return dict.__contains__(self._fill(), k)
+
+    def __iter__(self):
+        return dict.__iter__(self._fill())
+
+    def __len__(self):
+        return dict.__len__(self._fill())
+
+    def keys(self):
+        return dict.keys(self._fill())
+
+    def items(self):
+        return dict.items(self._fill())
+
+    def values(self):
+        return dict.values(self._fill())
+
+    def get(self, k, default=None):
+        return dict.get(self._fill(), k, default)
+
+    def __reduce__(self):                         # pickles as the plain dict the reference writes
+        return (dict, (dict(self._fill()), ))
+
+
 class SemBEVGenerator(BEVGenerator):
 
     def __init__(self,
@@ -75,6 +121,41 @@ class SemBEVGenerator(BEVGenerator):
                 out['gt_lanes'] = gt_lane_trajs
             return out
         return self.pack_bev(p16.cpu().numpy(), trajs_present, trajs_future, trajs_full, gt_lane_trajs)
+
+    def to_host_async(self, planes, results):
+        """planes: cuda float16 [k,21,px,px] holding the k device_only results `results` (generate(..., device_only=True,
+        out=planes[i])).  ONE device->host copy of all k samples is enqueued on a side stream into pinned memory; returns
+        k LazyBev dicts at once (bev_num > 1: the k augmented rasters run back to back, no host round trip between)."""
+        import torch
+        if getattr(self, '_d2h_stream', None) is None:
+            self._d2h_stream = torch.cuda.Stream(planes.device)
+            self._d2h_ring, self._d2h_next = [None] * 8, 0
+        # pinned ring: a block is reused 8 calls later; whoever still waits on it then is filled in first
+        slot = self._d2h_next % len(self._d2h_ring)
+        self._d2h_next += 1
+        old = self._d2h_ring[slot]
+        host = None
+        if old is not None:
+            for ref in old[1]:
+                bev = ref()
+                if bev is not None:
+                    bev._fill()
+            if tuple(old[0].shape) == tuple(planes.shape):
+                host = old[0]
+        if host is None:
+            host = torch.empty(tuple(planes.shape), dtype=torch.float16).pin_memory()
+        side = self._d2h_stream
+        side.wait_stream(torch.cuda.current_stream(planes.device))
+        with torch.cuda.stream(side):
+            host.copy_(planes, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record(side)
+        planes.record_stream(side)
+        out = [LazyBev(host, i, event, (r['trajs_present'], r['trajs_future'], r['trajs_full']), r.get('gt_lanes'))
+               for i, r in enumerate(results)]
+        import weakref
+        self._d2h_ring[slot] = (host, [weakref.ref(b) for b in out])
+        return out
 
     @staticmethod
     def warp_planes_device(p16, a_1, a_2, b_1, b_2, out16=None):

@@ -620,6 +620,40 @@ int pca_retransform_batch_tail(pca_ctx *ctx, const pca_store *store, const int64
     return 0;
 }
 
+// (H,W,3) u8 -> (3,H,W) f32, (x / 255 - mean) / std: the input normalisation of the reference's semseg wrapper
+// (utils/onnx_utils.py:26-29, torchvision ToTensor + Normalize) with IEEE f32 divisions, so the CNN sees the bits the
+// reference feeds it while the image never leaves the device.
+struct NormArgs { const uint8_t *rgb; float *out; int H, W; float mean[3], std[3]; };
+
+__global__ __launch_bounds__(SBLK) void image_to_nchw_f32(const NormArgs a)
+{
+    const int64_t n = (int64_t)a.H * a.W;
+    for (int64_t p = (int64_t)blockIdx.x * SBLK + threadIdx.x; p < n; p += (int64_t)gridDim.x * SBLK) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = (float)a.rgb[3 * p + c] / 255.0f;
+            a.out[c * n + p] = (x - a.mean[c]) / a.std[c];
+        }
+    }
+}
+
+int pca_image_to_nchw_f32(pca_ctx *ctx, const uint8_t *rgb, int H, int W, const float mean[3], const float std[3], float *out,
+                          void *stream)
+{
+    if (!ctx) return -1;
+    if (!rgb || !out || !mean || !std || H < 1 || W < 1) { ctx->err = "normalise: bad arguments"; return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    NormArgs a;
+    a.rgb = rgb; a.out = out; a.H = H; a.W = W;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.std[c] = std[c]; }
+    const int64_t n = (int64_t)H * W;
+    const int grid = (int)((n + SBLK - 1) / SBLK < 4096 ? (n + SBLK - 1) / SBLK : 4096);
+    hipLaunchKernelGGL(image_to_nchw_f32, dim3(grid), dim3(SBLK), 0, s, a);
+    PCA_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
 int pca_mark_dynamic(pca_ctx *ctx, const pca_store *store, const int64_t *frame_off, const int32_t *slots,
                      const int32_t *inst_idx, int n_pairs, void *stream)
 {

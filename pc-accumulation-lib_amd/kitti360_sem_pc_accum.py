@@ -95,9 +95,12 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         frame = {'pts': up(pc, torch.float32)}
         semseg = None
         if sem_gt is None:
-            semseg = self.semseg_model.pred(rgb)[0, 0]
             img = rgb if isinstance(rgb, torch.Tensor) or hasattr(rgb, 'dev') else np.array(rgb)
             frame['rgb'] = up(img, torch.uint8)
+            # a model that works on the device gets the uploaded image: one H2D serves the CNN and K1, and its class map
+            # (utils.onnx_utils.DeviceMap) goes to K1 without ever visiting the host
+            feed = frame['rgb'] if getattr(self.semseg_model, 'accepts_device', False) else rgb
+            semseg = self.semseg_model.pred(feed)[0, 0]
             frame['sem'] = up(semseg, torch.uint8)
             H, W = frame['sem'].shape
         else:

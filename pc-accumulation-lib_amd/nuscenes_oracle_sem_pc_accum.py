@@ -102,6 +102,7 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
         T_ego_world, pose = self._ego_world(T_ego_global, ego_pose_z)
         dev = self.store.device
         semsegs = [self.semseg_model.pred(rgb)[0, 0] for rgb in rgbs]
+        dev_sems = [getattr(m, 'dev', m) for m in semsegs]          # utils.onnx_utils.DeviceMap: already in HBM
 
         def up(a, np_dtype, t_dtype):
             if isinstance(a, torch.Tensor):
@@ -112,8 +113,8 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
             imgs = up(rgbs, np.uint8, torch.uint8)
         else:
             imgs = up(np.stack([np.array(rgb) for rgb in rgbs]), np.uint8, torch.uint8)
-        if isinstance(semsegs[0], torch.Tensor):
-            sems = torch.stack([s.to(device=dev, dtype=torch.uint8) for s in semsegs]).contiguous()
+        if isinstance(dev_sems[0], torch.Tensor):
+            sems = torch.stack([s.to(device=dev, dtype=torch.uint8) for s in dev_sems]).contiguous()
         else:
             sems = up(np.stack(semsegs), np.uint8, torch.uint8)
         self.store.append_nusc(up(pc, np.float64, torch.float64), up(pc_cam_idx, np.int64, torch.int64), imgs, sems,

@@ -3,6 +3,7 @@
 A loader is its own iterator: `for batch in loader` yields lists of `batch_size` consecutive observations
 (`read_obs(i)`), a trailing partial batch is dropped, and iterating again restarts from observation 0.
 """
+import os
 from abc import ABC, abstractmethod
 
 
@@ -22,6 +23,11 @@ class ObservationDataloader(ABC):
 
     def __iter__(self):
         self.idx = 0
+        if os.environ.get('PCA_PREFETCH', '0') not in ('', '0') and hasattr(self, 'pc_paths'):
+            # ingest pipeline (pca_amd/ingest.py): a reader thread decodes ahead and uploads through pinned buffers; the
+            # batches it yields hold device tensors, which the accumulators take in place of numpy / PIL inputs
+            from pca_amd.ingest import PrefetchingLoader
+            return iter(PrefetchingLoader(self, depth=int(os.environ.get('PCA_PREFETCH_DEPTH', '4'))))
         return self
 
     def __next__(self):

@@ -6,10 +6,12 @@ resident in HBM (the accumulators accept cuda tensors in place of numpy / PIL in
     for observations in loader:
         acc.integrate(observations)
 
-A reader thread fills a ring of REUSED pinned host buffers and enqueues the copies on a side stream; the consumer's
-stream waits on the copy event, never on the host, and every handed-out device tensor is registered with the consumer's
-stream (`record_stream`), so the caching allocator cannot recycle its block for a later copy while kernels that read it
-are still queued."""
+A reader thread does the part that has nothing to do with the GPU -- file reads, PNG decode, label remapping -- one or
+more batches ahead.  Everything that talks to HIP stays on the consumer's thread (measured: HIP calls from a second
+Python thread, even a lone event wait, cost the first one milliseconds per step): when batch k is handed out, batch k+1
+is copied into a ring of reused pinned buffers and its H2D copies are enqueued on a side stream, so they travel while
+the GPU works on batch k; the consumer's stream waits on the copy event, never on the host."""
+import os
 import queue
 import threading
 
@@ -38,54 +40,68 @@ def compose_label_lut(idx2idx, lo=-1, hi=255):
 
 
 class PrefetchingLoader:
+    """Ring of slots, each with pinned host staging AND device buffers allocated once and reused (a fresh device / pinned
+    allocation costs milliseconds when the allocator cache has no free block).  A slot's device buffers are overwritten
+    by the copy of a later batch only after an event recorded on the consumer's stream when it came back for the next
+    batch: everything it did with the slot has been enqueued by then (a GPU-side wait, nobody blocks on the host)."""
+
+    RING = 4                                 # batches: being used, staged ahead, and two of slack
 
     def __init__(self, loader, depth=4, device=None):
         import torch
+        from . import _lib
+        _lib.Context.get(device)            # no GPU / no library: fail here, loudly (there is no CPU fallback)
         self.loader = loader
         self.depth = depth
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-        self.stream = torch.cuda.Stream(self.device)
+        # PCA_INGEST_SIDE_STREAM=1: copies on a stream of their own (overlap with kernels); default: the consumer's stream
+        self.stream = torch.cuda.Stream(self.device) if os.environ.get('PCA_INGEST_SIDE_STREAM') else None
         self.lut = None
         if hasattr(loader, 'idx2idx'):
             self.lut = compose_label_lut(loader.idx2idx)
+        bs = max(int(getattr(loader, 'batch_size', 1)), 1)
+        self._ring = [dict(pin={}, dev={}, copied=None, released=None) for _ in range(self.RING * bs)]
+        self._ring_next = 0
 
     def __len__(self):
         return len(self.loader)
 
-    def _staging(self, name, shape, dtype):
-        """Pinned buffer `name` of the current ring slot, grown on demand and reused from then on."""
+    def _buffers(self, slot, name, shape, dtype):
+        """(pinned, device) buffers `name` of a slot, grown on demand and reused from then on."""
         import torch
-        slot = self._slot
         n = int(np.prod(shape))
-        buf = slot.get(name)
-        if buf is None or buf.numel() < n or buf.dtype != dtype:
-            buf = slot[name] = torch.empty(max(n, 1), dtype=dtype).pin_memory()
-        return buf[:n].view(*shape)
+        pin, dev = slot['pin'].get(name), slot['dev'].get(name)
+        if pin is None or pin.numel() < n or pin.dtype != dtype:
+            pin = slot['pin'][name] = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+            dev = slot['dev'][name] = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+        return pin[:n].view(*shape), dev[:n].view(*shape)
 
     def _to_device(self, obs):
+        """Consumer thread: stage one observation (host arrays) and enqueue its H2D copies on the side stream."""
         import torch
         img, pc, sem_gt = obs
-        if not hasattr(self, '_ring'):
-            self._ring = [dict() for _ in range(self.depth + 2)]      # one more than can be in flight + being filled
-            self._ring_next = 0
-        self._slot = self._ring[self._ring_next % len(self._ring)]
+        slot = self._ring[self._ring_next % len(self._ring)]
         self._ring_next += 1
-        if 'event' in self._slot:
-            self._slot['event'].synchronize()                           # the copy that last read this slot is done
-        host_img = np.array(np.asarray(img), dtype=np.uint8)            # own copy: kept by the accumulator (rgbs)
-        src = [np.ascontiguousarray(pc, dtype=np.float32), host_img,
-               np.ascontiguousarray(np.asarray(sem_gt)[:, -1]).astype(np.uint8)]
-        pin = []
-        for name, a in zip(('pc', 'img', 'sem'), src):
-            buf = self._staging(name, a.shape, torch.from_numpy(a).dtype)
-            buf.copy_(torch.from_numpy(a))
-            pin.append(buf)
-        with torch.cuda.stream(self.stream):
-            dev = [t.to(self.device, non_blocking=True) for t in pin]
+        if slot['copied'] is not None:
+            slot['copied'].synchronize()                                # long done: RING batches ago
+        host_img = img if isinstance(img, np.ndarray) and img.dtype == np.uint8 else np.asarray(img, dtype=np.uint8)
+        src = [('pc', np.ascontiguousarray(pc, dtype=np.float32)), ('img', np.ascontiguousarray(host_img)),
+               ('sem', np.ascontiguousarray(np.asarray(sem_gt)[:, -1]).astype(np.uint8))]
+        dev = []
+        stream = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(stream):
+            if slot['released'] is not None and self.stream is not None:
+                stream.wait_event(slot['released'])                     # kernels that read the device buffers are done
+            for name, a in src:
+                t = torch.from_numpy(a)
+                pin, d = self._buffers(slot, name, a.shape, t.dtype)
+                pin.copy_(t)
+                d.copy_(pin, non_blocking=True)
+                dev.append(d)
             ev = torch.cuda.Event()
-            ev.record(self.stream)
-        self._slot['event'] = ev
-        return (DeviceImage(host_img, dev[1]), dev[0], dev[2]), ev, dev
+            ev.record(stream)
+        slot['copied'] = ev
+        return (DeviceImage(host_img, dev[1]), dev[0], dev[2]), ev, slot
 
     def _read(self, idx):
         """read_obs with the label remap done through the composed table (identical result, one pass)."""
@@ -114,28 +130,50 @@ class PrefetchingLoader:
         n, bs = len(self.loader), self.loader.batch_size
         torch.cuda.set_device(self.device)
 
-        def worker():
-            torch.cuda.set_device(self.device)
+        def reader():                            # host-only work: no HIP call on this thread
             try:
                 idx = 0
                 while idx + bs <= n:
-                    batch = [self._to_device(self._read(idx + k)) for k in range(bs)]
+                    batch = [self._read(idx + k) for k in range(bs)]
                     idx += bs
                     q.put(batch)
             except BaseException as e:           # surfaced in the consumer
                 q.put(e)
             q.put(None)
 
-        threading.Thread(target=worker, daemon=True).start()
+        use_thread = os.environ.get('PCA_INGEST_THREAD', '1') != '0'
+        if use_thread:
+            threading.Thread(target=reader, daemon=True).start()
+        inline = {'idx': 0}
+
+        def stage():
+            if use_thread:
+                item = q.get()
+            elif inline['idx'] + bs <= n:
+                item = [self._read(inline['idx'] + k) for k in range(bs)]
+                inline['idx'] += bs
+            else:
+                item = None
+            if item is None or isinstance(item, BaseException):
+                return item
+            return [self._to_device(obs) for obs in item]
+
+        ahead = stage()
+        held = []
         while True:
-            item = q.get()
+            item = ahead
             if item is None:
                 return
             if isinstance(item, BaseException):
                 raise item
             cur = torch.cuda.current_stream(self.device)
-            for _, ev, dev in item:
-                cur.wait_event(ev)
-                for t in dev:                    # allocated on the copy stream, used on the consumer's from here on
-                    t.record_stream(cur)
+            for slot in held:                    # the previous batch: all its uses are on the consumer's stream by now
+                rel = torch.cuda.Event()
+                rel.record(cur)
+                slot['released'] = rel
+            held = [slot for _, _, slot in item]
+            if self.stream is not None:
+                for _, ev, _ in item:
+                    cur.wait_event(ev)
+            ahead = stage()                      # the next batch's copies travel while this one is being integrated
             yield [obs for obs, _, _ in item]

@@ -4,7 +4,9 @@
 
 `python script.py` puts the script's own directory first on sys.path, so a driver started from inside the
 reference checkout would import the reference's numpy modules.  This launcher puts the drop-in root first and
-executes the script file as __main__ (the file itself is not modified or copied)."""
+executes the script file as __main__ (the file itself is not modified or copied).  It also switches the ingest pipeline on
+(PCA_PREFETCH=1: the KITTI loader decodes and uploads ahead on a reader thread); BEV samples leave the device
+asynchronously and are written by background threads either way (PCA_ASYNC_WRITE=0 / PCA_SYNC_BEV=1 switch that off)."""
 import os
 import runpy
 import sys
@@ -18,6 +20,7 @@ def main():
     sys.path[:] = [pkg_root] + [p for p in sys.path if os.path.abspath(p or '.') != pkg_root]
     for m in [m for m in sys.modules if m == 'datasets' or m.startswith('datasets.')]:
         del sys.modules[m]
+    os.environ.setdefault('PCA_PREFETCH', '1')      # decode + upload ahead of the GPU (pca_amd/ingest.py); 0 disables
     sys.argv = [script] + sys.argv[2:]
     runpy.run_path(script, run_name='__main__')
 

@@ -147,6 +147,14 @@ class SemanticPointCloudAccumulator:
 
     @staticmethod
     def write_compressed_pickle(obj, filename, write_dir):
+        """gzip(pickle(obj)) -> write_dir/filename.gz, the reference's container (sem_pc_accum.py:280-294).  A BEV sample
+        whose planes are still in flight (LazyBev) goes to the process-wide background writer (pca_amd.writer: device wait,
+        pickling and compression off the driver's thread; flushed at exit); PCA_ASYNC_WRITE=0 keeps it synchronous."""
+        from bev_generator.sem_bev import LazyBev
+        if isinstance(obj, LazyBev) and os.environ.get('PCA_ASYNC_WRITE', '1') != '0':
+            from pca_amd.writer import shared_writer
+            shared_writer().submit(obj, filename, write_dir)
+            return
         path = os.path.join(write_dir, f"{filename}.gz")
         blob = pickle.dumps(obj)
         try:
@@ -157,6 +165,8 @@ class SemanticPointCloudAccumulator:
 
     @staticmethod
     def read_compressed_pickle(path):
+        from pca_amd import writer
+        writer.flush_shared()                 # samples handed to the background writer are on disk before anything is read
         try:
             with gzip.open(path, "rb") as f:
                 return pickle.loads(f.read())
@@ -279,9 +289,20 @@ class SemanticPointCloudAccumulator:
         return pcs, trajs
 
     def _run_bev(self, pcs, trajs, bev_num):
-        # the reference forks a multiprocessing.Pool for bev_num > 1 (pickling the window per worker);
-        # the rasteriser is ~100 us, so the copies are simply generated one after the other
-        return [self.sem_bev_generator.generate_multiproc((pcs, self._copy_trajs(trajs))) for _ in range(bev_num)]
+        """bev_num samples of one window.  The reference forks a multiprocessing.Pool for bev_num > 1 (pickling the window
+        per worker, kitti360_sem_pc_accum.py:236-241); here the bev_num rasters (each with its own random augmentation,
+        drawn exactly as generate_rand_aug draws it) are enqueued back to back on the device into one [bev_num,21,px,px]
+        tensor and leave it in ONE asynchronous copy: the returned dicts (LazyBev) fill in on first access."""
+        import torch
+        from bev_generator.bev_generator import WindowPart
+        gen = self.sem_bev_generator
+        if not isinstance(pcs['pc_present'], WindowPart) or os.environ.get('PCA_SYNC_BEV'):
+            return [gen.generate_multiproc((pcs, self._copy_trajs(trajs))) for _ in range(bev_num)]
+        px = gen.pixel_size
+        planes = torch.empty((bev_num, 21, px, px), dtype=torch.float16, device=self.store.device)
+        results = [gen.generate_multiproc((pcs, self._copy_trajs(trajs)), device_only=True, out=planes[k])
+                   for k in range(bev_num)]
+        return gen.to_host_async(planes, results)
 
     @staticmethod
     def _copy_trajs(trajs):

@@ -257,6 +257,8 @@ def test_driver_shaped_run_on_fake_kitti_tree(tmp_path, monkeypatch):
                     acc.get_semseg(present_idx))
         n_bev += 1
         last = (bevs[0], int(present_idx))
+    from pca_amd import writer
+    writer.flush_shared()          # samples go to the background writer; a driver process gets this flush at exit
     assert n_bev >= 5 and len(os.listdir(str(tmp_path / 'bevs' / 'subdir000'))) == 2 * n_bev
 
     # oracle replay of the same sequence
@@ -712,3 +714,117 @@ def test_nuscenes_full_size_scene_matches_oracle_pipeline():
     assert (bev['road_full'] != np.float16(0.5)).mean() > 0.9                          # the view is covered
     others = tracker.split_trajectories(pi)
     assert len(bev['trajs_full']) == 1 + len(others[2])
+
+
+def test_semseg_wrapper_keeps_the_class_map_on_the_device(monkeypatch):
+    """utils/onnx_utils.SemSegONNX with a GPU execution provider (onnxruntime faked: tests/fake_ort.py): normalisation on
+    the device == the reference's ToTensor + Normalize arithmetic, IOBinding on device pointers, a DeviceMap out whose
+    cuda tensor feeds K1 without a host round trip; without a GPU provider it is the reference's numpy path."""
+    import sys
+
+    import torch
+
+    import fake_ort
+    from PIL import Image
+    monkeypatch.setitem(sys.modules, 'onnxruntime', fake_ort)
+    from utils import onnx_utils
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
+    # host path (CPU provider only): numpy (1,1,H,W), as the reference
+    monkeypatch.setitem(fake_ort.STATE, 'providers', ['CPUExecutionProvider'])
+    host_model = onnx_utils.SemSegONNX('model.onnx')
+    assert host_model.keep_on_device is False and not host_model.accepts_device
+    want = host_model.pred(Image.fromarray(img))
+    assert isinstance(want, np.ndarray) and want.shape == (1, 1, 64, 96) and want.dtype == np.int64
+    # the normalisation is the reference's: ToTensor (x / 255) then Normalize ((x - mean) / std), all f32
+    x = onnx_utils.SemSegONNX.input_preproc(img)
+    ref = ((img.astype(np.float32) / np.float32(255.)) - np.float32(onnx_utils.MEAN)) / np.float32(onnx_utils.STD)
+    assert np.array_equal(x, np.transpose(ref, (2, 0, 1))) and x.dtype == np.float32
+    xd = onnx_utils.SemSegONNX.input_preproc_device(torch.from_numpy(img).cuda())
+    assert np.array_equal(xd.cpu().numpy()[0], x)
+    # device path
+    monkeypatch.setitem(fake_ort.STATE, 'providers', ['ROCMExecutionProvider', 'CPUExecutionProvider'])
+    model = onnx_utils.SemSegONNX('model.onnx')
+    model.ort_session_semseg.owner = model
+    assert model.keep_on_device and model.accepts_device
+    before = fake_ort.STATE['bound_runs']
+    got = model.pred(torch.from_numpy(img).cuda())
+    assert fake_ort.STATE['bound_runs'] == before + 1
+    assert isinstance(got, onnx_utils.DeviceMap) and got.shape == (1, 1, 64, 96) and got.dev.is_cuda
+    assert np.array_equal(np.asarray(got), want) and np.array_equal(np.asarray(got[0, 0]), want[0, 0])
+    # through the accumulator: the map reaches K1 as the cuda tensor it already is
+    import sem_pc_accum
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    monkeypatch.setattr(sem_pc_accum, 'SemSegONNX', lambda path: model)
+    P = np.array([[40., 0, 48, 0], [0, 40., 32, 0], [0, 0, 1, 0]]) @ np.linalg.inv(np.array(
+        [[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418], [-0.999004371, 0.007784614041, 0.04392796942, 0.2993489574],
+         [-0.01162548558, -0.9960641394, -0.08786966659, -0.1770225824], [0, 0, 0, 1]]))
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': P}
+    acc = Kitti360SemanticPointCloudAccumulator(50., calib, 1e3, 'model.onnx', KITTI_FILTERS, SEM_IDXS, False, dict(BEV_KITTI))
+    acc.pose_provider = lambda pc: np.eye(4)
+    pc = np.stack([rng.uniform(-20, 20, 3000), rng.uniform(-20, 20, 3000), rng.uniform(-2, 2, 3000), rng.uniform(0, 1, 3000)],
+                  1).astype(np.float32)
+    acc.integrate([(Image.fromarray(img), pc, None)])
+    rows = acc.sem_pcs[0]
+    from oracle import oracle as orc
+    ost = orc.Store(3000)
+    orc.kitti_project_sample_filter(ost, pc, P, img, want[0, 0].astype(np.uint8), None, 64, 96, KITTI_FILTERS)
+    assert np.array_equal(rows, ost.rows()) and rows.shape[0] > 100
+    assert isinstance(acc.get_semseg(0)[0], onnx_utils.DeviceMap)
+
+
+def test_bev_num_batch_equals_single_calls_and_lazy_dicts(golden, monkeypatch, tmp_path):
+    """generate_bev(bev_num=4) with random augmentation (rotation / shift / zoom / warp): the four rasters run back to
+    back on the device and leave in one asynchronous copy (LazyBev); with the random draws pinned they equal four single
+    calls.  A LazyBev pickles as the plain dict; write_compressed_pickle hands it to the background writer."""
+    import gzip
+    import pickle
+    import random
+
+    from PIL import Image
+
+    from bev_generator.sem_bev import LazyBev
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    from pca_amd import writer
+    g = golden('kitti_gtsem')
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': g['P']}
+    bev_params = dict(BEV_KITTI, max_trans_radius=3., zoom_thresh=0.2, do_warp=True)
+
+    def build():
+        acc = Kitti360SemanticPointCloudAccumulator(50., calib, 1e3, None, KITTI_FILTERS, SEM_IDXS, True, dict(bev_params))
+        queue = list(g['Ts'])
+        acc.pose_provider = lambda pc: queue.pop(0)
+        dummy = Image.fromarray(np.zeros((64, 96, 3), np.uint8))
+        for k in range(4):
+            acc.integrate([(dummy, g[f'pc_{k}'], g[f'sem_gt_{k}'])])
+        return acc
+    monkeypatch.setattr(np.random, 'seed', lambda *a: None)          # generate_rand_aug reseeds from pid * time
+    acc = build()
+    np.random.RandomState  # noqa: B018
+    np.random.mtrand._rand.seed(11)
+    random.seed(5)
+    batch = acc.generate_bev(2, 4, gen_future=True)
+    assert len(batch) == 4 and all(isinstance(b, LazyBev) for b in batch)
+    np.random.mtrand._rand.seed(11)
+    random.seed(5)
+    monkeypatch.setenv('PCA_SYNC_BEV', '1')                          # the one-after-the-other form
+    singles = [acc.generate_bev(2, 1, gen_future=True)[0] for _ in range(4)]
+    monkeypatch.delenv('PCA_SYNC_BEV')
+    assert not any(isinstance(b, LazyBev) for b in singles)
+    for b, s in zip(batch, singles):
+        assert set(b.keys()) == set(s.keys())
+        for key in s:
+            if key.startswith('trajs'):
+                assert len(b[key]) == len(s[key]) and all(np.array_equal(x, y) for x, y in zip(b[key], s[key]))
+            else:
+                assert np.array_equal(np.asarray(b[key]).view(np.uint16), np.asarray(s[key]).view(np.uint16)), key
+    assert not np.array_equal(np.asarray(batch[0]['road_full']), np.asarray(batch[1]['road_full']))   # augmentations differ
+    # container: a LazyBev pickles as the reference's plain dict; the writer thread produces the same file
+    fresh = acc.generate_bev(2, 1, gen_future=True)[0]
+    assert isinstance(fresh, LazyBev)
+    acc.write_compressed_pickle(fresh, 'bev_000.pkl', str(tmp_path))
+    writer.shared_writer().flush()
+    with gzip.open(str(tmp_path / 'bev_000.pkl.gz'), 'rb') as f:
+        back = pickle.loads(f.read())
+    assert type(back) is dict and back['rgb_full'].dtype == np.float16 and back['rgb_full'].shape == (3, 32, 32)
+    assert np.array_equal(back['road_present'], fresh['road_present'])

@@ -19,7 +19,7 @@ def test_unchanged_kitti_driver_runs_up_to_the_device(tmp_path):
     root = str(tmp_path / 'KITTI-360')
     write_tree(root, first_idx=130, n_frames=3)          # the driver starts sequence 0000 at frame 130
     env = dict(os.environ, PYTHONPATH=PKG, PCA_KITTI_T_FILE=os.path.join(root, 'T_new_prev.npy'),
-               PYTHONDONTWRITEBYTECODE='1')
+               PYTHONDONTWRITEBYTECODE='1', PCA_PREFETCH='0')     # the plain loader: the first device call is integrate()
     r = subprocess.run([sys.executable, '-m', 'pca_amd.run', REF_DRIVER, root, 'none.onnx', '--use_gt_sem', '--bev_pixel_size', '32',
                         '--accum_horizon_dist', '20', '--bev_horizon_dist', '5'], cwd=str(tmp_path), env=env,
                        capture_output=True, text=True, timeout=300)
@@ -30,6 +30,11 @@ def test_unchanged_kitti_driver_runs_up_to_the_device(tmp_path):
         # no GPU here: the first integrate() must die loudly in the product, not fall back to anything
         assert 'no CPU fallback' in out, out[-2000:]
         assert PKG in out
+        # the launcher's default (ingest pipeline on) dies just as loudly, in the loader
+        env.pop('PCA_PREFETCH')
+        r = subprocess.run([sys.executable, '-m', 'pca_amd.run', REF_DRIVER, root, 'none.onnx', '--use_gt_sem'],
+                           cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+        assert 'no CPU fallback' in r.stdout + r.stderr and 'ingest.py' in r.stdout + r.stderr
 
 
 REF_NUSC_DRIVER = '/root/reference/run_nuscenes_bev_gen.py'

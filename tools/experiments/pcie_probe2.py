@@ -1,0 +1,32 @@
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'pc-accumulation-lib_amd'))
+import builtins
+import numpy as np, torch
+import bench
+from obs_dataloaders.obs_dataloader import ObservationDataloader
+from pca_amd.ingest import PrefetchingLoader
+acc, pool, model = bench.make_accumulator(bench.synth_frame, 0)
+real = builtins.print
+builtins.print = lambda *a, **k: None
+st = bench.Stepper(acc, pool); st.fill()
+host_pool = [(f[0].cpu().numpy(), f[1].cpu().numpy(), f[2].cpu().numpy()) for f in pool]
+class M(ObservationDataloader):
+    def __init__(self, n):
+        super().__init__(None, 1); self.n, self.pc_paths = n, None
+    def __len__(self): return self.n
+    def read_obs(self, idx):
+        r, p, _ = host_pool[idx % 8]; return (r, p, np.zeros((1, 1)))
+class S:
+    def pred(self, rgb): return pool[0][2][None, None]
+acc.semseg_model = S()
+ld = PrefetchingLoader(M(60), depth=4)
+it = iter(ld)
+tn = ti = tb = 0
+for k in range(60):
+    a = time.perf_counter(); obs = next(it); b = time.perf_counter()
+    acc.integrate([(obs[0][0], obs[0][1], None)]); c = time.perf_counter()
+    bev = acc.generate_bev(bench.present_index(acc), 1, gen_future=True)[0]; d = time.perf_counter()
+    tn += b - a; ti += c - b; tb += d - c
+torch.cuda.synchronize()
+real('next %.3f  integrate %.3f  generate_bev %.3f ms' % (1e3 * tn / 60, 1e3 * ti / 60, 1e3 * tb / 60))
