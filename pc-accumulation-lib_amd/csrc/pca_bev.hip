@@ -59,6 +59,7 @@ struct BevArgs {
     uint32_t *boff;       // [T][G] exclusive scan of bh in that order
     uint32_t *tile_off;   // [T+1]
     uint32_t *heavy_hint; // host-visible word: the heavy count of this call, read by the host before the next one
+    uint32_t heavy_hint_known;   // its value when this call was made
     uint32_t *heavy;      // [3+T]: heavy count, heavy cursor, (reserved), ids of the tiles left to bev_tile_cells_heavy
     void *recs;           // RecF / RecD [max_points], tile-ordered; c = r | g<<8 | b<<16 | FLAG_*
     double *planes;
@@ -393,7 +394,7 @@ __device__ __forceinline__ void load_rec_key_colour(const BevArgs &a, uint32_t r
 
 // closed-form maps of the tile (thread -> (set, cell)), staged in LDS, then written row by row
 __device__ __forceinline__ void tile_finalize_write(const BevArgs &a, const TileStats &S, double (*s_out)[TCELLS], int tile,
-                                                    int nthreads)
+                                                    int nthreads, int cell_lo = 0, int cell_hi = TCELLS)
 {
     const pca_bev_params &q = a.prm;
     const bool extra = a.extra != nullptr;
@@ -435,7 +436,7 @@ __device__ __forceinline__ void tile_finalize_write(const BevArgs &a, const Tile
     for (int idx = threadIdx.x; idx < n_planes * TCELLS; idx += nthreads) {
         const int plane = idx / TCELLS, lc = idx % TCELLS;
         const int row = row0 + lc / TS, col = col0 + lc % TS;
-        if (row >= q.px || col >= q.px) continue;
+        if (row >= q.px || col >= q.px || lc < cell_lo || lc >= cell_hi) continue;
         const double v = s_out[plane][lc];
         if (plane < 21) {
             const int64_t o = (int64_t)plane * ncell + (int64_t)row * q.px + col;
@@ -728,19 +729,25 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool extra = a.extra != nullptr;
     const uint32_t n_heavy = a.heavy[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *a.heavy_hint = n_heavy;
-    // the queued tiles are drawn one at a time: a 12 000-record tile takes several times longer than a 4 100-record one
+    // the count goes to host-visible memory only when it differs from what the host already knows (a write over PCIe
+    // holds the kernel's end back by microseconds; in steady state nothing changes)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_heavy != a.heavy_hint_known) *a.heavy_hint = n_heavy;
+    // Work items are (tile, half of its cells): the two halves of a tile are independent (every statistic is per cell),
+    // so a 12 000-record tile is two items of half the time each, drawn one at a time by whichever workgroup is free --
+    // the kernel ends with its slowest ITEM, and most CUs would otherwise idle behind the few densest tiles.
+    constexpr int HALVES = TCELLS / H_CELLS;
     for (;;) {
     if (threadIdx.x == 0) s_next = atomicAdd(&a.heavy[1], 1u);
     __syncthreads();
     const uint32_t item = s_next;
-    if (item >= n_heavy) break;
-    const int tile = (int)a.heavy[3 + item];
+    if (item >= n_heavy * HALVES) break;
+    const int tile = (int)a.heavy[3 + item / HALVES];
+    const int half = (int)(item % HALVES);
     if (item >= (uint32_t)gridDim.x) t_begin = wall_clock64();
     const uint32_t r_lo = a.tile_off[tile], r_hi = a.tile_off[tile + 1];
     stats_init(L.S, H_THREADS);
     if (threadIdx.x == 0) L.overflow = 0;
-    for (int half = 0; half < TCELLS / H_CELLS; ++half) {
+    {
         for (int k = threadIdx.x; k < H_HIST_DWORDS / 4; k += H_THREADS) reinterpret_cast<uint4 *>(hist)[k] = make_uint4(0, 0, 0, 0);
         __syncthreads();
         // every thread walks a contiguous chunk of the tile's records (runs form: see Run)
@@ -785,7 +792,7 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs 
         if ((a.dbg & 8) && threadIdx.x == 0 && tile < 1024) g_dbg_stamps[tile][4 + 2 * half] = wall_clock64();
     }
     // (cell,set)s too large for 16-bit counters: 32-bit histograms, whole workgroup, re-reading the tile
-    for (int cell = 0; L.overflow && cell < TCELLS; ++cell) {
+    for (int cell = half * H_CELLS; L.overflow && cell < (half + 1) * H_CELLS; ++cell) {
         const uint32_t n_p = L.S.cnt[2 * cell], n_f = L.S.cnt[2 * cell + 1];
         if (n_p <= 0xffffu && n_f <= 0xffffu) continue;
         for (int round = 0; round < 2; ++round) {           // round 0: present, then + future = full; round 1: future
@@ -807,8 +814,8 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs 
         }
     }
     __syncthreads();
-    tile_finalize_write(a, L.S, reinterpret_cast<double(*)[TCELLS]>(smem), tile, H_THREADS);
-    __syncthreads();                                        // the staging area is the next tile's histogram
+    tile_finalize_write(a, L.S, reinterpret_cast<double(*)[TCELLS]>(smem), tile, H_THREADS, half * H_CELLS, (half + 1) * H_CELLS);
+    __syncthreads();                                        // the staging area is the next item's histogram
     if ((a.dbg & 8) && threadIdx.x == 0 && tile < 1024) {
         g_dbg_stamps[tile][0] = t_begin; g_dbg_stamps[tile][1] = wall_clock64(); g_dbg_stamps[tile][2] = r_hi - r_lo;
         g_dbg_stamps[tile][7] = __smid();
@@ -928,6 +935,7 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
     int heavy_grid = a.T < ctx->n_cu ? a.T : ctx->n_cu;
     if (*ctx->heavy_hint == 0 && heavy_grid > 16) heavy_grid = 16;
     a.heavy_hint = ctx->heavy_hint_dev;
+    a.heavy_hint_known = *ctx->heavy_hint;
     if (ctx->profiling == 2) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
     PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_hist, dim3(a.G), dim3(AB_THREADS), lds, s, a);
     PCA_LAUNCH(ctx, PCA_K_BEV_SCAN, bev_tile_scan, dim3(a.scan_tiles), dim3(SCAN_THREADS), s, a);

@@ -151,8 +151,11 @@ __device__ __forceinline__ K1Frame k1_find_frame(const K1Frame *frames, int f_lo
 }
 static_assert(sizeof(K1Frame) == 48, "k1_find_frame reads a descriptor as three 16-byte words");
 
+#define K1_INLINE_FRAMES 64
+struct K1InlineFrames { K1Frame f[K1_INLINE_FRAMES]; };   // descriptors of a small batch travel in the kernel arguments
+
 template <int BLK, int PPT, bool SPLIT, bool BILIN>
-__global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a)
+__device__ __forceinline__ void k1_body(const K1Args &a, const K1Frame *inl)
 {
     constexpr int TILE = BLK * PPT, NW = BLK / PCA_WAVE, NC = PPT * NW;
     static_assert(NC <= 64, "the per-(row, wave) counts are scanned by one wave");
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a)
         const int q = blockIdx.x, f_lo = a.qframe0[q], f_hi = a.qframe0[q + 1];
         if (a.tpf) {
             if (f_lo + (int)blockIdx.z >= f_hi) return;                   // queues of unequal length
-            fr = a.frames ? a.frames[f_lo + blockIdx.z] : a.one;           // uniform index: a scalar load
+            fr = inl ? inl[f_lo + blockIdx.z] : a.frames ? a.frames[f_lo + blockIdx.z] : a.one;   // uniform index: scalar loads
             tin = blockIdx.y;
         } else {
             if ((int)blockIdx.y >= a.qtiles[q]) return;
@@ -392,6 +395,13 @@ __global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a)
     K1_STAMP(6);
 }
 
+template <int BLK, int PPT, bool SPLIT, bool BILIN>
+__global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a) { k1_body<BLK, PPT, SPLIT, BILIN>(a, nullptr); }
+
+// same, with the frame descriptors in the kernel arguments (no upload before the launch): equal-sized frames, <= 64 of them
+template <int BLK, int PPT, bool BILIN>
+__global__ __launch_bounds__(BLK) void k1_kitti_inl(const K1Args a, const K1InlineFrames inl) { k1_body<BLK, PPT, true, BILIN>(a, inl.f); }
+
 // SPLIT, second kernel: streams a tile's kept records into the SoA store (consecutive lanes write consecutive
 // records: every store instruction is fully coalesced).  The tile's store offset is the sum of the counts of the
 // tiles before it, which every workgroup adds up for itself (<= K1_MAX_SPLIT_TILES values from L2: no scan kernel,
@@ -491,6 +501,8 @@ struct K1Plan {
     K1AppendArgs pa;
     dim3 grid_front;     // FUSED: (tiles); SPLIT: see k1_kitti
     int tiles;
+    const K1Frame *host_frames;   // the plan's descriptors on the host
+    bool inline_frames;           // they fit the kernel arguments: no device copy needed
 };
 
 // Fills the launch arguments of one (sub-)batch and its frame descriptors hf[0..n_frames) (the caller uploads them to
@@ -539,6 +551,8 @@ static int k1_prepare(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames,
     a.sample_mode = sample_mode;
     a.frames = n_frames > 1 ? dev_frames : nullptr;
     a.one = hf[0];
+    plan->host_frames = hf;
+    plan->inline_frames = !fused && equal && n_frames > 1 && n_frames <= K1_INLINE_FRAMES && !getenv("PCA_K1_NO_INLINE");
     for (int i = 0; i < 12; ++i) a.P.m[i] = P[i];
     a.H = H; a.W = W;
     {   // f32 rows and the error bound of the conservative test: 2^-19 relative is 6x the worst case of three
@@ -598,8 +612,13 @@ static int k1_prepare(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames,
 static int k1_launch_split(pca_ctx *ctx, int blk, int ppt, const K1Plan *plan, hipStream_t s)
 {
     bool launched = false;
+    K1InlineFrames inl;
+    if (plan->inline_frames) memcpy(inl.f, plan->host_frames, sizeof(K1Frame) * plan->fa.n_frames);
 #define K1_CASE(B, Pp) if (blk == B && ppt == Pp) { \
-        if (plan->fa.sample_mode) hipLaunchKernelGGL((k1_kitti<B, Pp, true, true>), plan->grid_front, dim3(B), 0, s, plan->fa); \
+        if (plan->inline_frames) { \
+            if (plan->fa.sample_mode) hipLaunchKernelGGL((k1_kitti_inl<B, Pp, true>), plan->grid_front, dim3(B), 0, s, plan->fa, inl); \
+            else hipLaunchKernelGGL((k1_kitti_inl<B, Pp, false>), plan->grid_front, dim3(B), 0, s, plan->fa, inl); \
+        } else if (plan->fa.sample_mode) hipLaunchKernelGGL((k1_kitti<B, Pp, true, true>), plan->grid_front, dim3(B), 0, s, plan->fa); \
         else hipLaunchKernelGGL((k1_kitti<B, Pp, true, false>), plan->grid_front, dim3(B), 0, s, plan->fa); \
         launched = true; }
     K1_CASE(256, 4) K1_CASE(512, 4) K1_CASE(1024, 4)
@@ -655,9 +674,10 @@ int pca_kitti_project_sample_filter_ex(pca_ctx *ctx, const pca_kitti_frame *fram
     if (k1_grow(ctx, &ctx->k1_frames_dev, &ctx->k1_frames_cap, (int64_t)sizeof(K1Frame) * n_frames, s)) return -1;
     const K1Frame *df = reinterpret_cast<const K1Frame *>(ctx->k1_frames_dev);
     bool prof_open = false;
+    bool need_upload = true;
     auto upload = [&]() -> int {
         if (ctx->profiling == 1) { pca_prof_begin(ctx, PCA_K_KITTI, s); prof_open = true; }   // one event pair around the unit's GPU work
-        if (n_frames > 1) {
+        if (n_frames > 1 && need_upload) {
             PCA_CHECK(ctx, hipMemcpyAsync(ctx->k1_frames_dev, hf, sizeof(K1Frame) * n_frames, hipMemcpyHostToDevice, s));
             PCA_CHECK(ctx, hipEventRecord(ctx->k1_pin_ev[slot], s));
             ctx->k1_pin_busy[slot] = true;
@@ -693,6 +713,8 @@ int pca_kitti_project_sample_filter_ex(pca_ctx *ctx, const pca_kitti_frame *fram
                             0, hf + k0, df + k0, &plans.back(), sample_mode, s);
             k0 = k1;
         }
+        need_upload = false;
+        for (const K1Plan &pl : plans) need_upload = need_upload || !pl.inline_frames;
         if (rc == 0) rc = upload();
         for (size_t i = 0; i < plans.size() && rc == 0; ++i) rc = k1_launch_split(ctx, blk, ppt, &plans[i], s);
     }
