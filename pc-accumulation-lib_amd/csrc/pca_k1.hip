@@ -300,7 +300,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const K1Frame *inl)
 #pragma unroll
         for (int r = 0; r < PPT; ++r) {
             ok[r] = false; cls[r] = 0; rgb[r] = 0;
-            if ((uint32_t)(r * BLK) < ncand) {
+            if ((uint32_t)(r * BLK + wave * PCA_WAVE) < ncand) {       // wave-uniform: a wave without candidates in this round skips it
                 const uint32_t j = (uint32_t)(r * BLK) + threadIdx.x;
                 double qu = 0.0, qv = 0.0;
                 const int px = BILIN ? k1_project_pixel(a.P, p[r].x, p[r].y, p[r].z, a.W, a.H, &qu, &qv)
