@@ -11,13 +11,16 @@
 //   icp_grid_count / icp_cell_scan / icp_grid_fill   two uniform grids around the sensor (0.5 m and 0.25 m cells):
 //                     counting sort of the target points by cell -- a cell's points are contiguous, a row of cells is
 //                     one range, and a neighbour search streams them (four loads in flight)
-//   icp_normals       per target point: the K = 30 nearest neighbours (shell-by-shell grid search, exact within the
-//                     search cap), covariance, eigenvector of the smallest eigenvalue (cyclic Jacobi, f64)
-//   icp_accumulate    per source point: q = T p, nearest target point (exact within the cap; the previous iteration's
-//                     partner bounds the search from the start), r = (q - t).n,
-//                     J = [q x n, n]; per-workgroup partial sums of J^T J, J^T r, |q - t|^2, inlier count
-//   icp_solve         one workgroup: fixed-order reduction of the partials (deterministic), 6x6 Cholesky solve,
-//                     T <- exp(x) T, fitness / rmse, convergence flag -- the iteration loop never leaves the device
+//   icp_normals       per target point (8 lanes each): the K = 30 nearest neighbours (shell-by-shell grid search, exact
+//                     within the search cap), covariance, eigenvector of the smallest eigenvalue (cyclic Jacobi, f64)
+//   icp_match         per source point (8 lanes each): q = T p, nearest target point (exact within the cap; the previous
+//                     iteration's partner bounds the search from the start)
+//   icp_accumulate    per source point: r = (q - t).n, J = [q x n, n]; per-workgroup partial sums of J^T J, J^T r,
+//                     |q - t|^2, inlier count.  The last workgroup to finish adds the partials up in workgroup order
+//                     (deterministic) and takes the step: 6x6 Cholesky solve, T <- exp(x) T, fitness / rmse, convergence
+//                     flag -- two launches per iteration, and the host looks at the flag only every sixth pass.
+// Measured on two 120 k-point sweeps (round 2): 10.9 ms -> 2.8 ms per registration (normals 1.63 -> 0.67 ms, a pass
+// 0.91 -> 0.17 ms); what changed is in the comments of icp_visit_shell, icp_match and icp_solve_step.
 #include "pca_common.h"
 
 // Two uniform grids of 512 x 512 x 64 cells around the sensor: level 0 = 0.5 m cells (256 m x 256 m x 32 m), level 1 =
@@ -37,6 +40,8 @@ template <int LV> struct IcpLevel {
 #define ICP_MATCH_RINGS 8        // search cap of a correspondence: 4 m (the reference passes 1e3 m = everything)
 #define ICP_THREADS 256
 #define ICP_NACC 30              // 21 (J^T J upper) + 6 (J^T r) + sum d^2 + inliers + sum r^2
+#define ICP_CHECK_EVERY 6         // the host looks at the convergence flag after every 6th pass
+#define ICP_MAX_GRID 512          // workgroups of icp_accumulate = rows of partial sums its last workgroup adds up
 
 struct IcpGrid {
     uint32_t *cnt;               // [cells] points per cell (counting pass), all zero again after the fill pass
@@ -51,6 +56,7 @@ struct IcpArgs {
     IcpGrid g[2];                // [0] coarse, [1] fine
     float *normal;               // [n_tgt,4]  nx, ny, nz, valid -- by ORIGINAL index
     int32_t *nn_prev;            // [n_src] original index of the previous iteration's correspondence, -1 = none
+    double *nn_d2;               // [n_src] its squared distance (icp_match -> icp_accumulate)
     uint64_t *lb_state;          // decoupled look-back of the cell scan
     uint32_t *ticket;
     uint32_t epoch;
@@ -58,6 +64,7 @@ struct IcpArgs {
     double *partial;             // [grid][ICP_NACC]
     double *state;               // [0..15] T (row-major), [16] fitness, [17] rmse, [18] prev fitness, [19] prev rmse,
                                  // [20] converged flag, [21] iterations done
+    uint32_t *arrived;           // workgroups of the running icp_accumulate that have written their partial sums
     double max_dist2;
     double rel_fitness, rel_rmse;
     int grid;
@@ -140,6 +147,18 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_grid_fill(const IcpArgs a)
 
 // the records [s0, e) of a range of cells, four loads in flight (a one-record-per-trip loop is a chain of memory latencies:
 // measured 1 ms per 120 k queries, independent of how much the search is culled)
+// SGN > 1: SGN neighbouring lanes share one query; lane `sub` takes every SGN-th record, two loads in flight
+template <int SGN, typename F>
+__device__ __forceinline__ void icp_scan_range_sg(const float4 *spts, uint32_t s0, uint32_t e, int sub, F &&f)
+{
+    for (uint32_t q = s0 + (uint32_t)sub; q < e; q += 2 * SGN) {
+        const uint32_t q1 = q + SGN;
+        const float4 w0 = spts[q], w1 = spts[q1 < e ? q1 : q];
+        f(w0);
+        if (q1 < e) f(w1);
+    }
+}
+
 template <typename F>
 __device__ __forceinline__ void icp_scan_range(const float4 *spts, uint32_t s0, uint32_t e, F &&f)
 {
@@ -154,45 +173,85 @@ __device__ __forceinline__ void icp_scan_range(const float4 *spts, uint32_t s0, 
     }
 }
 
-// visits every target point (its sorted record) of the shell of Chebyshev radius r around cell (cx,cy,cz) of grid LV,
-// skipping the cells whose box lies farther from the query (qx,qy,qz) than bound() -- the caller's current search
-// radius squared (after the own cell has produced a candidate a few centimetres away, almost every neighbour is culled)
-template <int LV, typename B, typename F>
+// Visits every target point (its sorted record) of the shell of Chebyshev radius r around cell (cx,cy,cz) of grid LV,
+// skipping the cells whose box lies farther from the query (qx,qy,qz) than bound() -- the caller's current search radius
+// squared (after the own cell has produced a candidate a few centimetres away, almost every neighbour is culled).
+// A shell is walked as
+//   (1) its four faces made of whole rows of cells (|dz| = r, or |dy| = r): a row is ONE range of sorted points;
+//   (2) its two faces at |dx| = r: (2r-1)^2 single cells each, four lookups in flight.
+// SGN = 1: one lane does it all.  SGN = 8: eight neighbouring lanes share the query (sub = the lane's number in its
+// group).  The LOOKUPS are dealt out piece by piece -- a far-field query that finds nothing walks ~2000 cells over its
+// shells -- and every range a lane finds non-empty is then SCANNED BY ALL EIGHT, record by record -- next to the sensor a
+// row of three cells holds hundreds of returns, and one lane scanning it alone was the slowest query of the launch
+// (measured per query with s_memrealtime: 0-5 m 36 us mean / 218 us max, beyond 20 m 13 us).  All loops have group-uniform
+// trip counts; the eight lanes must be converged at every call.
+template <int LV, int SGN, typename B, typename F>
 __device__ __forceinline__ void icp_visit_shell(const IcpGrid &g, int cx, int cy, int cz, int r, double qx, double qy,
-                                                double qz, B &&bound, F &&f)
+                                                double qz, int sub, B &&bound, F &&f)
 {
     using G = IcpLevel<LV>;
-    for (int dz = -r; dz <= r; ++dz) {
-        const int z = cz + dz;
-        if (z < 0 || z >= ICP_NZ) continue;
-        const double z0 = G::oz + z * G::cell;
-        const double ez = qz < z0 ? z0 - qz : (qz > z0 + G::cell ? qz - (z0 + G::cell) : 0.0);
-        for (int dy = -r; dy <= r; ++dy) {
-            const int y = cy + dy;
-            if (y < 0 || y >= ICP_NY) continue;
-            const double y0 = G::oy + y * G::cell;
-            const double ey = qy < y0 ? y0 - qy : (qy > y0 + G::cell ? qy - (y0 + G::cell) : 0.0);
-            const double eyz = ey * ey + ez * ez;
-            if (eyz >= bound()) continue;
-            const bool face = (dz == -r || dz == r || dy == -r || dy == r);
-            if (face) {
-                // a whole row of the shell: its cells are neighbours in memory, one range of sorted points
-                const int x_lo = cx - r < 0 ? 0 : cx - r, x_hi = cx + r >= ICP_NX ? ICP_NX - 1 : cx + r;
-                if (x_lo > x_hi) continue;
-                const int c0 = icp_cell_index(x_lo, y, z);
-                icp_scan_range(g.spts, g.start[c0], g.start[c0 + (x_hi - x_lo) + 1], f);
-            } else {                                        // interior rows: only the two end cells
-                for (int dx = -r; dx <= r; dx += 2 * r) {
-                    const int x = cx + dx;
-                    if (x < 0 || x >= ICP_NX) continue;
-                    const double x0 = G::ox + x * G::cell;
-                    const double ex = qx < x0 ? x0 - qx : (qx > x0 + G::cell ? qx - (x0 + G::cell) : 0.0);
-                    if (ex * ex + eyz >= bound()) continue;
-                    const int c0 = icp_cell_index(x, y, z);
-                    icp_scan_range(g.spts, g.start[c0], g.start[c0 + 1], f);
+    auto gap = [](double q, double lo) { return q < lo ? lo - q : (q > lo + G::cell ? q - (lo + G::cell) : 0.0); };
+    // the ranges the lanes of the group hold in (s0, e0), each scanned by the whole group
+    auto scan_found = [&](uint32_t s0, uint32_t e0) {
+        if (SGN == 1) {
+            if (e0 > s0) icp_scan_range(g.spts, s0, e0, f);
+            return;
+        }
+        const int base = (int)(threadIdx.x & 63) & ~(SGN - 1);
+        uint32_t bits = (uint32_t)(__ballot(e0 > s0) >> base) & ((1u << SGN) - 1u);
+        while (bits) {
+            const int l = __ffs(bits) - 1;
+            bits &= bits - 1;
+            const uint32_t s = (uint32_t)__shfl((int)s0, base + l, 64), e = (uint32_t)__shfl((int)e0, base + l, 64);
+            icp_scan_range_sg<SGN>(g.spts, s, e, sub, f);
+        }
+    };
+    if (r == 0) {
+        const int c0 = icp_cell_index(cx, cy, cz);
+        if (SGN == 1) icp_scan_range(g.spts, g.start[c0], g.start[c0 + 1], f);
+        else icp_scan_range_sg<SGN>(g.spts, g.start[c0], g.start[c0 + 1], sub, f);
+        return;
+    }
+    const int n = 2 * r + 1, m = 2 * r - 1;
+    const int x_lo = cx - r < 0 ? 0 : cx - r, x_hi = cx + r >= ICP_NX ? ICP_NX - 1 : cx + r;
+    for (int i0 = 0; i0 < 2 * n + 2 * m; i0 += SGN) {
+        const int i = i0 + sub;
+        uint32_t s0 = 0u, e0 = 0u;
+        if (i < 2 * n + 2 * m) {
+            int dz, dy;
+            if (i < 2 * n) { dz = i < n ? -r : r; dy = (i < n ? i : i - n) - r; }
+            else { const int j = i - 2 * n; dy = j < m ? -r : r; dz = (j < m ? j : j - m) - (r - 1); }
+            const int z = cz + dz, y = cy + dy;
+            if (z >= 0 && z < ICP_NZ && y >= 0 && y < ICP_NY) {
+                const double ez = gap(qz, G::oz + z * G::cell), ey = gap(qy, G::oy + y * G::cell);
+                if (ey * ey + ez * ez < bound()) {
+                    const int c0 = icp_cell_index(x_lo, y, z);
+                    s0 = g.start[c0];
+                    e0 = g.start[c0 + (x_hi - x_lo) + 1];
                 }
             }
         }
+        scan_found(s0, e0);
+    }
+    const int ncell = 2 * m * m;
+    for (int k0 = 0; k0 < ncell; k0 += 4 * SGN) {
+        uint32_t s0[4], e0[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s0[u] = e0[u] = 0u;
+            const int k = k0 + u * SGN + sub;
+            if (k >= ncell) continue;
+            const int mm = k >> 1, iz = mm / m;
+            const int z = cz + iz - (r - 1), y = cy + (mm - iz * m) - (r - 1), x = cx + ((k & 1) ? r : -r);
+            if (z < 0 || z >= ICP_NZ || y < 0 || y >= ICP_NY || x < 0 || x >= ICP_NX) continue;
+            const double ez = gap(qz, G::oz + z * G::cell), ey = gap(qy, G::oy + y * G::cell), ex = gap(qx, G::ox + x * G::cell);
+            if (ex * ex + ey * ey + ez * ez >= bound()) continue;
+            const int c0 = icp_cell_index(x, y, z);
+            s0[u] = g.start[c0];
+            e0[u] = g.start[c0 + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) scan_found(s0[u], e0[u]);
     }
 }
 
@@ -251,50 +310,102 @@ __device__ __forceinline__ void icp_smallest_eigvec(double A[3][3], double n[3])
     n[0] = V[0][m]; n[1] = V[1][m]; n[2] = V[2][m];
 }
 
+// Eight neighbouring lanes share one query (icp_normals, icp_match); sub = threadIdx.x & 7.
+#define ICP_SG 8
+__device__ __forceinline__ float icp_group_min(float v)
+{
+    v = fminf(v, __uint_as_float(lane_xor_fetch<1>(__float_as_uint(v))));
+    v = fminf(v, __uint_as_float(lane_xor_fetch<2>(__float_as_uint(v))));
+    return fminf(v, __uint_as_float(lane_xor_fetch<4>(__float_as_uint(v))));
+}
+__device__ __forceinline__ uint32_t icp_group_sum(uint32_t v)
+{
+    v += lane_xor_fetch<1>(v);
+    v += lane_xor_fetch<2>(v);
+    return v + lane_xor_fetch<4>(v);
+}
+__device__ __forceinline__ double icp_group_sum(double v)
+{
+#define ICP_SUM_STAGE(S)                                                                                               \
+    v += __hiloint2double((int)lane_xor_fetch<S>((uint32_t)__double2hiint(v)), (int)lane_xor_fetch<S>((uint32_t)__double2loint(v)));
+    ICP_SUM_STAGE(1) ICP_SUM_STAGE(2) ICP_SUM_STAGE(4)
+#undef ICP_SUM_STAGE
+    return v;
+}
+
+// icp_normals: per target point the K = 30 nearest neighbours, the covariance of everything within the K-th distance,
+// the eigenvector of its smallest eigenvalue.  Eight lanes per point: every lane keeps the K smallest distances of the
+// records IT scanned (sorted, in LDS); at the end of a shell the group merges the eight lists far enough to know the
+// K-th smallest distance of their union exactly (K steps of "smallest head"), which is the cull bound of the next shell
+// and decides whether the search has settled.  The covariance pass deals the records out the same way and adds the
+// eight partial sums up in a fixed butterfly.
 __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
 {
-    __shared__ float s_d[ICP_K][ICP_THREADS];               // per thread: the K smallest squared distances, ascending
-    const int p = blockIdx.x * ICP_THREADS + threadIdx.x;   // original index
+    __shared__ float s_d[ICP_K][ICP_THREADS];               // per lane: the K smallest squared distances it saw, ascending
+    const int p = (blockIdx.x * ICP_THREADS + threadIdx.x) / ICP_SG;   // original index
     if (p >= a.n_tgt) return;
+    const int sub = threadIdx.x & (ICP_SG - 1);
+    const int base = (int)(threadIdx.x & 63) & ~(ICP_SG - 1);
     const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
     float4 out = make_float4(0.f, 0.f, 1.f, 0.f);
     const int t = threadIdx.x;
-    int found = 0;
-    auto bound_k = [&]() { return found == ICP_K ? (double)s_d[ICP_K - 1][t] * (1.0 + 1e-6) + 1e-12 : 1e300; };
-    auto offer = [&](float d2) {                            // insertion into the sorted list of the K smallest
-        if (found == ICP_K && d2 >= s_d[ICP_K - 1][t]) return;
+    int found = 0;                                          // entries of this lane's list
+    float kth = __builtin_huge_valf();                      // K-th smallest distance of the group so far (inf: fewer than K)
+    auto bound_k = [&]() { return kth < __builtin_huge_valf() ? (double)kth * (1.0 + 1e-6) + 1e-12 : 1e300; };
+    auto offer = [&](float d2) {                            // insertion into the sorted list of the lane's K smallest
+        if (d2 > kth || (found == ICP_K && d2 >= s_d[ICP_K - 1][t])) return;
         int i = found < ICP_K ? found : ICP_K - 1;
         while (i > 0 && s_d[i - 1][t] > d2) { s_d[i][t] = s_d[i - 1][t]; --i; }
         s_d[i][t] = d2;
         if (found < ICP_K) ++found;
     };
+    auto merge_kth = [&]() {                                // exact K-th smallest of the union of the eight lists
+        if (icp_group_sum((uint32_t)found) < ICP_K) return;
+        int head = 0;
+        float g = 0.f;
+        for (int step = 0; step < ICP_K; ++step) {
+            const float mine = head < found ? s_d[head][t] : __builtin_huge_valf();
+            g = icp_group_min(mine);
+            const uint32_t eq = (uint32_t)(__ballot(mine == g) >> base) & 0xffu;      // one of the equal heads advances
+            if (sub == __ffs(eq) - 1) ++head;
+        }
+        kth = g;
+    };
     auto dist2 = [&](const float4 w) { const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z; return dx * dx + dy * dy + dz * dz; };
-    // pass A: the K-th smallest distance.  Fine grid first; every unvisited point is farther than r cells, so the list
-    // is final once its last entry lies inside that radius.
+    // pass A: the K-th smallest distance.  Fine grid first; every unvisited point is farther than r cells, so the K-th
+    // distance is final once it lies inside that radius.
     int fx, fy, fz, cx, cy, cz;
     const bool fine = icp_fine_box(v.x, v.y, v.z, fx, fy, fz);
     bool settled = false;
     if (fine)
         for (int r = 0; r <= ICP_FINE_RINGS && !settled; ++r) {
-            icp_visit_shell<1>(a.g[1], fx, fy, fz, r, v.x, v.y, v.z, bound_k, [&](const float4 w) { offer(dist2(w)); });
+            icp_visit_shell<1, ICP_SG>(a.g[1], fx, fy, fz, r, v.x, v.y, v.z, sub, bound_k, [&](const float4 w) { offer(dist2(w)); });
+            merge_kth();
             const float lim = (float)(r * IcpLevel<1>::cell);
-            settled = found == ICP_K && s_d[ICP_K - 1][t] <= lim * lim;
+            settled = kth <= lim * lim;
         }
     const bool coarse = icp_cell_of<0>(v.x, v.y, v.z, cx, cy, cz);
     if (!settled && coarse)
         for (int r = 0; r <= ICP_NORMAL_RINGS && !settled; ++r) {
-            icp_visit_shell<0>(a.g[0], cx, cy, cz, r, v.x, v.y, v.z, bound_k, [&](const float4 w) {
+            icp_visit_shell<0, ICP_SG>(a.g[0], cx, cy, cz, r, v.x, v.y, v.z, sub, bound_k, [&](const float4 w) {
                 if (fine && icp_in_fine_box(w, fx, fy, fz)) return;             // already offered by the fine pass
                 offer(dist2(w));
             });
+            merge_kth();
             const float lim = (float)(r * IcpLevel<0>::cell);
-            settled = found == ICP_K && s_d[ICP_K - 1][t] <= lim * lim;
+            settled = kth <= lim * lim;
         }
-    if (found >= 3) {
+    const uint32_t total = icp_group_sum((uint32_t)found);
+    if (total >= 3) {
+        // the search radius of pass B: the K-th distance, or -- fewer than K points inside the search cap -- the largest
+        float lim = kth;
+        if (!(lim < __builtin_huge_valf())) {
+            const float mine = found > 0 ? -s_d[found - 1][t] : __builtin_huge_valf();
+            lim = -icp_group_min(mine);
+        }
         // pass B: covariance of every point within that distance (relative to the query: well conditioned)
-        const float lim = s_d[found - 1][t];
         double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-        int cnt = 0;
+        uint32_t cnt = 0;
         auto bound_l = [&]() { return (double)lim * (1.0 + 1e-6) + 1e-12; };
         auto add = [&](const float4 w) {
             const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z;
@@ -307,12 +418,16 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
         const float fine_reach = (float)(ICP_FINE_RINGS * IcpLevel<1>::cell);
         if (fine && lim <= fine_reach * fine_reach) {                           // the whole ball lies in the fine box
             const int rmax = (int)ceil(sqrt((double)lim) / IcpLevel<1>::cell);
-            for (int r = 0; r <= rmax && r <= ICP_FINE_RINGS; ++r) icp_visit_shell<1>(a.g[1], fx, fy, fz, r, v.x, v.y, v.z, bound_l, add);
+            for (int r = 0; r <= rmax && r <= ICP_FINE_RINGS; ++r) icp_visit_shell<1, ICP_SG>(a.g[1], fx, fy, fz, r, v.x, v.y, v.z, sub, bound_l, add);
         } else if (coarse) {
             const int rmax = (int)ceil(sqrt((double)lim) / IcpLevel<0>::cell);
-            for (int r = 0; r <= rmax && r <= ICP_NORMAL_RINGS; ++r) icp_visit_shell<0>(a.g[0], cx, cy, cz, r, v.x, v.y, v.z, bound_l, add);
+            for (int r = 0; r <= rmax && r <= ICP_NORMAL_RINGS; ++r) icp_visit_shell<0, ICP_SG>(a.g[0], cx, cy, cz, r, v.x, v.y, v.z, sub, bound_l, add);
         }
-        if (cnt >= 3) {
+        cnt = icp_group_sum(cnt);
+        sx = icp_group_sum(sx); sy = icp_group_sum(sy); sz = icp_group_sum(sz);
+        sxx = icp_group_sum(sxx); sxy = icp_group_sum(sxy); sxz = icp_group_sum(sxz);
+        syy = icp_group_sum(syy); syz = icp_group_sum(syz); szz = icp_group_sum(szz);
+        if (cnt >= 3 && sub == 0) {
             const double inv = 1.0 / cnt;
             const double mx = sx * inv, my = sy * inv, mz = sz * inv;
             double A[3][3];
@@ -325,56 +440,173 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
             if (len > 0) out = make_float4((float)(n[0] / len), (float)(n[1] / len), (float)(n[2] / len), 1.f);
         }
     }
-    reinterpret_cast<float4 *>(a.normal)[p] = out;
+    if (sub == 0) reinterpret_cast<float4 *>(a.normal)[p] = out;
 }
 
+// Gauss-Newton step of one evaluation: fitness / rmse of the current transform, convergence test, 6x6 Cholesky solve,
+// T <- exp(x) T.  One thread.
+__device__ void icp_solve_step(const IcpArgs &a, const double *sum)
+{
+    double *S = a.state;
+    const double inl = sum[28];
+    const double fitness = a.n_src > 0 ? inl / a.n_src : 0.0;
+    const double rmse = inl > 0 ? sqrt(sum[27] / inl) : 0.0;
+    // Open3D evaluates fitness / rmse of the CURRENT transform, then updates; convergence compares successive evaluations
+    const bool first = S[21] == 0.0;
+    S[16] = fitness; S[17] = rmse;
+    if (!first && fabs(S[18] - fitness) < a.rel_fitness && fabs(S[19] - rmse) < a.rel_rmse) { S[20] = 1.0; return; }
+    S[18] = fitness; S[19] = rmse;
+    if (inl < 6) { S[20] = 1.0; return; }
+    // solve (J^T J) x = -J^T r  (Cholesky, upper triangle stored row-wise in sum[0..20]).  Every loop has a constant trip
+    // count and no early exit, so the 6x6 system lives in registers (indexed dynamically it sat in scratch memory: ~100
+    // dependent scratch round trips, most of the kernel's 55 us)
+    double A[6][6], b[6], x[6];
+    {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) { A[i][j] = A[j][i] = sum[k++]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = -sum[21 + i];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i][j];
+#pragma unroll
+            for (int m = 0; m < j; ++m) s -= A[i][m] * A[j][m];
+            if (i == j) { ok = ok && (s > 1e-12); A[i][i] = sqrt(ok ? s : 1.0); }
+            else A[i][j] = s / A[j][j];
+        }
+    }
+    if (!ok) { S[20] = 1.0; return; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int m = 0; m < i; ++m) s -= A[i][m] * x[m];
+        x[i] = s / A[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = x[i];
+#pragma unroll
+        for (int m = i + 1; m < 6; ++m) s -= A[m][i] * x[m];
+        x[i] = s / A[i][i];
+    }
+    // x = (alpha, beta, gamma, tx, ty, tz): R = Rz(gamma) Ry(beta) Rx(alpha)
+    const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+    const double U[12] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa, x[3],
+                          sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa, x[4],
+                          -sb, cb * sa, cb * ca, x[5]};
+    double N[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            N[4 * i + j] = U[4 * i] * S[j] + U[4 * i + 1] * S[4 + j] + U[4 * i + 2] * S[8 + j] + (j == 3 ? U[4 * i + 3] : 0.0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) S[i] = N[i];
+    S[21] += 1.0;
+}
+
+// icp_match: ICP_SG neighbouring lanes share one source point.  The own cell's records and the rows of every further
+// shell are dealt out over the lanes, each lane keeps its own best partner, and at the end of every shell the lanes agree
+// on the group's best (DPP butterfly inside the 8 lanes), which tightens everybody's cull bound and decides whether the
+// search has settled.  One lane per query was a chain of dependent loads and row walks as long as the worst query of its
+// wave (~0.8 ms per pass at < 2 waves per SIMD).  Ties: lowest ORIGINAL index (the order inside a cell varies from run
+// to run).
+__device__ __forceinline__ void icp_group_best(double &best, int &bidx)
+{
+#define ICP_BEST_STAGE(S)                                                                                              \
+    {                                                                                                                  \
+        const uint32_t lo = lane_xor_fetch<S>((uint32_t)__double2loint(best)), hi = lane_xor_fetch<S>((uint32_t)__double2hiint(best)); \
+        const int oi = (int)lane_xor_fetch<S>((uint32_t)bidx);                                                         \
+        const double od = __hiloint2double((int)hi, (int)lo);                                                          \
+        if (oi >= 0 && (bidx < 0 || od < best || (od == best && oi < bidx))) { best = od; bidx = oi; }                 \
+    }
+    ICP_BEST_STAGE(1) ICP_BEST_STAGE(2) ICP_BEST_STAGE(4)
+#undef ICP_BEST_STAGE
+}
+
+__global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
+{
+    if (a.state[20] != 0.0) return;                         // converged: the remaining passes are no-ops
+    const double *T = a.state;
+    const int sub = threadIdx.x & (ICP_SG - 1);
+    const int p = (blockIdx.x * ICP_THREADS + threadIdx.x) / ICP_SG;
+    if (p >= a.n_src) return;
+    const float4 v = reinterpret_cast<const float4 *>(a.src)[p];
+    const double qx = T[0] * v.x + T[1] * v.y + T[2] * v.z + T[3];
+    const double qy = T[4] * v.x + T[5] * v.y + T[6] * v.z + T[7];
+    const double qz = T[8] * v.x + T[9] * v.y + T[10] * v.z + T[11];
+    double best = a.max_dist2;
+    int bidx = -1;
+    auto bound = [&]() { return best * (1.0 + 1e-12) + 1e-300; };
+    auto offer = [&](const float4 w) {
+        const double dx = w.x - qx, dy = w.y - qy, dz = w.z - qz;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        const int wi = __float_as_int(w.w);
+        if (d2 < best || (d2 == best && bidx >= 0 && wi < bidx)) { best = d2; bidx = wi; }
+    };
+    // warm start: the previous iteration's partner bounds the search from the first cell on (the transform moved by a
+    // fraction of a cell), so nearly every cell is culled; the result is still the exact nearest neighbour
+    // (first pass: the target point of the same index -- consecutive sweeps share their scan order -- provided the search
+    // below would reach it: inside the coarse grid and within the match cap; any such point is a valid upper bound)
+    int prev = a.nn_prev[p];
+    const bool first = prev == (int)0xfefefefe;
+    if (first) prev = p < a.n_tgt ? p : -1;
+    if (prev >= 0) {
+        const float4 t = reinterpret_cast<const float4 *>(a.tgt)[prev];
+        const double dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
+        constexpr double cap = ICP_MATCH_RINGS * IcpLevel<0>::cell;
+        int tx, ty, tz;
+        if (!first || (dx * dx + dy * dy + dz * dz <= cap * cap && icp_cell_of<0>(t.x, t.y, t.z, tx, ty, tz)))
+            offer(make_float4(t.x, t.y, t.z, __int_as_float(prev)));
+    }
+    int fx, fy, fz, cx, cy, cz;
+    bool settled = false;
+    if (icp_fine_box(qx, qy, qz, fx, fy, fz))
+        for (int r = 0; r <= ICP_FINE_RINGS && !settled; ++r) {
+            icp_visit_shell<1, ICP_SG>(a.g[1], fx, fy, fz, r, qx, qy, qz, sub, bound, offer);
+            icp_group_best(best, bidx);
+            settled = bidx >= 0 && best <= (r * IcpLevel<1>::cell) * (r * IcpLevel<1>::cell);
+        }
+    if (!settled && icp_cell_of<0>(qx, qy, qz, cx, cy, cz))
+        for (int r = 0; r <= ICP_MATCH_RINGS && !settled; ++r) {
+            icp_visit_shell<0, ICP_SG>(a.g[0], cx, cy, cz, r, qx, qy, qz, sub, bound, offer);   // re-offering a point is harmless
+            icp_group_best(best, bidx);
+            settled = bidx >= 0 && best <= (r * IcpLevel<0>::cell) * (r * IcpLevel<0>::cell);
+        }
+    if (sub == 0) { a.nn_prev[p] = bidx; a.nn_d2[p] = best; }
+}
+
+// icp_accumulate: one thread per source point turns its correspondence into a point-to-plane row; fixed-order reduction:
+// lanes (butterfly), waves (serial), workgroups (serial, by the last one to arrive) -> deterministic; that last workgroup
+// also takes the Gauss-Newton step, so an iteration is two launches and the loop never leaves the device.
 __global__ __launch_bounds__(ICP_THREADS) void icp_accumulate(const IcpArgs a)
 {
     __shared__ double s_red[ICP_THREADS / 64][ICP_NACC];
+    __shared__ double s_sum[ICP_NACC];
+    __shared__ int s_last;
+    if (a.state[20] != 0.0) return;
     double acc[ICP_NACC];
 #pragma unroll
     for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
-    const bool done = a.state[20] != 0.0;
     const double *T = a.state;
-    for (int p = blockIdx.x * ICP_THREADS + threadIdx.x; p < a.n_src && !done; p += a.grid * ICP_THREADS) {
+    for (int p = blockIdx.x * ICP_THREADS + threadIdx.x; p < a.n_src; p += a.grid * ICP_THREADS) {
+        const int bidx = a.nn_prev[p];
+        if (bidx < 0) continue;
         const float4 v = reinterpret_cast<const float4 *>(a.src)[p];
+        const float4 w = reinterpret_cast<const float4 *>(a.tgt)[bidx];
+        const float4 nn = reinterpret_cast<const float4 *>(a.normal)[bidx];
         const double qx = T[0] * v.x + T[1] * v.y + T[2] * v.z + T[3];
         const double qy = T[4] * v.x + T[5] * v.y + T[6] * v.z + T[7];
         const double qz = T[8] * v.x + T[9] * v.y + T[10] * v.z + T[11];
-        double best = a.max_dist2;
-        float4 bw = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool have = false;
-        auto bound = [&]() { return best * (1.0 + 1e-12) + 1e-300; };
-        auto offer = [&](const float4 w) {
-            const double dx = w.x - qx, dy = w.y - qy, dz = w.z - qz;
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            // ties: lowest ORIGINAL index (the order inside a cell varies from run to run)
-            if (d2 < best || (d2 == best && have && __float_as_int(w.w) < __float_as_int(bw.w))) { best = d2; bw = w; have = true; }
-        };
-        // warm start: the previous iteration's partner bounds the search from the first cell on (the transform moved
-        // by a fraction of a cell), so nearly every cell is culled; the result is still the exact nearest neighbour
-        const int prev = a.nn_prev[p];
-        if (prev >= 0) {
-            const float4 t = reinterpret_cast<const float4 *>(a.tgt)[prev];
-            offer(make_float4(t.x, t.y, t.z, __int_as_float(prev)));
-        }
-        int fx, fy, fz, cx, cy, cz;
-        bool settled = false;
-        if (icp_fine_box(qx, qy, qz, fx, fy, fz))
-            for (int r = 0; r <= ICP_FINE_RINGS && !settled; ++r) {
-                icp_visit_shell<1>(a.g[1], fx, fy, fz, r, qx, qy, qz, bound, offer);
-                settled = have && best <= (r * IcpLevel<1>::cell) * (r * IcpLevel<1>::cell);
-            }
-        if (!settled && icp_cell_of<0>(qx, qy, qz, cx, cy, cz))
-            for (int r = 0; r <= ICP_MATCH_RINGS && !settled; ++r) {
-                icp_visit_shell<0>(a.g[0], cx, cy, cz, r, qx, qy, qz, bound, offer);      // re-offering a point is harmless
-                settled = have && best <= (r * IcpLevel<0>::cell) * (r * IcpLevel<0>::cell);
-            }
-        a.nn_prev[p] = have ? __float_as_int(bw.w) : -1;
-        if (!have) continue;
-        const float4 w = bw;
-        const float4 nn = reinterpret_cast<const float4 *>(a.normal)[__float_as_int(w.w)];
-        acc[27] += best;                                    // Open3D: fitness / rmse over all correspondences
+        acc[27] += a.nn_d2[p];                              // Open3D: fitness / rmse over all correspondences
         acc[28] += 1.0;
         if (nn.w == 0.f) continue;                          // no normal: the pair carries no point-to-plane row
         const double nx = nn.x, ny = nn.y, nz = nn.z;
@@ -389,84 +621,61 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_accumulate(const IcpArgs a)
         for (int i = 0; i < 6; ++i) acc[21 + i] += J[i] * r;
         acc[29] += r * r;
     }
-    // fixed-order reduction: lanes (butterfly), waves (serial), workgroups (icp_solve, serial) -> deterministic
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto block_sum = [&](double *out, bool to_global) {     // acc[] of the workgroup -> out[0..NACC)
 #pragma unroll
-    for (int k = 0; k < ICP_NACC; ++k) {
-        double v = acc[k];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) s_red[wave][k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < ICP_NACC) {
-        double v = 0.0;
-        for (int w = 0; w < ICP_THREADS / 64; ++w) v += s_red[w][threadIdx.x];
-        a.partial[(size_t)blockIdx.x * ICP_NACC + threadIdx.x] = v;
-    }
-}
-
-__global__ __launch_bounds__(64) void icp_solve(const IcpArgs a)
-{
-    __shared__ double s_sum[ICP_NACC];
-    if (a.state[20] != 0.0) return;
-    if (threadIdx.x < ICP_NACC) {
-        double v = 0.0;
-        for (int b = 0; b < a.grid; ++b) v += a.partial[(size_t)b * ICP_NACC + threadIdx.x];
-        s_sum[threadIdx.x] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    double *S = a.state;
-    const double inl = s_sum[28];
-    const double fitness = a.n_src > 0 ? inl / a.n_src : 0.0;
-    const double rmse = inl > 0 ? sqrt(s_sum[27] / inl) : 0.0;
-    // Open3D evaluates fitness / rmse of the CURRENT transform, then updates; convergence compares successive evaluations
-    const bool first = S[21] == 0.0;
-    S[16] = fitness; S[17] = rmse;
-    if (!first && fabs(S[18] - fitness) < a.rel_fitness && fabs(S[19] - rmse) < a.rel_rmse) { S[20] = 1.0; return; }
-    S[18] = fitness; S[19] = rmse;
-    if (inl < 6) { S[20] = 1.0; return; }
-    // solve (J^T J) x = -J^T r  (Cholesky, upper triangle stored row-wise in s_sum[0..20])
-    double A[6][6], b[6], x[6];
-    int k = 0;
-    for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j) { A[i][j] = A[j][i] = s_sum[k++]; }
-    for (int i = 0; i < 6; ++i) b[i] = -s_sum[21 + i];
-    bool ok = true;
-    for (int i = 0; i < 6 && ok; ++i) {
-        for (int j = 0; j <= i; ++j) {
-            double s = A[i][j];
-            for (int m = 0; m < j; ++m) s -= A[i][m] * A[j][m];
-            if (i == j) { if (!(s > 1e-12)) { ok = false; break; } A[i][i] = sqrt(s); }
-            else A[i][j] = s / A[j][j];
+        for (int k = 0; k < ICP_NACC; ++k) {
+            double v = acc[k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) s_red[wave][k] = v;
         }
+        __syncthreads();
+        if (threadIdx.x < ICP_NACC) {
+            double v = 0.0;
+            for (int w = 0; w < ICP_THREADS / 64; ++w) v += s_red[w][threadIdx.x];
+            out[threadIdx.x] = v;
+            if (to_global) __threadfence();                 // release at agent scope by the (one) wave that wrote the row
+        }
+    };
+    // the row of partial sums is released by the wave that wrote it; the arrival counter follows after the barrier
+    block_sum(a.partial + (size_t)blockIdx.x * ICP_NACC, true);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(a.arrived, 1u);
+        s_last = (t == gridDim.x - 1);
+        if (s_last) __hip_atomic_store(a.arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!ok) { S[20] = 1.0; return; }
-    for (int i = 0; i < 6; ++i) { double s = b[i]; for (int m = 0; m < i; ++m) s -= A[i][m] * x[m]; x[i] = s / A[i][i]; }
-    for (int i = 5; i >= 0; --i) { double s = x[i]; for (int m = i + 1; m < 6; ++m) s -= A[m][i] * x[m]; x[i] = s / A[i][i]; }
-    // x = (alpha, beta, gamma, tx, ty, tz): R = Rz(gamma) Ry(beta) Rx(alpha)
-    const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
-    const double U[12] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa, x[3],
-                          sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa, x[4],
-                          -sb, cb * sa, cb * ca, x[5]};
-    double N[12];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 4; ++j)
-            N[4 * i + j] = U[4 * i] * S[j] + U[4 * i + 1] * S[4 + j] + U[4 * i + 2] * S[8 + j] + (j == 3 ? U[4 * i + 3] : 0.0);
-    for (int i = 0; i < 12; ++i) S[i] = N[i];
-    S[21] += 1.0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                        // acquire: the rows the other XCDs released
+    // thread t adds up the rows t, t + 256, ... (ascending), then the same lanes -> waves reduction: a fixed order
+#pragma unroll
+    for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += ICP_THREADS) {
+        const double2 *row = reinterpret_cast<const double2 *>(a.partial + (size_t)b * ICP_NACC);
+        double2 rv[ICP_NACC / 2];
+#pragma unroll
+        for (int k = 0; k < ICP_NACC / 2; ++k) rv[k] = row[k];
+#pragma unroll
+        for (int k = 0; k < ICP_NACC / 2; ++k) { acc[2 * k] += rv[k].x; acc[2 * k + 1] += rv[k].y; }
+    }
+    __syncthreads();
+    block_sum(s_sum, false);
+    __syncthreads();
+    if (threadIdx.x == 0) icp_solve_step(a, s_sum);
 }
 
 extern "C" {
 
 static inline int64_t icp_align(int64_t v) { return (v + 255) & ~255ll; }
-static inline int icp_grid(int n) { const int g = (n + ICP_THREADS - 1) / ICP_THREADS; return g < 1 ? 1 : (g > 1024 ? 1024 : g); }
+static inline int icp_grid(int n) { const int g = (n + ICP_THREADS - 1) / ICP_THREADS; return g < 1 ? 1 : (g > ICP_MAX_GRID ? ICP_MAX_GRID : g); }
 
 int64_t pca_icp_workspace_bytes(int32_t max_points)
 {
     if (max_points < 1) max_points = 1;
     return 2 * (icp_align(ICP_CELLS * 4) + icp_align((ICP_CELLS + 1) * 4) + icp_align((int64_t)max_points * 16)) +
-           icp_align((int64_t)max_points * 16) + icp_align((int64_t)max_points * 4) + icp_align((int64_t)1024 * ICP_NACC * 8) +
+           icp_align((int64_t)max_points * 16) + icp_align((int64_t)max_points * 4) + icp_align((int64_t)max_points * 8) +
+           icp_align((int64_t)ICP_MAX_GRID * ICP_NACC * 8) +
            icp_align(32 * 8) + 512;
 }
 
@@ -492,8 +701,10 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
     }
     a.normal = reinterpret_cast<float *>(w); w += icp_align((int64_t)n_tgt * 16);
     a.nn_prev = reinterpret_cast<int32_t *>(w); w += icp_align((int64_t)n_src * 4);
-    a.partial = reinterpret_cast<double *>(w); w += icp_align((int64_t)1024 * ICP_NACC * 8);
+    a.nn_d2 = reinterpret_cast<double *>(w); w += icp_align((int64_t)n_src * 8);
+    a.partial = reinterpret_cast<double *>(w); w += icp_align((int64_t)ICP_MAX_GRID * ICP_NACC * 8);
     a.state = reinterpret_cast<double *>(w);
+    a.arrived = reinterpret_cast<uint32_t *>(a.state + 24);            // zero with the state block
     a.max_dist2 = max_corr_dist * max_corr_dist;
     a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse;
     a.grid = icp_grid(n_src);
@@ -502,7 +713,7 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
     for (int i = 0; i < 16; ++i) st[i] = init ? init[i] : eye[i];
     PCA_CHECK(ctx, hipMemsetAsync(a.g[0].cnt, 0, (size_t)cells * 4, s));
     PCA_CHECK(ctx, hipMemsetAsync(a.g[1].cnt, 0, (size_t)cells * 4, s));
-    PCA_CHECK(ctx, hipMemsetAsync(a.nn_prev, 0xff, (size_t)n_src * 4, s));
+    PCA_CHECK(ctx, hipMemsetAsync(a.nn_prev, 0xfe, (size_t)n_src * 4, s));        // 0xfefefefe: "first pass" (see icp_match)
     PCA_CHECK(ctx, hipMemcpyAsync(a.state, st, sizeof st, hipMemcpyHostToDevice, s));
     const int scan_tiles = (int)(cells / ICP_SCAN_TILE);
     if (pca_ctx_reserve_tiles(ctx, scan_tiles, s)) return -1;
@@ -518,12 +729,19 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
     }
     PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_fill<0>, per_point, dim3(ICP_THREADS), s, a);
     PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_fill<1>, per_point, dim3(ICP_THREADS), s, a);
-    PCA_LAUNCH(ctx, PCA_K_ICP, icp_normals, dim3((n_tgt + ICP_THREADS - 1) / ICP_THREADS), dim3(ICP_THREADS), s, a);
-    // one more evaluation than updates: Open3D reports fitness / rmse of the final transform
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_normals, dim3(((int64_t)n_tgt * ICP_SG + ICP_THREADS - 1) / ICP_THREADS), dim3(ICP_THREADS), s, a);
+    // one more evaluation than updates: Open3D reports fitness / rmse of the final transform.  The loop never leaves the
+    // device inside a group of ICP_CHECK_EVERY passes; between groups the host reads the convergence flag (a pass after
+    // convergence is a no-op, the check only saves launching the rest of the 31)
     for (int it = 0; it <= max_iter; ++it) {
-        PCA_LAUNCH(ctx, PCA_K_ICP, icp_accumulate, dim3(a.grid), dim3(ICP_THREADS), s, a);
         if (it == max_iter) a.rel_fitness = a.rel_rmse = 1e300;              // last pass only evaluates
-        PCA_LAUNCH(ctx, PCA_K_ICP, icp_solve, dim3(1), dim3(64), s, a);
+        PCA_LAUNCH(ctx, PCA_K_ICP, icp_match, dim3(((int64_t)n_src * ICP_SG + ICP_THREADS - 1) / ICP_THREADS), dim3(ICP_THREADS), s, a);
+        PCA_LAUNCH(ctx, PCA_K_ICP, icp_accumulate, dim3(a.grid), dim3(ICP_THREADS), s, a);
+        if (it % ICP_CHECK_EVERY == ICP_CHECK_EVERY - 1 && it < max_iter) {
+            PCA_CHECK(ctx, hipMemcpyAsync(st, a.state, sizeof st, hipMemcpyDeviceToHost, s));
+            PCA_CHECK(ctx, hipStreamSynchronize(s));
+            if (st[20] != 0.0) break;
+        }
     }
     PCA_CHECK(ctx, hipMemcpyAsync(st, a.state, sizeof st, hipMemcpyDeviceToHost, s));
     PCA_CHECK(ctx, hipStreamSynchronize(s));

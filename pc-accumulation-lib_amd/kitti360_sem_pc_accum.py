@@ -95,7 +95,8 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         frame = {'pts': up(pc, torch.float32)}
         semseg = None
         if sem_gt is None:
-            img = rgb if isinstance(rgb, torch.Tensor) or hasattr(rgb, 'dev') else np.array(rgb)
+            # (np.asarray: a PIL image is converted as the reference's np.array(rgb) does, an ndarray is not copied again)
+            img = rgb if isinstance(rgb, torch.Tensor) or hasattr(rgb, 'dev') else np.asarray(rgb)
             frame['rgb'] = up(img, torch.uint8)
             # a model that works on the device gets the uploaded image: one H2D serves the CNN and K1, and its class map
             # (utils.onnx_utils.DeviceMap) goes to K1 without ever visiting the host

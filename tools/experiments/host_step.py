@@ -5,7 +5,8 @@ import pstats
 import sys
 import time
 
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench  # noqa: E402
 import torch  # noqa: E402
 
