@@ -239,10 +239,31 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_scatter(const BevArgs a)
 {
     extern __shared__ uint32_t s_cur[];                     // [T]
     const Window w = chunk_of(a);
-    // queue of the tiles whose records exceed the LDS colour buffer of bev_tile_cells: they are bev_tile_cells_heavy's
-    if (blockIdx.x == 0)
-        for (int t = threadIdx.x; t < a.T; t += AB_THREADS)
-            if (a.tile_off[t + 1] - a.tile_off[t] > (uint32_t)a.heavy_min) a.heavy[3 + atomicAdd(&a.heavy[0], 1u)] = (uint32_t)t;
+    // Queue of the tiles whose records exceed the LDS colour buffer of bev_tile_cells: they are bev_tile_cells_heavy's.
+    // Larger first (32 size classes of 1024 records, a counting sort in LDS): its workgroups draw items one at a time
+    // and the kernel ends with the last item to finish -- a 12 000-record tile drawn last runs alone while the other
+    // CUs idle.
+    if (blockIdx.x == 0) {
+        __shared__ uint32_t s_cls[32], s_base[32];
+        if (threadIdx.x < 32) s_cls[threadIdx.x] = 0;
+        __syncthreads();
+        auto cls_of = [](uint32_t sz) { const uint32_t c = sz >> 10; return 31u - (c > 31u ? 31u : c); };   // class 0 = largest
+        for (int t = threadIdx.x; t < a.T; t += AB_THREADS) {
+            const uint32_t sz = a.tile_off[t + 1] - a.tile_off[t];
+            if (sz > (uint32_t)a.heavy_min) atomicAdd(&s_cls[cls_of(sz)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int c = 0; c < 32; ++c) { s_base[c] = run; run += s_cls[c]; }
+            a.heavy[0] = run;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < a.T; t += AB_THREADS) {
+            const uint32_t sz = a.tile_off[t + 1] - a.tile_off[t];
+            if (sz > (uint32_t)a.heavy_min) a.heavy[3 + atomicAdd(&s_base[cls_of(sz)], 1u)] = (uint32_t)t;
+        }
+    }
     for (int t = threadIdx.x; t < a.T; t += AB_THREADS) s_cur[t] = a.boff[(int64_t)t * a.G + blockIdx.x];
     __syncthreads();
     const pca_bev_params &q = a.prm;

@@ -1,11 +1,12 @@
 """Per-workgroup begin/end stamps of bev_tile_cells_heavy on the ring model (PCA_BEV_DBG=8)."""
 import sys, os, ctypes as C
 os.environ['PCA_BEV_DBG'] = os.environ.get('PCA_BEV_DBG', '8')
-sys.path.insert(0, '.'); sys.path.insert(0, 'pc-accumulation-lib_amd')
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'pc-accumulation-lib_amd'))
 import numpy as np, builtins, bench
 rp = builtins.print
 builtins.print = lambda *a, **k: None
-r = bench.ring_model_pass(5, bench.synth_frame if os.environ.get('SCENE') == 'uniform' else None)
+r = bench.ring_model_pass(5)
 builtins.print = rp
 from pca_amd import _lib
 lib = _lib.Context.get().lib
