@@ -1,15 +1,16 @@
 // pca_bev.hip -- BEV rasteriser for gfx950: two-level counting sort with LDS-staged atomics, no global atomics.
 //
 //   level 1 (tiles of 8x8 cells, T tiles)
-//     bev_tile_hist     every workgroup bins a contiguous chunk of the window: rotate / translate / crop /
-//                       height / floor -> key = tile<<7 | cell_in_tile<<1 | set; per-workgroup LDS histogram
-//                       over tiles -> bh[workgroup][tile]           (reads 25 B/pt, writes 4 B/pt)
-//     bev_tile_scan     exclusive scan of bh in (tile, workgroup) order (decoupled look-back)
-//     bev_tile_scatter  16-byte records {z, intensity | set, rgb | flags | cell} -> one tile-ordered stream; the
-//                       position comes from an LDS cursor per tile (returning LDS atomics); workgroup 0 also queues
-//                       the tiles that are too dense for the light tile kernel
+//     bev_tile_bin      every workgroup bins a contiguous chunk of the window (rotate / translate / crop / height /
+//                       floor -> key = tile<<7 | cell_in_tile<<1 | set; applies and writes back an owed re-transform),
+//                       scans its own LDS histogram over the tiles and leaves the chunk's kept records -- 16 bytes:
+//                       {z, intensity | set, rgb | flags | cell} -- SORTED BY TILE in its own segment of the record
+//                       buffer, with the per-tile counts / offsets bh, boff [tile][workgroup].  No global scan, no
+//                       second pass over the window: ~10 000 points per chunk stay in registers between the passes.
 //   level 2 (one workgroup per tile)
-//     bev_tile_cells    tiles of at most heavy_min (<= RGB_CAP) records.  pass 1: per (cell,set) counts / exact
+//     bev_tile_cells    gathers its tile from the G segments (RecMap: an LDS prefix table over the workgroups' counts,
+//                       binary search per record); tiles above heavy_min (<= RGB_CAP) records are pushed to the heavy
+//                       queue, larger size classes first.  pass 1: per (cell,set) counts / exact
 //                       integer intensity sums / min z (per-thread runs of equal keys, then LDS atomics); pass 2: LDS
 //                       counting sort of the colours by (cell,set); exact medians per cell (n <= 64: bit-sliced radix
 //                       select on bit planes obtained by a cross-lane transpose, one lane per target; else a per-wave
@@ -57,20 +58,20 @@ struct BevArgs {
     uint32_t *key;        // [max_points]
     uint32_t *bh;         // [T][G] kept records per (tile, workgroup)
     uint32_t *boff;       // [T][G] exclusive scan of bh in that order
-    uint32_t *tile_off;   // [T+1]
     uint32_t *heavy_hint; // host-visible word: the heavy count of this call, read by the host before the next one
     uint32_t heavy_hint_known;   // its value when this call was made
-    uint32_t *heavy;      // [3+T]: heavy count, heavy cursor, (reserved), ids of the tiles left to bev_tile_cells_heavy
+    uint32_t *heavy;      // [64 + 32 T]: [0..32) tiles per size class (class 0 = largest), [32] item cursor, then the
+                          // classes' tile ids [class][T] -- the queue of bev_tile_cells_heavy, filled by bev_tile_cells
     void *recs;           // RecF / RecD [max_points], tile-ordered; c = r | g<<8 | b<<16 | FLAG_*
     double *planes;
     uint16_t *planes_f16;
     double *extra;        // [3 sets][PCA_BEV_EXTRA_PLANES][px][px] or NULL
-    uint64_t *state;
-    uint32_t *ticket;
-    uint32_t epoch;
-    int scan_tiles;
+    uint32_t *status;     // context status word (PCA_STATUS_* bits)
     int dbg;
 };
+#define HQ_CLASSES 32
+#define HQ_CURSOR 32
+#define HQ_IDS 64
 
 struct Window { int64_t lo, hi, sp, c_lo, c_hi; };
 
@@ -88,22 +89,135 @@ __device__ __forceinline__ Window chunk_of(const BevArgs &a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// level 1a: keys + per-workgroup tile histogram
+// level 1: bev_tile_bin -- every workgroup bins its contiguous chunk of the window into the T tiles and leaves the
+// chunk's kept records SORTED BY TILE in its own segment of the record buffer (recs[g * chunk ...]), together with the
+// per-tile counts and segment-local offsets bh / boff [tile][workgroup].  Level 2 gathers a tile from the G segments.
+//   pass A  subtract origin, 3x3 chain, crop, height, floor -> key = tile<<7 | cell<<1 | set; LDS histogram over the
+//           tiles; applies and writes back the owed re-transform (K2 fused)
+//   scan    exclusive scan of the histogram in LDS -> the chunk's tile offsets (no global scan, no second kernel: a
+//           global scan over T x G counters plus a scatter into tile-major order cost 6 + 31 us -- the scatter's ~5-record
+//           runs were partial-line writes all over a 33 MB buffer; here a workgroup's records fill one dense 64 KB window)
+//   pass B  re-reads the keys and z it has just written (L2), gathers intensity and colour of the kept points, packs
+//           the 16-byte record, LDS cursor per tile
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(AB_THREADS) void bev_tile_hist(const BevArgs a)
+// One point of pass A: owed re-transform (returns the stored coordinates), BEV-frame key.  KEY_INVALID = not in the view.
+struct BinPoint { double x, y, z; uint32_t key; };
+__device__ __forceinline__ BinPoint bin_point(const BevArgs &a, const Window &w, int64_t pend_hi, int64_t p, double X, double Y, double Z,
+                                              uint8_t D)
 {
-    extern __shared__ uint32_t s_h[];                       // [T]
-    const Window w = chunk_of(a);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.frame_off[a.slot_end] - w.lo > a.max_points)
-        atomicOr(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
-    for (int t = threadIdx.x; t < a.T; t += AB_THREADS) s_h[t] = 0;
-    __syncthreads();
     const pca_bev_params &q = a.prm;
+    BinPoint r;
+    if (p < pend_hi) {
+        const double nx = row4(a.pend_T.m + 0, X, Y, Z), ny = row4(a.pend_T.m + 4, X, Y, Z), nz = row4(a.pend_T.m + 8, X, Y, Z);
+        X = nx; Y = ny; Z = nz;
+        a.st.x[p] = nx; a.st.y[p] = ny; a.st.z[p] = nz;
+    }
+    r.x = X; r.y = Y; r.z = Z;
     const double v = q.view, vlo = -0.5 * v, vhi = 0.5 * v, pxd = (double)q.px, half_px = 0.5 * pxd;
     const bool use_h = !(q.height_filter != q.height_filter);
-    const int64_t pend_hi = a.pend_slot_end > a.slot_begin ? a.frame_off[a.pend_slot_end] : w.lo;
+    const double x = X - q.origin[0];
+    const double y = Y - q.origin[1];
+    const double z = Z - q.origin[2];
+    double ax = q.R[0] * x; ax = fma(q.R[1], y, ax); ax = fma(q.R[2], z, ax);
+    double ay = q.R[3] * x; ay = fma(q.R[4], y, ay); ay = fma(q.R[5], z, ay);
+    double az = q.R[6] * x; az = fma(q.R[7], y, az); az = fma(q.R[8], z, az);
+    ax += q.dx;
+    ay += q.dy;
+    bool keep = (ax > vlo) && (ax < vhi) && (ay > vlo) && (ay < vhi);
+    if (use_h) keep = keep && (az < q.height_filter);
+    keep = keep && (D != 1);
+    r.key = KEY_INVALID;
+    if (keep) {
+        int i = (int)floor(ax / v * pxd + half_px);
+        int j = (int)floor(ay / v * pxd + half_px);
+        i = i > q.px - 1 ? q.px - 1 : (i < 0 ? 0 : i);
+        j = j > q.px - 1 ? q.px - 1 : (j < 0 ? 0 : j);
+        const int row = q.px - 1 - j, col = i;
+        const uint32_t tile = (uint32_t)((row / TS) * a.tx + (col / TS));
+        const uint32_t fk = (uint32_t)(((row % TS) * TS + (col % TS)) * 2) + (p >= w.sp ? 1u : 0u);
+        r.key = (tile << 7) | fk;
+    }
+    return r;
+}
+// packs and stores one kept record (pass B)
+template <bool I64>
+__device__ __forceinline__ void bin_store(const BevArgs &a, uint32_t pos, uint32_t key, uint32_t rgbs, double z_store, double iv)
+{
+    const pca_bev_params &q = a.prm;
+    const unsigned sem = rgbs >> 24;
+    uint32_t c = rgbs & 0xffffffu;
+    if ((int)sem == q.road_class) c |= FLAG_ROAD;
+    if ((q.dynobj_mask[sem >> 6] >> (sem & 63)) & 1ull) c |= FLAG_DYNOBJ;
+    const double z = z_store - q.origin[2];                 // rotation about z: row 3 of R is (0,0,1)
+    if (I64) {
+        RecD r; r.z = z; r.inten = iv; r.c = c; r.fk = key & 127u;
+        reinterpret_cast<RecD *>(a.recs)[pos] = r;
+    } else {
+        const float fi = (float)iv;
+        if (fi < 0.0f) atomicOr(a.status, PCA_STATUS_NEGATIVE_INTENSITY);
+        RecF r; r.z = z;
+        r.iw = (__float_as_uint(fi) & 0x7fffffffu) | ((key & 1u) << 31);
+        r.cw = c | (((key & 127u) >> 1) << 26);
+        reinterpret_cast<RecF *>(a.recs)[pos] = r;
+    }
+}
+
+// The first REG_P * 1024 points of a chunk stay in REGISTERS between the passes (key, stored z, intensity, colour: the
+// gathers of the kept points are issued in pass A and land while it streams on), so pass B is LDS cursors and 16-byte
+// stores only.  A 200-frame KITTI window is ~10 000 points per chunk: all of it.  Whatever a chunk holds beyond that
+// (giant windows) takes the memory path: keys to the key buffer, re-read with z / intensity / colour in pass B.
+template <bool I64>
+__global__ __launch_bounds__(AB_THREADS) void bev_tile_bin(const BevArgs a)
+{
+    constexpr int REG_P = I64 ? 0 : 12;
     constexpr int UNR = 4;          // independent points per thread and iteration (memory-level parallelism)
-    for (int64_t base = w.c_lo + threadIdx.x; base < w.c_hi; base += UNR * AB_THREADS) {
+    extern __shared__ uint32_t s_lds[];                     // [T] histogram, [T] cursors
+    __shared__ uint32_t s_wsum[AB_THREADS / 64];
+    uint32_t *s_h = s_lds, *s_cur = s_lds + a.T;
+    const Window w = chunk_of(a);
+    const int64_t chunk = (w.hi - w.lo + a.G - 1) / a.G;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0 && a.frame_off[a.slot_end] - w.lo > a.max_points) atomicOr(a.status, PCA_STATUS_STORE_OVERFLOW);
+        if (threadIdx.x < HQ_IDS) a.heavy[threadIdx.x] = 0;  // the heavy queue of this call starts empty
+    }
+    for (int t = threadIdx.x; t < a.T; t += AB_THREADS) s_h[t] = 0;
+    __syncthreads();
+    const int64_t pend_hi = a.pend_slot_end > a.slot_begin ? a.frame_off[a.pend_slot_end] : w.lo;
+    const int64_t reg_hi = w.c_lo + (int64_t)REG_P * AB_THREADS < w.c_hi ? w.c_lo + (int64_t)REG_P * AB_THREADS : w.c_hi;
+    // ---- pass A, register part ----
+    uint32_t rkey[REG_P > 0 ? REG_P : 1], rrgb[REG_P > 0 ? REG_P : 1];
+    float rinten[REG_P > 0 ? REG_P : 1];
+    double rz[REG_P > 0 ? REG_P : 1];
+#pragma unroll
+    for (int j0 = 0; j0 < REG_P; j0 += UNR) {
+        double X[UNR], Y[UNR], Z[UNR];
+        uint8_t D[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t p = w.c_lo + (int64_t)(j0 + u) * AB_THREADS + threadIdx.x;
+            const bool in = p < reg_hi;
+            X[u] = in ? a.st.x[p] : 0.0;
+            Y[u] = in ? a.st.y[p] : 0.0;
+            Z[u] = in ? a.st.z[p] : 0.0;
+            D[u] = in ? a.st.dyn[p] : (uint8_t)1;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t p = w.c_lo + (int64_t)(j0 + u) * AB_THREADS + threadIdx.x;
+            rkey[j0 + u] = KEY_INVALID; rrgb[j0 + u] = 0u; rinten[j0 + u] = 0.f; rz[j0 + u] = 0.0;
+            if (p >= reg_hi) continue;
+            const BinPoint b = bin_point(a, w, pend_hi, p, X[u], Y[u], Z[u], D[u]);
+            rkey[j0 + u] = b.key;
+            rz[j0 + u] = b.z;
+            if (b.key != KEY_INVALID) {
+                atomicAdd(&s_h[b.key >> 7], 1u);
+                rrgb[j0 + u] = a.st.rgbs[p];
+                rinten[j0 + u] = a.st.intensity[p];
+            }
+        }
+    }
+    // ---- pass A, memory part (what the chunk holds beyond the registers) ----
+    for (int64_t base = reg_hi + threadIdx.x; base < w.c_hi; base += UNR * AB_THREADS) {
         double X[UNR], Y[UNR], Z[UNR];
         uint8_t D[UNR];
 #pragma unroll
@@ -116,160 +230,49 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_hist(const BevArgs a)
             D[u] = in ? a.st.dyn[p] : (uint8_t)1;
         }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {                     // owed re-transform: apply and write back
-            const int64_t p = base + u * AB_THREADS;
-            if (p < w.c_hi && p < pend_hi) {
-                const double nx = row4(a.pend_T.m + 0, X[u], Y[u], Z[u]), ny = row4(a.pend_T.m + 4, X[u], Y[u], Z[u]),
-                             nz = row4(a.pend_T.m + 8, X[u], Y[u], Z[u]);
-                X[u] = nx; Y[u] = ny; Z[u] = nz;
-                a.st.x[p] = nx; a.st.y[p] = ny; a.st.z[p] = nz;
-            }
-        }
-#pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int64_t p = base + u * AB_THREADS;
             if (p >= w.c_hi) continue;
-            const double x = X[u] - q.origin[0];
-            const double y = Y[u] - q.origin[1];
-            const double z = Z[u] - q.origin[2];
-            double ax = q.R[0] * x; ax = fma(q.R[1], y, ax); ax = fma(q.R[2], z, ax);
-            double ay = q.R[3] * x; ay = fma(q.R[4], y, ay); ay = fma(q.R[5], z, ay);
-            double az = q.R[6] * x; az = fma(q.R[7], y, az); az = fma(q.R[8], z, az);
-            ax += q.dx;
-            ay += q.dy;
-            bool keep = (ax > vlo) && (ax < vhi) && (ay > vlo) && (ay < vhi);
-            if (use_h) keep = keep && (az < q.height_filter);
-            keep = keep && (D[u] != 1);
-            uint32_t key = KEY_INVALID;
-            if (keep) {
-                int i = (int)floor(ax / v * pxd + half_px);
-                int j = (int)floor(ay / v * pxd + half_px);
-                i = i > q.px - 1 ? q.px - 1 : (i < 0 ? 0 : i);
-                j = j > q.px - 1 ? q.px - 1 : (j < 0 ? 0 : j);
-                const int row = q.px - 1 - j, col = i;
-                const uint32_t tile = (uint32_t)((row / TS) * a.tx + (col / TS));
-                const uint32_t fk = (uint32_t)(((row % TS) * TS + (col % TS)) * 2) + (p >= w.sp ? 1u : 0u);
-                key = (tile << 7) | fk;
-                atomicAdd(&s_h[tile], 1u);
-            }
-            a.key[p - w.lo] = key;
+            const BinPoint b = bin_point(a, w, pend_hi, p, X[u], Y[u], Z[u], D[u]);
+            if (b.key != KEY_INVALID) atomicAdd(&s_h[b.key >> 7], 1u);
+            a.key[p - w.lo] = b.key;
         }
     }
     __syncthreads();
-    // tile-major layout [tile][workgroup]: the scan then streams, the strided accesses ride along here and in the scatter
-    for (int t = threadIdx.x; t < a.T; t += AB_THREADS) a.bh[(int64_t)t * a.G + blockIdx.x] = s_h[t];
-}
-
-// ---------------------------------------------------------------------------------------------
-// level 1b: exclusive scan of bh in (tile-major, workgroup-minor) order -> boff, tile_off
-// ---------------------------------------------------------------------------------------------
-#define SCAN_THREADS 1024
-#ifndef SCAN_PER
-#define SCAN_PER 4                         // counters per thread (8: same time, 16: slower)
-#endif
-#define SCAN_TILE (SCAN_PER * SCAN_THREADS) // few large scan tiles: all of them run at once and each waits for its
-                                           // predecessor's prefix, so the critical path grows with their number
-__global__ __launch_bounds__(SCAN_THREADS) void bev_tile_scan(const BevArgs a)
-{
-    __shared__ int s_tile;
-    __shared__ uint32_t s_w[SCAN_THREADS / 64];
-    __shared__ uint64_t s_excl;
-    const int n = a.T * a.G;
-    if (threadIdx.x == 0 && blockIdx.x == 0) { a.heavy[0] = 0; a.heavy[1] = 0; a.heavy[2] = 0; }
-    if (threadIdx.x == 0) {
-        const uint32_t t = atomicAdd(a.ticket, 1u);
-        if ((int)t == a.scan_tiles - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_tile = (int)t;
-    }
-    __syncthreads();
-    const int tile = s_tile;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int base = tile * SCAN_TILE + threadIdx.x * SCAN_PER;    // bh and boff are both [tile][workgroup]: contiguous
-    uint32_t c[SCAN_PER];
-    if (base + SCAN_PER <= n) {
-#pragma unroll
-        for (int k = 0; k < SCAN_PER; k += 4) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(a.bh + base + k);
-            c[k] = v.x; c[k + 1] = v.y; c[k + 2] = v.z; c[k + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < SCAN_PER; ++k) c[k] = (base + k < n) ? a.bh[base + k] : 0u;
-    }
-    uint32_t tsum = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) tsum += c[k];
-    const uint32_t inc = wave_incl_scan_add(tsum);
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    if (wave == 0) {
-        const uint32_t v = lane < SCAN_THREADS / 64 ? s_w[lane] : 0u;
-        const uint32_t winc = wave_incl_scan_add(v);
-        if (lane < SCAN_THREADS / 64) s_w[lane] = winc - v;                // exclusive wave offsets
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)winc, 63);
-        const uint64_t e = lb_exclusive_prefix(a.state, tile, (uint64_t)total, a.epoch, a.ticket + 1);
-        if (lane == 0) s_excl = (e << 32) | total;                          // both fit 32 bits (checked by the host)
-    }
-    __syncthreads();
-    const uint32_t excl = (uint32_t)(s_excl >> 32), total = (uint32_t)s_excl;
-    uint32_t run = excl + s_w[wave] + (inc - tsum);
-    uint32_t o[SCAN_PER];
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) {
-        const int i = base + k;
-        o[k] = run;
-        if (i < n && i % a.G == 0) a.tile_off[i / a.G] = run;
-        run += c[k];
-    }
-    if (base + SCAN_PER <= n) {
-#pragma unroll
-        for (int k = 0; k < SCAN_PER; k += 4) *reinterpret_cast<uint4 *>(a.boff + base + k) = make_uint4(o[k], o[k + 1], o[k + 2], o[k + 3]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < SCAN_PER; ++k) if (base + k < n) a.boff[base + k] = o[k];
-    }
-    if (tile == a.scan_tiles - 1 && threadIdx.x == SCAN_THREADS - 1) a.tile_off[a.T] = excl + total;
-}
-
-// ---------------------------------------------------------------------------------------------
-// level 1c: scatter records into tile order
-// ---------------------------------------------------------------------------------------------
-template <bool I64>
-__global__ __launch_bounds__(AB_THREADS) void bev_tile_scatter(const BevArgs a)
-{
-    extern __shared__ uint32_t s_cur[];                     // [T]
-    const Window w = chunk_of(a);
-    // Queue of the tiles whose records exceed the LDS colour buffer of bev_tile_cells: they are bev_tile_cells_heavy's.
-    // Larger first (32 size classes of 1024 records, a counting sort in LDS): its workgroups draw items one at a time
-    // and the kernel ends with the last item to finish -- a 12 000-record tile drawn last runs alone while the other
-    // CUs idle.
-    if (blockIdx.x == 0) {
-        __shared__ uint32_t s_cls[32], s_base[32];
-        if (threadIdx.x < 32) s_cls[threadIdx.x] = 0;
+    // ---- exclusive scan of the histogram: thread t owns `per` consecutive tiles ----
+    {
+        const int per = (a.T + AB_THREADS - 1) / AB_THREADS;
+        const int t0 = threadIdx.x * per;
+        uint32_t sum = 0;
+        for (int k = 0; k < per; ++k) sum += t0 + k < a.T ? s_h[t0 + k] : 0u;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const uint32_t inc = wave_incl_scan_add(sum);
+        if (lane == 63) s_wsum[wave] = inc;
         __syncthreads();
-        auto cls_of = [](uint32_t sz) { const uint32_t c = sz >> 10; return 31u - (c > 31u ? 31u : c); };   // class 0 = largest
-        for (int t = threadIdx.x; t < a.T; t += AB_THREADS) {
-            const uint32_t sz = a.tile_off[t + 1] - a.tile_off[t];
-            if (sz > (uint32_t)a.heavy_min) atomicAdd(&s_cls[cls_of(sz)], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (int c = 0; c < 32; ++c) { s_base[c] = run; run += s_cls[c]; }
-            a.heavy[0] = run;
-        }
-        __syncthreads();
-        for (int t = threadIdx.x; t < a.T; t += AB_THREADS) {
-            const uint32_t sz = a.tile_off[t + 1] - a.tile_off[t];
-            if (sz > (uint32_t)a.heavy_min) a.heavy[3 + atomicAdd(&s_base[cls_of(sz)], 1u)] = (uint32_t)t;
+        uint32_t before = 0;
+        for (int k = 0; k < wave; ++k) before += s_wsum[k];
+        uint32_t run = before + inc - sum;
+        for (int k = 0; k < per; ++k) {
+            const int t = t0 + k;
+            if (t >= a.T) break;
+            const uint32_t c = s_h[t];
+            s_cur[t] = run;
+            // tile-major tables [tile][workgroup]: a tile's workgroup of level 2 reads its G counters as one range
+            a.bh[(int64_t)t * a.G + blockIdx.x] = c;
+            a.boff[(int64_t)t * a.G + blockIdx.x] = run;
+            run += c;
         }
     }
-    for (int t = threadIdx.x; t < a.T; t += AB_THREADS) s_cur[t] = a.boff[(int64_t)t * a.G + blockIdx.x];
     __syncthreads();
-    const pca_bev_params &q = a.prm;
-    const double oz = q.origin[2];
-    constexpr int UNR = 4;
-    for (int64_t base = w.c_lo + threadIdx.x; base < w.c_hi; base += UNR * AB_THREADS) {
+    // ---- pass B: the chunk's records into its segment, tile by tile ----
+    const uint32_t seg = (uint32_t)((int64_t)blockIdx.x * chunk);
+#pragma unroll
+    for (int j = 0; j < REG_P; ++j) {
+        if (rkey[j] == KEY_INVALID) continue;
+        const uint32_t pos = seg + atomicAdd(&s_cur[rkey[j] >> 7], 1u);
+        bin_store<I64>(a, pos, rkey[j], rrgb[j], rz[j], (double)rinten[j]);
+    }
+    for (int64_t base = reg_hi + threadIdx.x; base < w.c_hi; base += UNR * AB_THREADS) {
         uint32_t key[UNR], pos[UNR], rgbs[UNR];
         double zz[UNR], iv[UNR];
 #pragma unroll
@@ -285,29 +288,68 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_scatter(const BevArgs a)
             zz[u] = ok ? a.st.z[p] : 0.0;
             if (I64) iv[u] = ok ? a.intensity64[p] : 0.0;
             else iv[u] = ok ? (double)a.st.intensity[p] : 0.0;
-            pos[u] = ok ? atomicAdd(&s_cur[key[u] >> 7], 1u) : 0u;
+            pos[u] = ok ? seg + atomicAdd(&s_cur[key[u] >> 7], 1u) : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            if (key[u] == KEY_INVALID) continue;
-            const unsigned sem = rgbs[u] >> 24;
-            uint32_t c = rgbs[u] & 0xffffffu;
-            if ((int)sem == q.road_class) c |= FLAG_ROAD;
-            if ((q.dynobj_mask[sem >> 6] >> (sem & 63)) & 1ull) c |= FLAG_DYNOBJ;
-            const double z = zz[u] - oz;                    // rotation about z: row 3 of R is (0,0,1)
-            if (I64) {
-                RecD r; r.z = z; r.inten = iv[u]; r.c = c; r.fk = key[u] & 127u;
-                reinterpret_cast<RecD *>(a.recs)[pos[u]] = r;
-            } else {
-                const float fi = (float)iv[u];
-                if (fi < 0.0f) atomicOr(a.ticket + 1, PCA_STATUS_NEGATIVE_INTENSITY);
-                RecF r; r.z = z;
-                r.iw = (__float_as_uint(fi) & 0x7fffffffu) | ((key[u] & 1u) << 31);
-                r.cw = c | (((key[u] & 127u) >> 1) << 26);
-                reinterpret_cast<RecF *>(a.recs)[pos[u]] = r;
-            }
-        }
+        for (int u = 0; u < UNR; ++u)
+            if (key[u] != KEY_INVALID) bin_store<I64>(a, pos[u], key[u], rgbs[u], zz[u], iv[u]);
     }
+}
+
+// A tile's records lie in up to G pieces, one per level-1 workgroup.  RecMap (LDS) turns the tile-local record number
+// into its place in the record buffer: pre[g] = records of the pieces before piece g, base[g] = where piece g starts.
+struct RecMap {
+    uint32_t pre[1024 + 1];
+    uint32_t base[1024];
+    uint32_t wsum[16];
+};
+// builds the map of `tile` (all `nthreads` threads of the workgroup, G <= 1024); returns the tile's record count.
+// Ends with a barrier.
+__device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, int tile, int nthreads)
+{
+    const int64_t lo = a.frame_off[a.slot_begin], hi0 = a.frame_off[a.slot_end];
+    const int64_t n = hi0 - lo > a.max_points ? a.max_points : hi0 - lo;
+    const uint32_t chunk = (uint32_t)((n + a.G - 1) / a.G);
+    const int per = (a.G + nthreads - 1) / nthreads;
+    const int g0 = threadIdx.x * per;
+    const uint32_t *cnt = a.bh + (int64_t)tile * a.G, *off = a.boff + (int64_t)tile * a.G;
+    uint32_t c[4] = {0, 0, 0, 0}, sum = 0;                  // per <= 4: G <= 1024, nthreads >= 256
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < per && g0 + k < a.G) {
+            c[k] = cnt[g0 + k];
+            M.base[g0 + k] = (uint32_t)(g0 + k) * chunk + off[g0 + k];
+            sum += c[k];
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan_add(sum);
+    if (lane == 63) M.wsum[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int k = 0; k < wave; ++k) run += M.wsum[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < per && g0 + k < a.G) { M.pre[g0 + k] = run; run += c[k]; }
+    if ((int)threadIdx.x == nthreads - 1) M.pre[a.G] = run;
+    __syncthreads();
+    return M.pre[a.G];
+}
+// place of the tile's record number i (< the tile's count): the last piece g with pre[g] <= i
+__device__ __forceinline__ uint32_t recmap_at(const RecMap &M, int G, uint32_t i)
+{
+    int lo = 0, hi = G;                                     // pre[lo] <= i < pre[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (M.pre[mid] <= i) lo = mid; else hi = mid;
+    }
+    return M.base[lo] + (i - M.pre[lo]);
+}
+// the tile joins the queue of bev_tile_cells_heavy, larger size classes first (classes of 1024 records): its workgroups
+// draw items one at a time and the kernel ends with the last item to finish
+__device__ __forceinline__ void heavy_push(const BevArgs &a, int tile, uint32_t count)
+{
+    const uint32_t c = count >> 10, cls = (HQ_CLASSES - 1) - (c > HQ_CLASSES - 1 ? HQ_CLASSES - 1 : c);
+    a.heavy[HQ_IDS + (size_t)cls * a.T + atomicAdd(&a.heavy[cls], 1u)] = (uint32_t)tile;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -614,11 +656,15 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
     // Dense tiles are neighbours in the grid (they follow the driven path).  Workgroup b takes tile b * tile_mult mod T
     // (tile_mult coprime to T), which interleaves them with the empty ones in dispatch order.
     const int tile = (int)(((int64_t)blockIdx.x * a.tile_mult) % a.T);
-    const uint32_t r_lo = a.tile_off[tile], r_hi = a.tile_off[tile + 1];
-    if (r_hi - r_lo > (uint32_t)a.heavy_min) return;        // bev_tile_cells_heavy's (queued by bev_tile_scatter)
     const unsigned long long t_begin = wall_clock64();
+    RecMap &M = *reinterpret_cast<RecMap *>(s_buf);         // lives in the colour buffer until pass 2 fills that
+    static_assert(sizeof(RecMap) <= sizeof(s_buf), "RecMap aliases the colour buffer");
     stats_init(L.S, C_THREADS);
-    __syncthreads();
+    const uint32_t r_lo = 0, r_hi = recmap_build(M, a, tile, C_THREADS);
+    if (r_hi > (uint32_t)a.heavy_min) {                     // bev_tile_cells_heavy's
+        if (threadIdx.x == 0) heavy_push(a, tile, r_hi);
+        return;
+    }
 
     // ---- pass 1: per (cell,set) statistics; every thread keeps its <= RPT records' (key, rank, colour) in registers
     // -- the rank is the run's base (returned by the counting atomic) + the position in the run -- so that pass 2 is
@@ -640,7 +686,7 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
             const int uu = h * HALF + u;
             const uint32_t r = r_lo + (contig ? threadIdx.x * RPT + uu : uu * C_THREADS + threadIdx.x);
             k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
-            if (r < r_hi) load_rec<I64>(a, r, k[u], c[u], z[u], iv[u]);
+            if (r < r_hi) load_rec<I64>(a, recmap_at(M, a.G, r), k[u], c[u], z[u], iv[u]);
         }
 #pragma unroll
         for (int u = 0; u < HALF; ++u) {
@@ -705,6 +751,7 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
 #define H_HIST_DWORDS (H_CELLS * 2 * 3 * 128)               // 96 KiB
 struct HeavyLds {
     TileStats S;
+    RecMap M;
     uint32_t hist[3][256];                                  // 32-bit fallback for a (cell,set) of 65 536 values or more
     uint32_t overflow;                                      // some (cell,set) of this tile needs it
 };
@@ -720,7 +767,7 @@ __device__ __forceinline__ void heavy_hist32(HeavyLds &L, const BevArgs &a, uint
         uint32_t v = 0;
         if (act) {
             uint32_t k;
-            load_rec_key_colour<I64>(a, r, k, v);
+            load_rec_key_colour<I64>(a, recmap_at(L.M, a.G, r), k, v);
             act = k == fk;
         }
         const uint32_t tag = act ? v : 0xffffffffu;
@@ -749,7 +796,15 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs 
     __shared__ uint32_t s_next;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool extra = a.extra != nullptr;
-    const uint32_t n_heavy = a.heavy[0];
+    // the queue: HQ_CLASSES lists of tile ids, larger tiles first; item -> (class, place) by the classes' running counts
+    __shared__ uint32_t s_cls[HQ_CLASSES + 1];
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int c = 0; c < HQ_CLASSES; ++c) { s_cls[c] = run; run += a.heavy[c]; }
+        s_cls[HQ_CLASSES] = run;
+    }
+    __syncthreads();
+    const uint32_t n_heavy = s_cls[HQ_CLASSES];
     // the count goes to host-visible memory only when it differs from what the host already knows (a write over PCIe
     // holds the kernel's end back by microseconds; in steady state nothing changes)
     if (blockIdx.x == 0 && threadIdx.x == 0 && n_heavy != a.heavy_hint_known) *a.heavy_hint = n_heavy;
@@ -758,15 +813,21 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs 
     // the kernel ends with its slowest ITEM, and most CUs would otherwise idle behind the few densest tiles.
     constexpr int HALVES = TCELLS / H_CELLS;
     for (;;) {
-    if (threadIdx.x == 0) s_next = atomicAdd(&a.heavy[1], 1u);
+    if (threadIdx.x == 0) s_next = atomicAdd(&a.heavy[HQ_CURSOR], 1u);
     __syncthreads();
     const uint32_t item = s_next;
     if (item >= n_heavy * HALVES) break;
-    const int tile = (int)a.heavy[3 + item / HALVES];
+    int tile;
+    {
+        const uint32_t ti = item / HALVES;
+        int cls = 0;
+        while (cls + 1 < HQ_CLASSES && s_cls[cls + 1] <= ti) ++cls;
+        tile = (int)a.heavy[HQ_IDS + (size_t)cls * a.T + (ti - s_cls[cls])];
+    }
     const int half = (int)(item % HALVES);
     if (item >= (uint32_t)gridDim.x) t_begin = wall_clock64();
-    const uint32_t r_lo = a.tile_off[tile], r_hi = a.tile_off[tile + 1];
     stats_init(L.S, H_THREADS);
+    const uint32_t r_lo = 0, r_hi = recmap_build(L.M, a, tile, H_THREADS);
     if (threadIdx.x == 0) L.overflow = 0;
     {
         for (int k = threadIdx.x; k < H_HIST_DWORDS / 4; k += H_THREADS) reinterpret_cast<uint4 *>(hist)[k] = make_uint4(0, 0, 0, 0);
@@ -784,7 +845,7 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs 
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
-                if (r0 + u < t_hi) load_rec<I64>(a, r0 + u, k[u], c[u], z[u], iv[u]);
+                if (r0 + u < t_hi) load_rec<I64>(a, recmap_at(L.M, a.G, r0 + u), k[u], c[u], z[u], iv[u]);
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -869,8 +930,8 @@ int64_t pca_bev_workspace_bytes(int64_t max_points, int px)
 {
     if (max_points < 1) max_points = 1;
     const int64_t T = (int64_t)tiles_x(px) * tiles_x(px), G = n_groups(max_points);
-    return align256(max_points * 4) + 2 * align256(G * T * 4) + align256((T + 1) * 4) + align256((T + 3) * 4) +
-           align256(max_points * 24) + 512;
+    return align256(max_points * 4) + 2 * align256(G * T * 4) + align256((HQ_IDS + HQ_CLASSES * T) * 4) +
+           align256((max_points + G) * 24) + 512;
 }
 
 int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensity64, const int64_t *frame_off,
@@ -922,29 +983,27 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
     a.key = reinterpret_cast<uint32_t *>(w); w += align256(max_points * 4);
     a.bh = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)a.G * a.T * 4);
     a.boff = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)a.G * a.T * 4);
-    a.tile_off = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.T + 1) * 4);
-    a.heavy = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.T + 3) * 4);
+    a.heavy = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(HQ_IDS + HQ_CLASSES * (int64_t)a.T) * 4);
     a.recs = w;
     a.planes = planes;
     a.planes_f16 = planes_f16;
     a.extra = extra_planes;
     { static int hm = -1; if (hm < 0) { const char *e = getenv("PCA_BEV_HEAVY_MIN"); hm = e ? atoi(e) : HEAVY_MIN_DEFAULT; if (hm < 1 || hm > RGB_CAP) hm = RGB_CAP; } a.heavy_min = hm; }
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("PCA_BEV_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
-    static bool heavy_lds_set = false;                      // > 64 KiB of dynamic LDS has to be asked for once
-    if (!heavy_lds_set) {
+    const size_t lds = (size_t)a.T * 8;                     // bev_tile_bin: histogram + cursors
+    static bool lds_set = false;                            // > 64 KiB of dynamic LDS has to be asked for once
+    if (!lds_set) {
         PCA_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&bev_tile_cells_heavy<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAVY_LDS_BYTES));
         PCA_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&bev_tile_cells_heavy<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAVY_LDS_BYTES));
-        heavy_lds_set = true;
+        PCA_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&bev_tile_bin<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        PCA_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&bev_tile_bin<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        lds_set = true;
     }
-    const int64_t n_scan = (int64_t)a.T * a.G;
-    a.scan_tiles = (int)((n_scan + SCAN_TILE - 1) / SCAN_TILE);
-    if (pca_ctx_reserve_tiles(ctx, a.scan_tiles, s)) return -1;
-    a.state = ctx->tile_state;
-    a.ticket = ctx->ticket;
-    a.epoch = pca_ctx_next_epoch(ctx, s);
-    const size_t lds = (size_t)a.T * 4;
+    a.status = ctx->ticket + 1;
     {
         auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
         int m = (int)(a.T * 0.6180339887) | 1;
@@ -958,16 +1017,14 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
     a.heavy_hint = ctx->heavy_hint_dev;
     a.heavy_hint_known = *ctx->heavy_hint;
     if (ctx->profiling == 2) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
-    PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_hist, dim3(a.G), dim3(AB_THREADS), lds, s, a);
-    PCA_LAUNCH(ctx, PCA_K_BEV_SCAN, bev_tile_scan, dim3(a.scan_tiles), dim3(SCAN_THREADS), s, a);
     // (Running the two tile kernels side by side was tried: a second stream with fork / join events costs ~20 us per
     // call, and hipExtAnyOrderLaunch is not honoured on gfx9 -- see DESIGN.md.)
     if (intensity64) {
-        PCA_LAUNCH_SHM(ctx, PCA_K_BEV_SCATTER, bev_tile_scatter<true>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
+        PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_bin<true>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
         PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_tile_cells<true>, dim3(a.T), dim3(C_THREADS), s, a);
         PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, bev_tile_cells_heavy<true>, dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a);
     } else {
-        PCA_LAUNCH_SHM(ctx, PCA_K_BEV_SCATTER, bev_tile_scatter<false>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
+        PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_bin<false>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
         PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_tile_cells<false>, dim3(a.T), dim3(C_THREADS), s, a);
         PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, bev_tile_cells_heavy<false>, dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a);
     }
