@@ -334,13 +334,17 @@ __device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, in
     __syncthreads();
     return M.pre[a.G];
 }
-// place of the tile's record number i (< the tile's count): the last piece g with pre[g] <= i
+// place of the tile's record number i (< the tile's count): the last piece g with pre[g] <= i.  Ten fixed steps, no
+// branches: the lookups of a thread's 16 records are independent chains of LDS reads that the compiler interleaves (a
+// data-dependent loop per record cost the light kernel 7 us).
 __device__ __forceinline__ uint32_t recmap_at(const RecMap &M, int G, uint32_t i)
 {
-    int lo = 0, hi = G;                                     // pre[lo] <= i < pre[hi]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (M.pre[mid] <= i) lo = mid; else hi = mid;
+    int lo = 0;
+#pragma unroll
+    for (int step = 512; step >= 1; step >>= 1) {
+        const int m = lo + step;
+        const uint32_t pm = M.pre[m < G ? m : G];          // pre[G] = the tile's count > i
+        lo = pm <= i ? m : lo;
     }
     return M.base[lo] + (i - M.pre[lo]);
 }
