@@ -60,6 +60,7 @@ struct BevArgs {
     uint32_t *boff;       // [T][G] exclusive scan of bh in that order
     uint32_t *heavy_hint; // host-visible word: the heavy count of this call, read by the host before the next one
     uint32_t heavy_hint_known;   // its value when this call was made
+    int heavy_launched;   // a bev_tile_cells_heavy launch follows (else the light kernel's last workgroup drains the queue)
     uint32_t *heavy;      // [64 + 32 T]: [0..32) tiles per size class (class 0 = largest), [32] item cursor, then the
                           // classes' tile ids [class][T] -- the queue of bev_tile_cells_heavy, filled by bev_tile_cells
     void *recs;           // RecF / RecD [max_points], tile-ordered; c = r | g<<8 | b<<16 | FLAG_*
@@ -71,6 +72,7 @@ struct BevArgs {
 };
 #define HQ_CLASSES 32
 #define HQ_CURSOR 32
+#define HQ_DONE 33              // workgroups of bev_tile_cells that have finished (cells_drain)
 #define HQ_IDS 64
 
 struct Window { int64_t lo, hi, sp, c_lo, c_hi; };
@@ -647,6 +649,69 @@ __device__ __forceinline__ void wave_cells_hist(TileLds &L, const uint32_t *s_rg
     }
 }
 
+template <bool I64, int NT>
+__device__ __forceinline__ void tile_cell_medians32(TileStats &S, uint32_t (*hist)[256], const RecMap &M, const BevArgs &a, int cell,
+                                                    uint32_t r_lo, uint32_t r_hi);
+
+// When the previous call queued no heavy tile the host launches no bev_tile_cells_heavy (an empty launch is 4-6 us of
+// every step on uniform data).  Should tiles be queued nonetheless -- the first dense tile of a sequence -- the LAST
+// workgroup of the light kernel to finish works them off, slowly but exactly: statistics in one pass, then 32-bit
+// histograms cell by cell.  It also tells the host, so that the next call launches the heavy kernel.
+template <bool I64>
+__device__ __forceinline__ void cells_drain(const BevArgs &a, TileStats &S, unsigned char *s_buf, bool pushed)
+{
+    if (a.heavy_launched) return;
+    __shared__ uint32_t s_drain_n;
+    if (threadIdx.x == 0) {
+        uint32_t n = 0;
+        if (pushed) __threadfence();                        // this workgroup's queue entry, before it counts as done
+        if (__hip_atomic_fetch_add(&a.heavy[HQ_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            __threadfence();
+            for (int c = 0; c < HQ_CLASSES; ++c) n += __hip_atomic_load(&a.heavy[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n != a.heavy_hint_known) *a.heavy_hint = n;
+        }
+        s_drain_n = n;
+    }
+    __syncthreads();
+    if (s_drain_n == 0) return;
+    __threadfence();
+    const bool extra = a.extra != nullptr;
+    RecMap &M = *reinterpret_cast<RecMap *>(s_buf);
+    uint32_t (*hist)[256] = reinterpret_cast<uint32_t (*)[256]>(s_buf + ((sizeof(RecMap) + 15) & ~(size_t)15));
+    static_assert(((sizeof(RecMap) + 15) & ~(size_t)15) + 3 * 256 * 4 <= RGB_CAP * 4, "RecMap + histograms live in the colour buffer");
+    for (int cls = 0; cls < HQ_CLASSES; ++cls) {
+        const uint32_t n_cls = __hip_atomic_load(&a.heavy[cls], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t k = 0; k < n_cls; ++k) {
+            const int tile = (int)__hip_atomic_load(&a.heavy[HQ_IDS + (size_t)cls * a.T + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();                                // the staging area of the tile before
+            stats_init(S, C_THREADS);
+            const uint32_t r_hi = recmap_build(M, a, tile, C_THREADS);
+            Run run;
+            run_reset(run, RUN_NONE);
+            const uint32_t per_thread = (r_hi + C_THREADS - 1) / C_THREADS;
+            const uint32_t t_lo = threadIdx.x * per_thread, t_hi = t_lo + per_thread < r_hi ? t_lo + per_thread : r_hi;
+            for (uint32_t r = t_lo; r < t_hi; ++r) {
+                uint32_t kk, c;
+                double z, iv;
+                load_rec<I64>(a, recmap_at(M, a.G, r), kk, c, z, iv);
+                if (kk != run.key) {
+                    if (run.key != RUN_NONE) run_flush(S, extra, run);
+                    run_reset(run, kk);
+                }
+                run_add(run, extra, c, z, iv);
+            }
+            if (run.key != RUN_NONE) run_flush(S, extra, run);
+            __syncthreads();
+            for (int cell = 0; cell < TCELLS; ++cell) {
+                if (S.cnt[2 * cell] + S.cnt[2 * cell + 1] == 0) continue;
+                tile_cell_medians32<I64, C_THREADS>(S, hist, M, a, cell, 0u, r_hi);
+            }
+            __syncthreads();
+            tile_finalize_write(a, S, reinterpret_cast<double(*)[TCELLS]>(s_buf), tile, C_THREADS);
+        }
+    }
+}
+
 __device__ unsigned long long g_dbg_stamps[1024][8];   // PCA_BEV_DBG=8|16: per-tile phase stamps (diagnostics)
 #define DBG_STAMP(bit, slot) do { if ((a.dbg & (bit)) && threadIdx.x == 0 && tile < 1024) g_dbg_stamps[tile][slot] = wall_clock64(); } while (0)
 template <bool I64>
@@ -667,6 +732,7 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
     const uint32_t r_lo = 0, r_hi = recmap_build(M, a, tile, C_THREADS);
     if (r_hi > (uint32_t)a.heavy_min) {                     // bev_tile_cells_heavy's
         if (threadIdx.x == 0) heavy_push(a, tile, r_hi);
+        cells_drain<I64>(a, L.S, s_buf, true);
         return;
     }
 
@@ -740,6 +806,7 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
     __syncthreads();
     DBG_STAMP(16, 6);
     tile_finalize_write(a, L.S, reinterpret_cast<double(*)[TCELLS]>(s_buf), tile, C_THREADS);
+    cells_drain<I64>(a, L.S, s_buf, false);
     if ((a.dbg & 16) && threadIdx.x == 0 && tile < 1024) {
         g_dbg_stamps[tile][0] = t_begin; g_dbg_stamps[tile][1] = wall_clock64(); g_dbg_stamps[tile][2] = r_hi - r_lo;
         uint32_t big = 0;
@@ -761,17 +828,19 @@ struct HeavyLds {
 };
 #define HEAVY_LDS_BYTES (H_HIST_DWORDS * 4 + sizeof(HeavyLds))
 
-template <bool I64>
-__device__ __forceinline__ void heavy_hist32(HeavyLds &L, const BevArgs &a, uint32_t fk, uint32_t r_lo, uint32_t r_hi)
+// 32-bit 256-bin histograms hist[3][256] of the colours of one fine key (cell,set), whole workgroup of NT threads
+template <bool I64, int NT>
+__device__ __forceinline__ void tile_hist32(uint32_t (*hist)[256], const RecMap &M, const BevArgs &a, uint32_t fk, uint32_t r_lo,
+                                            uint32_t r_hi)
 {
     const int lane = threadIdx.x & 63;
-    for (uint32_t r0 = r_lo; r0 < r_hi; r0 += H_THREADS) {
+    for (uint32_t r0 = r_lo; r0 < r_hi; r0 += NT) {
         const uint32_t r = r0 + threadIdx.x;
         bool act = r < r_hi;
         uint32_t v = 0;
         if (act) {
             uint32_t k;
-            load_rec_key_colour<I64>(a, recmap_at(L.M, a.G, r), k, v);
+            load_rec_key_colour<I64>(a, recmap_at(M, a.G, r), k, v);
             act = k == fk;
         }
         const uint32_t tag = act ? v : 0xffffffffu;
@@ -781,12 +850,37 @@ __device__ __forceinline__ void heavy_hist32(HeavyLds &L, const BevArgs &a, uint
         if (__ballot(tag == first) == actm && first != 0xffffffffu) {
             if (lane == (int)__ffsll((unsigned long long)actm) - 1) {
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) atomicAdd(&L.hist[ch][(v >> (8 * ch)) & 255u], (uint32_t)__popcll(actm));
+                for (int ch = 0; ch < 3; ++ch) atomicAdd(&hist[ch][(v >> (8 * ch)) & 255u], (uint32_t)__popcll(actm));
             }
         } else if (act) {
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) atomicAdd(&L.hist[ch][(v >> (8 * ch)) & 255u], 1u);
+            for (int ch = 0; ch < 3; ++ch) atomicAdd(&hist[ch][(v >> (8 * ch)) & 255u], 1u);
         }
+    }
+}
+// present / future / full medians of one cell from 32-bit histograms (three passes over the tile's records)
+template <bool I64, int NT>
+__device__ __forceinline__ void tile_cell_medians32(TileStats &S, uint32_t (*hist)[256], const RecMap &M, const BevArgs &a, int cell,
+                                                    uint32_t r_lo, uint32_t r_hi)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n_p = S.cnt[2 * cell], n_f = S.cnt[2 * cell + 1];
+    for (int round = 0; round < 2; ++round) {               // round 0: present, then + future = full; round 1: future
+        for (int i = threadIdx.x; i < 3 * 256; i += NT) (&hist[0][0])[i] = 0;
+        __syncthreads();
+        if (round == 0) {
+            tile_hist32<I64, NT>(hist, M, a, 2 * cell, r_lo, r_hi);
+            __syncthreads();
+            if (wave < 3) { const uint32_t m = hist_med2(hist[wave], n_p); if (lane == 0) S.med2[0][cell][wave] = m; }
+            __syncthreads();
+        }
+        tile_hist32<I64, NT>(hist, M, a, 2 * cell + 1, r_lo, r_hi);
+        __syncthreads();
+        if (wave < 3) {
+            const uint32_t m = hist_med2(hist[wave], round == 0 ? n_p + n_f : n_f);
+            if (lane == 0) S.med2[round == 0 ? 2 : 1][cell][wave] = m;
+        }
+        __syncthreads();
     }
 }
 
@@ -881,23 +975,7 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs 
     for (int cell = half * H_CELLS; L.overflow && cell < (half + 1) * H_CELLS; ++cell) {
         const uint32_t n_p = L.S.cnt[2 * cell], n_f = L.S.cnt[2 * cell + 1];
         if (n_p <= 0xffffu && n_f <= 0xffffu) continue;
-        for (int round = 0; round < 2; ++round) {           // round 0: present, then + future = full; round 1: future
-            for (int i = threadIdx.x; i < 3 * 256; i += H_THREADS) (&L.hist[0][0])[i] = 0;
-            __syncthreads();
-            if (round == 0) {
-                heavy_hist32<I64>(L, a, 2 * cell, r_lo, r_hi);
-                __syncthreads();
-                if (wave < 3) { const uint32_t m = hist_med2(L.hist[wave], n_p); if (lane == 0) L.S.med2[0][cell][wave] = m; }
-                __syncthreads();
-            }
-            heavy_hist32<I64>(L, a, 2 * cell + 1, r_lo, r_hi);
-            __syncthreads();
-            if (wave < 3) {
-                const uint32_t m = hist_med2(L.hist[wave], round == 0 ? n_p + n_f : n_f);
-                if (lane == 0) L.S.med2[round == 0 ? 2 : 1][cell][wave] = m;
-            }
-            __syncthreads();
-        }
+        tile_cell_medians32<I64, H_THREADS>(L.S, L.hist, L.M, a, cell, r_lo, r_hi);
     }
     __syncthreads();
     tile_finalize_write(a, L.S, reinterpret_cast<double(*)[TCELLS]>(smem), tile, H_THREADS, half * H_CELLS, (half + 1) * H_CELLS);
@@ -1016,21 +1094,26 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
     }
     // one resident workgroup per CU draws from the queue -- when the previous call had no heavy tile (uniform data)
     // only a few are launched: any number of them drains the queue, and 256 idle 110-KiB workgroups cost ~5 us
-    int heavy_grid = a.T < ctx->n_cu ? a.T : ctx->n_cu;
-    if (*ctx->heavy_hint == 0 && heavy_grid > 16) heavy_grid = 16;
+    const int heavy_grid = a.T < ctx->n_cu ? a.T : ctx->n_cu;
     a.heavy_hint = ctx->heavy_hint_dev;
     a.heavy_hint_known = *ctx->heavy_hint;
+    // the heavy kernel is launched while heavy tiles were seen in one of the last 64 calls (a tile hovering around the
+    // threshold must not pay the light kernel's slow path every other call); PCA_BEV_HEAVY_ALWAYS=1: regardless (A/B)
+    if (a.heavy_hint_known != 0) ctx->heavy_cooldown = 64;
+    else if (ctx->heavy_cooldown > 0) --ctx->heavy_cooldown;
+    a.heavy_launched = a.heavy_hint_known != 0 || ctx->heavy_cooldown > 0;
+    { static int always = -1; if (always < 0) { const char *e = getenv("PCA_BEV_HEAVY_ALWAYS"); always = e ? atoi(e) : 0; } if (always) a.heavy_launched = 1; }
     if (ctx->profiling == 2) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
     // (Running the two tile kernels side by side was tried: a second stream with fork / join events costs ~20 us per
     // call, and hipExtAnyOrderLaunch is not honoured on gfx9 -- see DESIGN.md.)
     if (intensity64) {
         PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_bin<true>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
         PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_tile_cells<true>, dim3(a.T), dim3(C_THREADS), s, a);
-        PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, bev_tile_cells_heavy<true>, dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a);
+        if (a.heavy_launched) PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, bev_tile_cells_heavy<true>, dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a);
     } else {
         PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_bin<false>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
         PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_tile_cells<false>, dim3(a.T), dim3(C_THREADS), s, a);
-        PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, bev_tile_cells_heavy<false>, dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a);
+        if (a.heavy_launched) PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, bev_tile_cells_heavy<false>, dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a);
     }
     if (ctx->profiling == 2) pca_prof_end(ctx, s);
     PCA_CHECK(ctx, hipGetLastError());

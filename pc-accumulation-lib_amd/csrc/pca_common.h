@@ -43,6 +43,7 @@ struct pca_ctx {
     int k1_pin_next = 0;
     unsigned long long *dbg = nullptr; // diagnostic stamps of the last K1 launch (PCA_K1_STAMPS)
     int dbg_blocks = 0;
+    int heavy_cooldown = 0;           // calls for which bev_tile_cells_heavy is still launched after the last heavy tile
     uint32_t *status_host = nullptr;  // pinned
     uint32_t *heavy_hint = nullptr;   // pinned, device-visible: heavy-tile count of the latest rasteriser call
     uint32_t *heavy_hint_dev = nullptr;

@@ -462,6 +462,22 @@ def test_bev_ring_like_skew_heavy_and_light_tiles(T, orc, n, sigma, spread):
     assert_planes_match(p16, p64, ref, f'skew n={n}')
 
 
+def test_bev_heavy_tiles_without_and_with_the_heavy_kernel(T, orc):
+    """The heavy kernel is only launched while heavy tiles were seen in one of the last 64 calls.  After 70 sparse
+    rasters a dense one finds no heavy launch behind it: the light kernel's last workgroup works the queue off (exact,
+    slow) and tells the host; the call after that goes through the heavy kernel.  Both equal the oracle."""
+    rng = np.random.default_rng(5)
+    sparse = _skewed_rows(rng, 2000, 6.0, 8)
+    for _ in range(70):
+        run_dev_bev(T, sparse[:800], sparse[800:], 32, 64, None, (1., 30., 0.12), True, 0.2)
+    rows = _skewed_rows(rng, 200000, 0.9, 4)
+    cut = 80000
+    ref = run_orc_bev(orc, rows[:cut], rows[cut:], 32, 64, None, (1., 30., 0.12), True, 0.2)
+    for which in ('drained by the light kernel', 'heavy kernel'):
+        p16, p64, _ = run_dev_bev(T, rows[:cut], rows[cut:], 32, 64, None, (1., 30., 0.12), True, 0.2)
+        assert_planes_match(p16, p64, ref, which)
+
+
 def test_bev_cell_beyond_16bit_counters(T, orc):
     """One (cell, set) with more than 65 535 values: the heavy kernel's packed 16-bit histograms overflow there and the
     32-bit whole-workgroup path must take over for that cell only."""
