@@ -658,8 +658,9 @@ __device__ __forceinline__ void tile_cell_medians32(TileStats &S, uint32_t (*his
 // workgroup of the light kernel to finish works them off, slowly but exactly: statistics in one pass, then 32-bit
 // histograms cell by cell.  It also tells the host, so that the next call launches the heavy kernel.
 template <bool I64>
-__device__ __forceinline__ void cells_drain(const BevArgs &a, TileStats &S, unsigned char *s_buf, bool pushed)
+__device__ __forceinline__ void cells_drain(const BevArgs &a, TileLds &L, unsigned char *s_buf, bool pushed)
 {
+    TileStats &S = L.S;
     if (a.heavy_launched) return;
     __shared__ uint32_t s_drain_n;
     if (threadIdx.x == 0) {
@@ -702,9 +703,35 @@ __device__ __forceinline__ void cells_drain(const BevArgs &a, TileStats &S, unsi
             }
             if (run.key != RUN_NONE) run_flush(S, extra, run);
             __syncthreads();
-            for (int cell = 0; cell < TCELLS; ++cell) {
-                if (S.cnt[2 * cell] + S.cnt[2 * cell + 1] == 0) continue;
-                tile_cell_medians32<I64, C_THREADS>(S, hist, M, a, cell, 0u, r_hi);
+            // medians: four cells (eight fine keys) per pass over the tile's records, 16-bit packed histograms in the
+            // light path's per-wave histogram area; a (cell,set) beyond 65 535 values takes the 32-bit path on its own
+            uint32_t *h16 = &L.whist[0][0][0][0];           // [8 keys][3 channels][128 dwords]
+            for (int c0 = 0; c0 < TCELLS; c0 += 4) {
+                uint32_t any = 0;
+                for (int c = c0; c < c0 + 4; ++c) any += S.cnt[2 * c] + S.cnt[2 * c + 1];
+                if (any == 0) continue;                     // uniform: LDS values
+                for (int k = threadIdx.x; k < 8 * 3 * 128 / 4; k += C_THREADS) reinterpret_cast<uint4 *>(h16)[k] = make_uint4(0, 0, 0, 0);
+                __syncthreads();
+                for (uint32_t r = threadIdx.x; r < r_hi; r += C_THREADS) {
+                    uint32_t kk, v;
+                    load_rec_key_colour<I64>(a, recmap_at(M, a.G, r), kk, v);
+                    const uint32_t rel = kk - 2u * (uint32_t)c0;
+                    if (rel >= 8u) continue;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) hist16_add(h16 + (rel * 3 + ch) * 128, (v >> (8 * ch)) & 255u, 1u);
+                }
+                __syncthreads();
+                const int wave = threadIdx.x >> 6;
+                for (int job = wave; job < 4 * 3; job += C_THREADS / 64) {
+                    const int cl = job / 3, ch = job % 3, cell = c0 + cl;
+                    const uint32_t n_p = S.cnt[2 * cell], n_f = S.cnt[2 * cell + 1];
+                    if (n_p + n_f == 0 || n_p > 0xffffu || n_f > 0xffffu) continue;
+                    hist16_medians(S, h16 + ((2 * cl) * 3 + ch) * 128, h16 + ((2 * cl + 1) * 3 + ch) * 128, cell, ch, n_p, n_f);
+                }
+                __syncthreads();
+                for (int cell = c0; cell < c0 + 4; ++cell)
+                    if (S.cnt[2 * cell] > 0xffffu || S.cnt[2 * cell + 1] > 0xffffu)
+                        tile_cell_medians32<I64, C_THREADS>(S, hist, M, a, cell, 0u, r_hi);
             }
             __syncthreads();
             tile_finalize_write(a, S, reinterpret_cast<double(*)[TCELLS]>(s_buf), tile, C_THREADS);
@@ -732,7 +759,7 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
     const uint32_t r_lo = 0, r_hi = recmap_build(M, a, tile, C_THREADS);
     if (r_hi > (uint32_t)a.heavy_min) {                     // bev_tile_cells_heavy's
         if (threadIdx.x == 0) heavy_push(a, tile, r_hi);
-        cells_drain<I64>(a, L.S, s_buf, true);
+        cells_drain<I64>(a, L, s_buf, true);
         return;
     }
 
@@ -806,7 +833,7 @@ __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
     __syncthreads();
     DBG_STAMP(16, 6);
     tile_finalize_write(a, L.S, reinterpret_cast<double(*)[TCELLS]>(s_buf), tile, C_THREADS);
-    cells_drain<I64>(a, L.S, s_buf, false);
+    cells_drain<I64>(a, L, s_buf, false);
     if ((a.dbg & 16) && threadIdx.x == 0 && tile < 1024) {
         g_dbg_stamps[tile][0] = t_begin; g_dbg_stamps[tile][1] = wall_clock64(); g_dbg_stamps[tile][2] = r_hi - r_lo;
         uint32_t big = 0;
