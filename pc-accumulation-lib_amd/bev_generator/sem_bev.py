@@ -13,19 +13,36 @@ from .bev_generator import PLANES, SETS, BEVGenerator, WindowPart
 class LazyBev(dict):
     """The reference's BEV dict whose plane arrays are still on their way from the device: the fp16 D2H copy was
     enqueued on a side stream into pinned memory; the first access waits for THAT copy only and fills the dict in.
-    A consumer that hands the dict to a background writer (write_compressed_pickle does) never waits at all."""
+    A consumer that hands the dict to a background writer (write_compressed_pickle does) never waits at all.
+    The arrays are VIEWS of the pinned block the copy landed in (no second copy of the 2.75 MB sample: that was 0.12 ms
+    of the unchanged driver's 0.5 ms step); the block returns to torch's pinned-memory cache when the last array dies.
+    A program that keeps more than MAX_PINNED_LIVE samples alive gets ordinary (copied) arrays for the ones beyond."""
+
+    MAX_PINNED_LIVE = 64
+    _live = [0]
 
     def __init__(self, host, index, event, trajs, gt_lanes=None):
         super().__init__()
         self._pending = (host, index, event, trajs, gt_lanes)
+        self._zero_copy = LazyBev._live[0] < LazyBev.MAX_PINNED_LIVE
+        if self._zero_copy:
+            import weakref
+            LazyBev._live[0] += 1
+            weakref.finalize(self, LazyBev._released)
+
+    @staticmethod
+    def _released():
+        LazyBev._live[0] -= 1
 
     def _fill(self):
         if self._pending is not None:
             host, index, event, trajs, gt_lanes = self._pending
             self._pending = None
             event.synchronize()
-            # own copy: the pinned block belongs to a ring and is reused for a later sample
-            dict.update(self, SemBEVGenerator.pack_bev(np.array(host[index].numpy()), trajs[0], trajs[1], trajs[2], gt_lanes))
+            planes = host[index].numpy()
+            if not self._zero_copy:
+                planes = np.array(planes)
+            dict.update(self, SemBEVGenerator.pack_bev(planes, trajs[0], trajs[1], trajs[2], gt_lanes))
         return self
 
     def __getitem__(self, k):
@@ -129,21 +146,9 @@ class SemBEVGenerator(BEVGenerator):
         import torch
         if getattr(self, '_d2h_stream', None) is None:
             self._d2h_stream = torch.cuda.Stream(planes.device)
-            self._d2h_ring, self._d2h_next = [None] * 8, 0
-        # pinned ring: a block is reused 8 calls later; whoever still waits on it then is filled in first
-        slot = self._d2h_next % len(self._d2h_ring)
-        self._d2h_next += 1
-        old = self._d2h_ring[slot]
-        host = None
-        if old is not None:
-            for ref in old[1]:
-                bev = ref()
-                if bev is not None:
-                    bev._fill()
-            if tuple(old[0].shape) == tuple(planes.shape):
-                host = old[0]
-        if host is None:
-            host = torch.empty(tuple(planes.shape), dtype=torch.float16).pin_memory()
+        # a fresh pinned block per call: torch's caching host allocator hands back a block whose arrays have all died
+        # (and whose copies have completed), so in steady state this allocates nothing
+        host = torch.empty(tuple(planes.shape), dtype=torch.float16, pin_memory=True)
         side = self._d2h_stream
         side.wait_stream(torch.cuda.current_stream(planes.device))
         with torch.cuda.stream(side):
@@ -151,11 +156,8 @@ class SemBEVGenerator(BEVGenerator):
             event = torch.cuda.Event()
             event.record(side)
         planes.record_stream(side)
-        out = [LazyBev(host, i, event, (r['trajs_present'], r['trajs_future'], r['trajs_full']), r.get('gt_lanes'))
-               for i, r in enumerate(results)]
-        import weakref
-        self._d2h_ring[slot] = (host, [weakref.ref(b) for b in out])
-        return out
+        return [LazyBev(host, i, event, (r['trajs_present'], r['trajs_future'], r['trajs_full']), r.get('gt_lanes'))
+                for i, r in enumerate(results)]
 
     @staticmethod
     def warp_planes_device(p16, a_1, a_2, b_1, b_2, out16=None):
