@@ -905,7 +905,7 @@ def main():
         'bev': 40.0 * stored + 21.0 * PX * PX * 4.0 + (48.0 * (stored - sizes[-1]) if k2_fused else 0.0),
     }
     bev_us = 1e3 * unit[0] / unit[1]                    # one event pair around the unit (see above)
-    bev_names = ('bev_bin', 'bev_scan', 'bev_scatter', 'bev_cells', 'bev_cells_heavy')
+    bev_names = ('bev_bin', 'bev_cells', 'bev_cells_heavy')
     bev_us_sum = sum(kern[k]['avg_us'] for k in bev_names if k in kern)
     units = {'kitti_project_sample_filter': kern['kitti_project_sample_filter']['avg_us'], 'bev': bev_us}
     if not k2_fused:

@@ -271,6 +271,8 @@ int pca_host_ego_to_grid(const double *full, int F, const double R[9], double dx
  * (ids PCA_K_KITTI .. PCA_K_DEDUP); on = 2: only whole multi-kernel units are (PCA_K_BEV_UNIT = one
  * pca_bev_generate call, launch gaps included, without the per-kernel events in between); 0: off.  pca_profile_read synchronises, returns the accumulated time / launch count of one
  * kernel id since the last pca_profile_enable(ctx, 1) and keeps recording.  (No reference counterpart.)
+ * PCA_K_BEV_SCAN / PCA_K_BEV_SCATTER are kept for the numbering only: level 1 of the rasteriser is one kernel
+ * (PCA_K_BEV_BIN) since round 2 and these two never record a launch.
  * ------------------------------------------------------------------------------------------------ */
 enum {
     PCA_K_KITTI = 0, PCA_K_NUSC, PCA_K_PROJECT_CAMS, PCA_K_RETRANSFORM, PCA_K_MARK_DYNAMIC,
