@@ -30,7 +30,7 @@
 #define C_THREADS 256             // workgroup size of the tile kernel
 #define RGB_CAP 4096              // colour records resident in LDS
 #define CONTIG_MIN 2560           // tiles above this many records are read thread-contiguously (runs form)
-#define HEAVY_MIN_DEFAULT 3072    // tiles above this many records go to bev_tile_cells_heavy (PCA_BEV_HEAVY_MIN; the
+#define HEAVY_MIN_DEFAULT 2560    // tiles above this many records go to bev_tile_cells_heavy (PCA_BEV_HEAVY_MIN; the
                                   // uniform benchmark's tiles hold ~2000, a dense tile costs the light kernel 4x its neighbours)
 #define FLAG_ROAD (1u << 24)
 #define FLAG_DYNOBJ (1u << 25)
