@@ -6,7 +6,16 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'pc-accumulation
 import numpy as np, builtins, bench
 rp = builtins.print
 builtins.print = lambda *a, **k: None
-r = bench.ring_model_pass(5)
+if os.environ.get('SCENE') == 'uniform':
+    import torch
+    acc, pool, _ = bench.make_accumulator(bench.synth_frame, 0)
+    st = bench.Stepper(acc, pool)
+    st.fill()
+    o = torch.empty((21, bench.PX, bench.PX), dtype=torch.float16, device='cuda')
+    for _ in range(5):
+        st.step(o)
+else:
+    r = bench.ring_model_pass(5)
 builtins.print = rp
 from pca_amd import _lib
 lib = _lib.Context.get().lib
