@@ -6,24 +6,40 @@ resident in HBM (the accumulators accept cuda tensors in place of numpy / PIL in
     for observations in loader:
         acc.integrate(observations)
 
-A reader thread does the part that has nothing to do with the GPU -- file reads, PNG decode, label remapping -- one or
-more batches ahead.  Everything that talks to HIP stays on the consumer's thread (measured: HIP calls from a second
+A small pool of reader threads (PCA_INGEST_THREADS, default 8; the decoders release the GIL) does the part that has
+nothing to do with the GPU -- file reads, PNG decode, label remapping -- up to `depth` batches ahead, delivered in
+order.  Everything that talks to HIP stays on the consumer's thread (measured: HIP calls from a second
 Python thread, even a lone event wait, cost the first one milliseconds per step): when batch k is handed out, batch k+1
 is copied into a ring of reused pinned buffers and its H2D copies are enqueued on a side stream, so they travel while
 the GPU works on batch k; the consumer's stream waits on the copy event, never on the host."""
+import collections
 import os
-import queue
-import threading
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
 
 class DeviceImage:
-    """An image that lives on the device for the kernels and on the host (numpy, pinned) for viz / PIL users."""
+    """An image that lives on the device for the kernels and on the host (numpy) for viz / PIL users.  Built from a decoded
+    array with its device copy already on the way, or -- images not wanted ahead of time (PCA_INGEST_IMAGES=0: the
+    ground-truth-semantics flow never looks at them) -- from the lazily opened file: decoded / uploaded on first use."""
 
-    def __init__(self, host, dev):
-        self.host, self.dev = host, dev
-        self.shape = host.shape
+    def __init__(self, host, dev, shape=None):
+        self._host, self._dev = host, dev
+        self.shape = tuple(shape) if shape is not None else tuple(host.shape)
+
+    @property
+    def host(self):
+        if not isinstance(self._host, np.ndarray):
+            self._host = np.asarray(self._host, dtype=np.uint8)
+        return self._host
+
+    @property
+    def dev(self):
+        if self._dev is None:
+            import torch
+            self._dev = torch.from_numpy(np.ascontiguousarray(self.host)).cuda()
+        return self._dev
 
     def __array__(self, dtype=None, copy=None):
         return self.host if dtype is None else self.host.astype(dtype)
@@ -56,6 +72,8 @@ class PrefetchingLoader:
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         # PCA_INGEST_SIDE_STREAM=1: copies on a stream of their own (overlap with kernels); default: the consumer's stream
         self.stream = torch.cuda.Stream(self.device) if os.environ.get('PCA_INGEST_SIDE_STREAM') else None
+        # PCA_INGEST_IMAGES=0: do not decode / upload images ahead (the ground-truth-semantics flow never reads them)
+        self.images = os.environ.get('PCA_INGEST_IMAGES', '1') != '0'
         self.lut = None
         if hasattr(loader, 'idx2idx'):
             self.lut = compose_label_lut(loader.idx2idx)
@@ -84,36 +102,45 @@ class PrefetchingLoader:
         self._ring_next += 1
         if slot['copied'] is not None:
             slot['copied'].synchronize()                                # long done: RING batches ago
-        host_img = img if isinstance(img, np.ndarray) and img.dtype == np.uint8 else np.asarray(img, dtype=np.uint8)
-        src = [('pc', np.ascontiguousarray(pc, dtype=np.float32)), ('img', np.ascontiguousarray(host_img)),
+        lazy_img = not isinstance(img, np.ndarray)           # images are not staged ahead: see DeviceImage
+        src = [('pc', np.ascontiguousarray(pc, dtype=np.float32)),
                ('sem', np.ascontiguousarray(np.asarray(sem_gt)[:, -1]).astype(np.uint8))]
-        dev = []
+        if not lazy_img:
+            src.append(('img', np.ascontiguousarray(img, dtype=np.uint8)))
+        dev = {}
         stream = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
         with torch.cuda.stream(stream):
             if slot['released'] is not None and self.stream is not None:
                 stream.wait_event(slot['released'])                     # kernels that read the device buffers are done
             for name, a in src:
-                t = torch.from_numpy(a)
-                pin, d = self._buffers(slot, name, a.shape, t.dtype)
-                pin.copy_(t)
+                pin, d = self._buffers(slot, name, a.shape, torch.from_numpy(a[:0]).dtype)
+                # numpy does the host copy: torch's CPU copy_ fans a 2 MB copy out over every core of the box and
+                # took 1-3 ms per call here
+                np.copyto(pin.numpy(), a)
                 d.copy_(pin, non_blocking=True)
-                dev.append(d)
+                dev[name] = d
             ev = torch.cuda.Event()
             ev.record(stream)
         slot['copied'] = ev
-        return (DeviceImage(host_img, dev[1]), dev[0], dev[2]), ev, slot
+        image = DeviceImage(img, None, shape=(img.size[1], img.size[0], 3)) if lazy_img else DeviceImage(src[2][1], dev['img'])
+        return (image, dev['pc'], dev['sem']), ev, slot
 
     def _read(self, idx):
         """read_obs with the label remap done through the composed table (identical result, one pass)."""
         ld = self.loader
         if self.lut is None or not hasattr(ld, 'pc_paths'):
-            return ld.read_obs(idx)
+            obs = ld.read_obs(idx)
+            if self.images and not isinstance(obs[0], np.ndarray):
+                obs = (np.asarray(obs[0], dtype=np.uint8), ) + tuple(obs[1:])   # decode on the reader thread
+            return obs
         import os
 
         import PIL.Image as Image
         from datasets.kitti360_utils import read_pc_bin_file, read_sem_gt_bin_file
         pc = read_pc_bin_file(os.path.join(ld.root_path, ld.pc_paths[idx]))
         img = Image.open(os.path.join(ld.root_path, ld.img_paths[idx]))
+        if self.images:
+            img = np.asarray(img, dtype=np.uint8)    # decode HERE, on the reader thread (Image.open is lazy)
         sem = read_sem_gt_bin_file(os.path.join(ld.root_path, ld.sem_gt_paths[idx]))
         if sem is None:
             sem = np.zeros((pc.shape[0], 1))
@@ -126,36 +153,31 @@ class PrefetchingLoader:
 
     def __iter__(self):
         import torch
-        q = queue.Queue(maxsize=self.depth)
         n, bs = len(self.loader), self.loader.batch_size
         torch.cuda.set_device(self.device)
+        # host-only work on the pool's threads: no HIP call there.  Batches are submitted in order and collected in order.
+        n_threads = int(os.environ.get('PCA_INGEST_THREADS', '8')) if os.environ.get('PCA_INGEST_THREAD', '1') != '0' else 0
+        pool = ThreadPoolExecutor(max_workers=n_threads) if n_threads > 0 else None
+        pending = collections.deque()
+        state = {'idx': 0}
 
-        def reader():                            # host-only work: no HIP call on this thread
-            try:
-                idx = 0
-                while idx + bs <= n:
-                    batch = [self._read(idx + k) for k in range(bs)]
-                    idx += bs
-                    q.put(batch)
-            except BaseException as e:           # surfaced in the consumer
-                q.put(e)
-            q.put(None)
-
-        use_thread = os.environ.get('PCA_INGEST_THREAD', '1') != '0'
-        if use_thread:
-            threading.Thread(target=reader, daemon=True).start()
-        inline = {'idx': 0}
+        def read_batch(i0):
+            return [self._read(i0 + k) for k in range(bs)]
 
         def stage():
-            if use_thread:
-                item = q.get()
-            elif inline['idx'] + bs <= n:
-                item = [self._read(inline['idx'] + k) for k in range(bs)]
-                inline['idx'] += bs
-            else:
-                item = None
-            if item is None or isinstance(item, BaseException):
-                return item
+            while state['idx'] + bs <= n and len(pending) < max(self.depth, 1):
+                i0 = state['idx']
+                state['idx'] += bs
+                pending.append(pool.submit(read_batch, i0) if pool is not None else i0)
+            if not pending:
+                if pool is not None:
+                    pool.shutdown(wait=False)
+                return None
+            head = pending.popleft()
+            try:
+                item = head.result() if pool is not None else read_batch(head)
+            except BaseException as e:           # surfaced in the consumer
+                return e
             return [self._to_device(obs) for obs in item]
 
         ahead = stage()

@@ -21,6 +21,8 @@ def main():
     for m in [m for m in sys.modules if m == 'datasets' or m.startswith('datasets.')]:
         del sys.modules[m]
     os.environ.setdefault('PCA_PREFETCH', '1')      # decode + upload ahead of the GPU (pca_amd/ingest.py); 0 disables
+    if '--use_gt_sem' in sys.argv:                  # the driver's flag: the images are never looked at
+        os.environ.setdefault('PCA_INGEST_IMAGES', '0')
     sys.argv = [script] + sys.argv[2:]
     runpy.run_path(script, run_name='__main__')
 
