@@ -26,6 +26,7 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         self.P_cam_frame = calib_params['p_cam_frame']
         self.P_velo_frame = calib_params['p_velo_frame']
         self._gpu_icp = None
+        self._uploader = None            # pinned staging of host-array observations (pca_amd.ingest.PinnedUploader)
         self._prev_sweep = None
         self.pose_provider = self._default_pose_provider()
 
@@ -85,28 +86,31 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         import torch
         dev = self.store.device
 
-        def up(a, dtype):
+        def up(a, dtype, kind):
             a = getattr(a, 'dev', a)             # pca_amd.ingest.DeviceImage
             if isinstance(a, torch.Tensor):
                 return a.to(device=dev, dtype=dtype).contiguous()
-            return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype_np[dtype])).to(dev)
+            if self._uploader is None:
+                from pca_amd.ingest import PinnedUploader
+                self._uploader = PinnedUploader(dev)
+            return self._uploader(kind, np.ascontiguousarray(a, dtype=dtype_np[dtype]))
 
         dtype_np = {torch.float32: np.float32, torch.uint8: np.uint8}
-        frame = {'pts': up(pc, torch.float32)}
+        frame = {'pts': up(pc, torch.float32, 'pts')}
         semseg = None
         if sem_gt is None:
             # (np.asarray: a PIL image is converted as the reference's np.array(rgb) does, an ndarray is not copied again)
             img = rgb if isinstance(rgb, torch.Tensor) or hasattr(rgb, 'dev') else np.asarray(rgb)
-            frame['rgb'] = up(img, torch.uint8)
+            frame['rgb'] = up(img, torch.uint8, 'rgb')
             # a model that works on the device gets the uploaded image: one H2D serves the CNN and K1, and its class map
             # (utils.onnx_utils.DeviceMap) goes to K1 without ever visiting the host
             feed = frame['rgb'] if getattr(self.semseg_model, 'accepts_device', False) else rgb
             semseg = self.semseg_model.pred(feed)[0, 0]
-            frame['sem'] = up(semseg, torch.uint8)
+            frame['sem'] = up(semseg, torch.uint8, 'sem')
             H, W = frame['sem'].shape
         else:
             sg = sem_gt if isinstance(sem_gt, torch.Tensor) else np.asarray(sem_gt)[:, -1]
-            frame['sem_gt'] = up(sg, torch.uint8)       # trainIds 0..18 and 255
+            frame['sem_gt'] = up(sg, torch.uint8, 'sem_gt')       # trainIds 0..18 and 255
             H = W = 1
         return frame, semseg, H, W
 

@@ -45,6 +45,39 @@ class DeviceImage:
         return self.host if dtype is None else self.host.astype(dtype)
 
 
+class PinnedUploader:
+    """Host array -> device tensor without a pageable copy: numpy copies the array into a reused pinned block (25 us for
+    2 MB) and the H2D copy is asynchronous.  torch's `.to(device)` of a pageable array is synchronous -- the host sits
+    in it until the stream's earlier kernels AND the copy are done, 0.2 ms of the unchanged driver's 0.42 ms step."""
+
+    DEPTH = 4
+
+    def __init__(self, device):
+        self.device = device
+        self._slots = {}                        # kind -> [next, [(pinned tensor, event)] * DEPTH]
+
+    def __call__(self, kind, a):
+        import torch
+        a = np.ascontiguousarray(a)
+        ring = self._slots.setdefault(kind, [0, [None] * self.DEPTH])
+        i = ring[0] % self.DEPTH
+        ring[0] += 1
+        slot = ring[1][i]
+        tdtype = torch.from_numpy(a.reshape(-1)[:0]).dtype
+        if slot is None or slot[0].numel() < a.size or slot[0].dtype != tdtype:
+            slot = (torch.empty(max(a.size, 1), dtype=tdtype, pin_memory=True), None)
+        elif slot[1] is not None:
+            slot[1].synchronize()                # the copy out of this block, DEPTH uploads ago: long done
+        pin = slot[0][:a.size].view(*a.shape)
+        np.copyto(pin.numpy(), a)
+        dev = torch.empty(a.shape, dtype=tdtype, device=self.device)
+        dev.copy_(pin, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring[1][i] = (slot[0], ev)
+        return dev
+
+
 def compose_label_lut(idx2idx, lo=-1, hi=255):
     """The reference remaps labels with a SEQUENCE of in-place masked assignments (conv_semantic_ids): a later pair
     sees the result of an earlier one.  Returns the composed table as an array indexed by (label - lo)."""

@@ -54,5 +54,5 @@ loop(100)
 pr.disable()
 builtins.print = real_print
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(30)
+pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45)
 sys.stdout.write(s.getvalue())
