@@ -711,7 +711,7 @@ def self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', choices=['config2', 'config5'], default='config2',
                     help='config2 = the per-frame step on one sequence per rank (headline, weak scaling); config5 = the nine '
