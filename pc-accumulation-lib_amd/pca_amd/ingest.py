@@ -45,6 +45,11 @@ class DeviceImage:
         return self.host if dtype is None else self.host.astype(dtype)
 
 
+def _torch_dtype(np_dtype):
+    import torch
+    return torch.from_numpy(np.empty(0, dtype=np_dtype)).dtype
+
+
 class PinnedUploader:
     """Host array -> device tensor without a pageable copy: numpy copies the array into a reused pinned block (25 us for
     2 MB) and the H2D copy is asynchronous.  torch's `.to(device)` of a pageable array is synchronous -- the host sits
@@ -63,7 +68,7 @@ class PinnedUploader:
         i = ring[0] % self.DEPTH
         ring[0] += 1
         slot = ring[1][i]
-        tdtype = torch.from_numpy(a.reshape(-1)[:0]).dtype
+        tdtype = _torch_dtype(a.dtype)
         if slot is None or slot[0].numel() < a.size or slot[0].dtype != tdtype:
             slot = (torch.empty(max(a.size, 1), dtype=tdtype, pin_memory=True), None)
         elif slot[1] is not None:
@@ -146,7 +151,7 @@ class PrefetchingLoader:
             if slot['released'] is not None and self.stream is not None:
                 stream.wait_event(slot['released'])                     # kernels that read the device buffers are done
             for name, a in src:
-                pin, d = self._buffers(slot, name, a.shape, torch.from_numpy(a[:0]).dtype)
+                pin, d = self._buffers(slot, name, a.shape, _torch_dtype(a.dtype))
                 # numpy does the host copy: torch's CPU copy_ fans a 2 MB copy out over every core of the box and
                 # took 1-3 ms per call here
                 np.copyto(pin.numpy(), a)

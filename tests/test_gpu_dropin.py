@@ -397,6 +397,36 @@ def test_prefetching_loader_and_async_writer(tmp_path, monkeypatch):
     assert np.array_equal(table[:47], conv_semantic_ids(ids.copy(), base.idx2idx)[:, 0])
 
 
+def test_prefetching_loader_order_and_reader_errors(tmp_path, monkeypatch):
+    """Eight reader threads deliver the frames in order; with PCA_INGEST_IMAGES=0 the image is decoded on first use only;
+    a reader's exception (a missing file) surfaces in the consumer at that frame."""
+    import torch
+    from fake_kitti import SEQ, write_tree
+
+    from obs_dataloaders.kitti360_obs_dataloader import Kitti360Dataloader
+    from pca_amd.ingest import DeviceImage, PrefetchingLoader
+    root = str(tmp_path / 'KITTI-360')
+    n_frames = 20
+    frames, _, _ = write_tree(root, first_idx=0, n_frames=n_frames, n_pts=500, H=16, W=24)
+    monkeypatch.setenv('PCA_INGEST_THREADS', '8')
+    for images in ('1', '0'):
+        monkeypatch.setenv('PCA_INGEST_IMAGES', images)
+        k = 0
+        for obs in PrefetchingLoader(Kitti360Dataloader(root, 1, [SEQ], [0], [n_frames]), depth=6):
+            img, pc, sem = obs[0]                 # device buffers belong to a ring: look at a batch while it is current
+            assert isinstance(img, DeviceImage) and isinstance(pc, torch.Tensor) and pc.is_cuda
+            assert np.array_equal(pc.cpu().numpy(), frames[k][0])
+            assert np.array_equal(np.asarray(img), frames[k][1]) and np.array_equal(img.dev.cpu().numpy(), frames[k][1])
+            k += 1
+        assert k == n_frames
+    os.remove(os.path.join(root, 'data_3d_raw', SEQ, 'velodyne_points', 'data', f'{7:010d}.bin'))
+    seen = 0
+    with pytest.raises((FileNotFoundError, OSError)):
+        for obs in PrefetchingLoader(Kitti360Dataloader(root, 1, [SEQ], [0], [n_frames]), depth=6):
+            seen += 1
+    assert seen == 7
+
+
 def test_kitti_accumulator_voxel_dedup_option(golden):
     """Opt-in extension: acc.voxel_dedup = size de-duplicates the buffer after every integrate().  Model: the same
     sequence WITHOUT the option gives every point's coordinates (transforms are per point, so survivors are bitwise
