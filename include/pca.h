@@ -237,6 +237,20 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
                         void *workspace /*dev*/, int64_t workspace_bytes, double *planes /*dev*/,
                         uint16_t *planes_f16 /*dev*/, double *extra_planes /*dev, may be NULL*/, void *stream);
 
+/* The same with a CHAIN of owed re-transforms (sem_pc_accum.py:167-183 issues one per integrate): transform k (4x4 row-major
+ * in pending_Ts[16 k ..], oldest first) is owed by slots [slot_begin, pending_slot_ends[k]) (ascending).  The rasteriser
+ * applies them one after the other to the coordinates it reads -- the roundings of one pca_retransform pass each -- and,
+ * with write_back != 0, stores the result (the transforms are then no longer owed); with write_back == 0 they stay owed
+ * and the store is untouched: the caller passes them again, together with the next one, and saves the 24 B per stored
+ * point of the write-back on that call.  n_pending <= PCA_BEV_MAX_CHAIN. */
+#define PCA_BEV_MAX_CHAIN 4
+int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *intensity64,
+                           const int64_t *frame_off /*dev*/, int slot_begin, int slot_split, int slot_end,
+                           int64_t max_points, const pca_bev_params *prm, const double *pending_Ts,
+                           const int *pending_slot_ends, int n_pending, int write_back, void *workspace /*dev*/,
+                           int64_t workspace_bytes, double *planes /*dev*/, uint16_t *planes_f16 /*dev*/,
+                           double *extra_planes /*dev, may be NULL*/, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Input normalisation of the semseg CNN on the device.  Replaces utils/onnx_utils.py:26-29, :35-36
  *     (torchvision ToTensor + Normalize on the host): out[c][y][x] = (rgb[y][x][c] / 255 - mean[c]) / std[c] in IEEE f32.

@@ -50,8 +50,10 @@ struct BevArgs {
     int slot_begin, slot_split, slot_end;
     int64_t max_points;
     pca_bev_params prm;
-    Mat34 pend_T;         // owed re-transform of slots [slot_begin, pend_slot_end), fused into the hist kernel
-    int pend_slot_end;    // <= slot_begin: none
+    int n_pend;           // owed re-transforms, oldest first: transform k is owed by slots [slot_begin, pend_slot_end[k])
+    int write_back;       // apply them to the store (else to this raster only: they stay owed)
+    int pend_slot_end[PCA_BEV_MAX_CHAIN];   // ascending
+    Mat34 pend_T[PCA_BEV_MAX_CHAIN];
     int tx, T, G;
     int tile_mult;        // bev_tile_cells: workgroup -> tile permutation (coprime to T)
     int heavy_min;        // tiles with more records than this are bev_tile_cells_heavy's (<= RGB_CAP)
@@ -104,16 +106,22 @@ __device__ __forceinline__ Window chunk_of(const BevArgs &a)
 // ---------------------------------------------------------------------------------------------
 // One point of pass A: owed re-transform (returns the stored coordinates), BEV-frame key.  KEY_INVALID = not in the view.
 struct BinPoint { double x, y, z; uint32_t key; };
-__device__ __forceinline__ BinPoint bin_point(const BevArgs &a, const Window &w, int64_t pend_hi, int64_t p, double X, double Y, double Z,
-                                              uint8_t D)
+struct PendHi { int64_t v[PCA_BEV_MAX_CHAIN]; };           // first point index that does NOT owe transform k
+__device__ __forceinline__ BinPoint bin_point(const BevArgs &a, const Window &w, const PendHi &pend_hi, int64_t p, double X, double Y,
+                                              double Z, uint8_t D)
 {
     const pca_bev_params &q = a.prm;
     BinPoint r;
-    if (p < pend_hi) {
-        const double nx = row4(a.pend_T.m + 0, X, Y, Z), ny = row4(a.pend_T.m + 4, X, Y, Z), nz = row4(a.pend_T.m + 8, X, Y, Z);
-        X = nx; Y = ny; Z = nz;
-        a.st.x[p] = nx; a.st.y[p] = ny; a.st.z[p] = nz;
-    }
+    // the owed re-transforms, oldest first, each a separate fma chain (the roundings of one K2 pass per transform)
+    bool moved = false;
+#pragma unroll
+    for (int k = 0; k < PCA_BEV_MAX_CHAIN; ++k)
+        if (k < a.n_pend && p < pend_hi.v[k]) {
+            const double nx = row4(a.pend_T[k].m + 0, X, Y, Z), ny = row4(a.pend_T[k].m + 4, X, Y, Z), nz = row4(a.pend_T[k].m + 8, X, Y, Z);
+            X = nx; Y = ny; Z = nz;
+            moved = true;
+        }
+    if (moved && a.write_back) { a.st.x[p] = X; a.st.y[p] = Y; a.st.z[p] = Z; }
     r.x = X; r.y = Y; r.z = Z;
     const double v = q.view, vlo = -0.5 * v, vhi = 0.5 * v, pxd = (double)q.px, half_px = 0.5 * pxd;
     const bool use_h = !(q.height_filter != q.height_filter);
@@ -184,7 +192,10 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_bin(const BevArgs a)
     }
     for (int t = threadIdx.x; t < a.T; t += AB_THREADS) s_h[t] = 0;
     __syncthreads();
-    const int64_t pend_hi = a.pend_slot_end > a.slot_begin ? a.frame_off[a.pend_slot_end] : w.lo;
+    PendHi pend_hi;
+#pragma unroll
+    for (int k = 0; k < PCA_BEV_MAX_CHAIN; ++k)
+        pend_hi.v[k] = (k < a.n_pend && a.pend_slot_end[k] > a.slot_begin) ? a.frame_off[a.pend_slot_end[k]] : w.lo;
     const int64_t reg_hi = w.c_lo + (int64_t)REG_P * AB_THREADS < w.c_hi ? w.c_lo + (int64_t)REG_P * AB_THREADS : w.c_hi;
     // ---- pass A, register part ----
     uint32_t rkey[REG_P > 0 ? REG_P : 1], rrgb[REG_P > 0 ? REG_P : 1];
@@ -1057,7 +1068,23 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
                         const double *pending_T, int pending_slot_end, void *workspace, int64_t workspace_bytes,
                         double *planes, uint16_t *planes_f16, double *extra_planes, void *stream)
 {
+    const int n = (pending_T && pending_slot_end > slot_begin) ? 1 : 0;
+    return pca_bev_generate_chain(ctx, store, intensity64, frame_off, slot_begin, slot_split, slot_end, max_points, prm,
+                                  pending_T, &pending_slot_end, n, 1, workspace, workspace_bytes, planes, planes_f16,
+                                  extra_planes, stream);
+}
+
+int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *intensity64, const int64_t *frame_off,
+                           int slot_begin, int slot_split, int slot_end, int64_t max_points, const pca_bev_params *prm,
+                           const double *pending_Ts, const int *pending_slot_ends, int n_pending, int write_back,
+                           void *workspace, int64_t workspace_bytes, double *planes, uint16_t *planes_f16,
+                           double *extra_planes, void *stream)
+{
     if (!ctx) return -1;
+    if (n_pending < 0 || n_pending > PCA_BEV_MAX_CHAIN || (n_pending > 0 && (!pending_Ts || !pending_slot_ends))) {
+        ctx->err = "bev: bad chain of owed transforms";
+        return -1;
+    }
     if (!store || !frame_off || !prm || !workspace || (!planes && !planes_f16)) { ctx->err = "bev: bad arguments"; return -1; }
     if (prm->px < 1 || prm->px > 1024) { ctx->err = "bev: px must be in 1..1024"; return -1; }
     // the elevation plane is min(z - origin_z): the rotation has to leave z alone (rotation_matrix_3d of the reference)
@@ -1078,12 +1105,16 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
     a.slot_begin = slot_begin; a.slot_split = slot_split; a.slot_end = slot_end;
     a.max_points = max_points;
     a.prm = *prm;
-    a.pend_slot_end = slot_begin;
-    for (int i = 0; i < 12; ++i) a.pend_T.m[i] = 0.0;
-    if (pending_T && pending_slot_end > slot_begin) {
-        if (pending_slot_end > slot_end) { ctx->err = "bev: pending_slot_end beyond the window"; return -1; }
-        a.pend_slot_end = pending_slot_end;
-        for (int i = 0; i < 12; ++i) a.pend_T.m[i] = pending_T[i];
+    a.n_pend = n_pending;
+    a.write_back = write_back ? 1 : 0;
+    for (int k = 0; k < PCA_BEV_MAX_CHAIN; ++k) {
+        a.pend_slot_end[k] = slot_begin;
+        for (int i = 0; i < 12; ++i) a.pend_T[k].m[i] = 0.0;
+        if (k >= n_pending) continue;
+        if (pending_slot_ends[k] > slot_end) { ctx->err = "bev: a pending slot end lies beyond the window"; return -1; }
+        if (k > 0 && pending_slot_ends[k] < pending_slot_ends[k - 1]) { ctx->err = "bev: pending slot ends must ascend"; return -1; }
+        a.pend_slot_end[k] = pending_slot_ends[k];
+        for (int i = 0; i < 12; ++i) a.pend_T[k].m[i] = pending_Ts[16 * k + i];
     }
     a.tx = tiles_x(prm->px);
     a.T = a.tx * a.tx;

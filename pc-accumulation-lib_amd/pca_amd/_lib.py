@@ -20,7 +20,7 @@ EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error',
            'pca_kitti_project_sample_filter', 'pca_kitti_project_sample_filter_ex',
            'pca_nusc_sample_filter_transform', 'pca_nusc_sample_filter_transform_ex', 'pca_sample_bilinear', 'pca_nusc_project_cams', 'pca_retransform', 'pca_retransform_batch_tail',
            'pca_mark_dynamic',
-           'pca_bev_workspace_bytes', 'pca_bev_generate', 'pca_bev_generate_ex', 'pca_bev_warp', 'pca_image_to_nchw_f32', 'pca_voxel_dedup_workspace_bytes', 'pca_voxel_dedup', 'pca_icp_workspace_bytes', 'pca_icp_register', 'pca_host_ego_to_grid',
+           'pca_bev_workspace_bytes', 'pca_bev_generate', 'pca_bev_generate_ex', 'pca_bev_generate_chain', 'pca_bev_warp', 'pca_image_to_nchw_f32', 'pca_voxel_dedup_workspace_bytes', 'pca_voxel_dedup', 'pca_icp_workspace_bytes', 'pca_icp_register', 'pca_host_ego_to_grid',
            'pca_profile_enable', 'pca_profile_read')
 
 KERNEL_IDS = ('kitti_project_sample_filter', 'nusc_sample_filter_transform', 'nusc_project_cams', 'retransform',
@@ -117,6 +117,8 @@ def load():
         vp, i64, vp, vp, vp, vp
     ]
     lib.pca_image_to_nchw_f32.argtypes = [vp, vp, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp]
+    a = list(lib.pca_bev_generate_ex.argtypes)
+    lib.pca_bev_generate_chain.argtypes = a[:9] + [vp, vp, i32, i32] + a[11:]
     lib.pca_bev_warp.argtypes = [vp, vp, vp, i32, i32, C.c_double, C.c_double, C.c_double, C.c_double, vp]
     lib.pca_voxel_dedup_workspace_bytes.restype = C.c_int64
     lib.pca_voxel_dedup_workspace_bytes.argtypes = [i64, i32]

@@ -9,6 +9,7 @@ Slots: frame k of the live window occupies slot ``head + k``; eviction advances 
 capacity run out the live window is moved to the front (rare, amortised).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -18,6 +19,8 @@ from ._lib import PcaBevParams, PcaKittiFrame, PcaStore
 
 
 class DeviceStore:
+    CHAIN_MAX = 4            # owed re-transforms at most (PCA_BEV_MAX_CHAIN of the C ABI)
+    CHAIN_K = int(os.environ.get('PCA_BEV_CHAIN', '4'))   # the rasteriser writes them back when this many are owed
 
     def __init__(self, capacity=1 << 24, max_frames=4096, device=None, intensity_div255=False):
         self.ctx = _lib.Context.get(device)
@@ -32,7 +35,7 @@ class DeviceStore:
         self.lb_head = 0         # lower bound of frame_off[head] (exact after a sync)
         self._ub = []            # per live frame: upper bound of its size (its input point count)
         self._ub_sum = 0         # sum(self._ub), kept incrementally
-        self._pending = None     # (T 4x4, end slot): a re-transform owed to slots [head, end slot)
+        self._pending = []       # [(T 16 doubles, end slot)], oldest first: re-transforms owed to slots [head, end slot)
         self._k1_cache = None
         self._ws = None
         self._ws_points, self._ws_px = 0, 0
@@ -129,7 +132,7 @@ class DeviceStore:
         self.ub_tail = self.lb_head = 0
         self._ub = []
         self._ub_sum = 0
-        self._pending = None
+        self._pending = []
         self.frame_off.zero_()
 
     # ---- K1: KITTI ------------------------------------------------------------------------
@@ -193,20 +196,24 @@ class DeviceStore:
         """Applies the 4x4 transform(s) to every live point, in order (Ts: (4,4) or (k,4,4)).
         defer=True (single transform): the transform is only recorded; it is applied by the next consumer
         of the coordinates -- fused into the BEV rasteriser's first pass if that comes next (it reads every
-        coordinate anyway), otherwise by a K2 launch (`flush_pending`).  Results are bit-identical."""
+        coordinate anyway), otherwise by a K2 launch (`flush_pending`).  Up to CHAIN_MAX transforms may be owed at a
+        time: the rasteriser applies all of them to what it reads and writes the result back only every CHAIN_K-th time
+        (the write-back is 24 B per stored point).  Results are bit-identical either way: one fma chain per transform."""
         if self.n_frames == 0:
             return
-        self.flush_pending()
         Ts = np.ascontiguousarray(Ts, dtype=np.float64).reshape(-1, 16)
         if defer and Ts.shape[0] == 1:
-            self._pending = (Ts[0].copy(), self.tail)
+            if len(self._pending) >= self.CHAIN_MAX:
+                self.flush_pending()
+            self._pending.append((Ts[0].copy(), self.tail))
             return
-        self._launch_retransform(Ts, self.tail)
+        self.flush_pending()
+        self._launch_retransform(Ts, self.head, self.tail)
 
-    def _launch_retransform(self, Ts, end_slot):
+    def _launch_retransform(self, Ts, begin_slot, end_slot):
         st = self.c_store()
         ctx = self.ctx
-        ctx.check(ctx.lib.pca_retransform(ctx.h, C.byref(st), self.frame_off.data_ptr(), self.head, end_slot,
+        ctx.check(ctx.lib.pca_retransform(ctx.h, C.byref(st), self.frame_off.data_ptr(), begin_slot, end_slot,
                                           _lib.f64_array(Ts, Ts.size), Ts.shape[0], ctx.stream()))
 
     def retransform_batch(self, Ts, n_new):
@@ -226,11 +233,14 @@ class DeviceStore:
                                                      _lib.f64_array(Ts, Ts.size), ctx.stream()))
 
     def flush_pending(self):
-        if self._pending is not None:
-            T, end_slot = self._pending
-            self._pending = None
-            if end_slot > self.head:
-                self._launch_retransform(T.reshape(1, 16), end_slot)
+        """Applies the owed transforms with K2: the slots between two consecutive end slots owe the same transforms (all
+        the later ones), so every stored point is touched once."""
+        pend, self._pending = self._pending, []
+        begin = self.head
+        for k, (_, end_slot) in enumerate(pend):
+            if end_slot > begin:
+                self._launch_retransform(np.stack([T for T, _ in pend[k:]]), begin, end_slot)
+                begin = end_slot
 
     def mark_dynamic(self, pairs):
         """pairs: iterable of (frame index in the live window, instance index)."""
@@ -281,23 +291,29 @@ class DeviceStore:
         p16 = out16 if out16 is not None else torch.empty((21, px, px), dtype=torch.float16, device=self.device)
         p64 = torch.empty((21, px, px), dtype=torch.float64, device=self.device) if want_f64 else None
         st = self.c_store()
-        pend_T, pend_end = None, 0
-        if self._pending is not None:
-            if first_frame == 0 and self._pending[1] <= self.head + last_frame:
-                pend_T, pend_end = _lib.f64_array(self._pending[0], 16), self._pending[1]
+        # the owed re-transforms ride along (oldest first); they are written back only when CHAIN_K of them are owed
+        n_pend, pend_T, pend_ends, write_back = 0, None, None, 1
+        if self._pending:
+            if first_frame == 0 and self._pending[-1][1] <= self.head + last_frame:
+                live = [(T, e) for T, e in self._pending if e > self.head]
+                n_pend = len(live)
+                if n_pend:
+                    pend_T = _lib.f64_array(np.concatenate([T for T, _ in live]), 16 * n_pend)
+                    pend_ends = (C.c_int * n_pend)(*[int(e) for _, e in live])
+                write_back = 1 if n_pend >= self.CHAIN_K else 0
             else:
                 self.flush_pending()
         if extra is not None:
             assert extra.dtype == torch.float64 and extra.is_contiguous() \
                 and tuple(extra.shape) == (3, len(_lib.BEV_EXTRA_PLANES), px, px)
-        ctx.check(lib.pca_bev_generate_ex(ctx.h, C.byref(st), None if intensity64 is None else intensity64.data_ptr(),
-                                          self.frame_off.data_ptr(), self.head + first_frame, self.head + split_frame,
-                                          self.head + last_frame, max_points, C.byref(prm), pend_T, pend_end,
-                                          self._ws.data_ptr(), self._ws.numel(),
-                                          None if p64 is None else p64.data_ptr(), p16.data_ptr(),
-                                          None if extra is None else extra.data_ptr(), ctx.stream()))
-        if pend_T is not None:
-            self._pending = None               # only now: a failed call above leaves the owed re-transform owed
+        ctx.check(lib.pca_bev_generate_chain(ctx.h, C.byref(st), None if intensity64 is None else intensity64.data_ptr(),
+                                             self.frame_off.data_ptr(), self.head + first_frame, self.head + split_frame,
+                                             self.head + last_frame, max_points, C.byref(prm), pend_T, pend_ends, n_pend,
+                                             write_back, self._ws.data_ptr(), self._ws.numel(),
+                                             None if p64 is None else p64.data_ptr(), p16.data_ptr(),
+                                             None if extra is None else extra.data_ptr(), ctx.stream()))
+        if self._pending and write_back:
+            self._pending = []                 # only now: a failed call above leaves the owed re-transforms owed
         return p16, p64
 
     # ---- host views (synchronise) -----------------------------------------------------------
