@@ -815,3 +815,51 @@ def test_k1n_bilinear_mode_matches_oracle(T, orc):
     finally:
         orc.set_sample_mode(0)
     assert np.array_equal(st.rows(0), ost.rows()) and ost.n > 1000
+
+
+def test_bev_chain_of_owed_transforms_equals_eager_retransform(T):
+    """Up to four re-transforms stay owed: the rasteriser applies them to what it reads and writes back every fourth
+    time (pca_bev_generate_chain).  Planes and stored coordinates equal those of a store that re-transforms eagerly --
+    with frames appended and evicted in between, a BEV missing now and then (the chain fills up and is flushed by K2)
+    and the rows read back mid-chain (flush of a partial chain)."""
+    from pca_amd.device_store import DeviceStore, make_bev_params
+    rng = np.random.default_rng(123)
+
+    def frame(n):
+        rows = np.zeros((n, 10))
+        rows[:, 0:2] = rng.uniform(-40, 40, (n, 2))
+        rows[:, 2] = rng.uniform(-2, 2, n)
+        rows[:, 3] = rng.integers(0, 256, n)
+        rows[:, 4:7] = rng.integers(0, 256, (n, 3))
+        rows[:, 7] = rng.integers(0, 19, n)
+        rows[:, 9] = rng.integers(0, 2, n)
+        return rows
+    lazy, eager = DeviceStore(capacity=1 << 18, max_frames=32), DeviceStore(capacity=1 << 18, max_frames=32)
+    lazy.CHAIN_K, eager.CHAIN_K = 4, 1
+    assert lazy.load_rows([frame(6000) for _ in range(3)]) is None
+    assert eager.load_rows(lazy.frame_rows()) is None
+    prm = make_bev_params(np.zeros(3), np.eye(3), 0., 0., 80., 128, None, 20., 20., 0.5, 0, [13, 14, 15, 17], False, 0)
+    for step in range(14):
+        a = 0.01 * (step + 1)
+        Tm = np.eye(4)
+        Tm[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        Tm[0, 3], Tm[1, 3] = 0.9, -0.05 * step
+        n_new = 5000 + 100 * step                          # a new frame through K1's ground-truth-semantics branch
+        host = rng.uniform(-40, 40, (n_new, 4)).astype(np.float32)
+        host[:, 3] = rng.integers(0, 256, n_new)
+        pts = T.from_numpy(host).cuda()
+        sem = T.from_numpy(rng.integers(0, 19, n_new).astype(np.uint8)).cuda()
+        for st in (lazy, eager):
+            st.retransform(Tm, defer=True)
+            st.append_kitti([dict(pts=pts, sem_gt=sem)], np.eye(3, 4), 1, 1, [])
+        if step in (5, 9):
+            for st in (lazy, eager):
+                st.evict(1)
+        if step % 5 != 3:                                  # no BEV on steps 3, 8, 13: the chain grows past the write-back point
+            pl, pe = lazy.bev(lazy.n_frames // 2, prm)[0], eager.bev(eager.n_frames // 2, prm)[0]
+            assert T.equal(pl.view(T.int16), pe.view(T.int16)), step
+        if step == 6:                                      # mid-chain read-back
+            assert np.array_equal(lazy.rows(), eager.rows())
+    assert np.array_equal(lazy.rows(), eager.rows())
+    lazy.check_status()
+    eager.check_status()
