@@ -19,6 +19,10 @@ from ._lib import PcaBevParams, PcaKittiFrame, PcaStore
 
 
 class DeviceStore:
+    """The accumulated points in HBM (SoA) with the host-side bookkeeping of slots and owed re-transforms.
+    NOTE: the coordinate tensors x / y / z lag behind by the re-transforms in `_pending` (up to CHAIN_MAX of them);
+    every method of this class that reads coordinates applies them first.  Code that reads the tensors directly calls
+    `flush_pending()` before."""
     CHAIN_MAX = 4            # owed re-transforms at most (PCA_BEV_MAX_CHAIN of the C ABI)
     CHAIN_K = int(os.environ.get('PCA_BEV_CHAIN', '4'))   # the rasteriser writes them back when this many are owed
 
