@@ -212,8 +212,12 @@ class BEVGenerator(ABC):
             pc = pc[pc[:, 2] < self.height_filter]
         return self.pos2grid(pc, aug_view_size), out_trajs
 
-    def generate_rand_aug(self, pcs: dict, trajs: dict, do_warping: bool = True, device_only: bool = False, out=None):
-        np.random.seed((os.getpid() * int(time.time())) % 123456789)
+    def generate_rand_aug(self, pcs: dict, trajs: dict, do_warping: bool = True, device_only: bool = False, out=None,
+                          worker: int = 0):
+        # The reference seeds from pid * time (bev_generator.py:168) and draws each of the bev_num samples in its own
+        # Pool worker, i.e. under its own pid.  Here the samples of one window are drawn in ONE process: `worker` (the
+        # sample's number in the batch) stands in for the worker's pid offset, so that the samples differ.
+        np.random.seed(((os.getpid() + int(worker)) * int(time.time())) % 123456789)
         rot_ang = 2 * np.pi * np.random.random()
         trans_r = self.max_trans_radius * np.random.random()
         trans_ang = 2 * np.pi * np.random.random()
@@ -223,10 +227,10 @@ class BEVGenerator(ABC):
         zoom_scalar = 1 + min(max(zoom_scalar, -self.zoom_thresh), self.zoom_thresh)
         return self.generate(pcs, trajs, rot_ang, trans_dx, trans_dy, zoom_scalar, do_warping, device_only, out)
 
-    def generate_multiproc(self, bev_gen_inputs, device_only: bool = False, out=None):
+    def generate_multiproc(self, bev_gen_inputs, device_only: bool = False, out=None, worker: int = 0):
         pcs, trajs = bev_gen_inputs
         if self.do_aug:
-            return self.generate_rand_aug(pcs, trajs, device_only=device_only, out=out)
+            return self.generate_rand_aug(pcs, trajs, device_only=device_only, out=out, worker=worker)
         return self.generate(pcs, trajs, device_only=device_only, out=out)
 
     def generate_rand_aug_multiproc(self, bev_gen_inputs):

@@ -158,6 +158,7 @@ void pca_ctx_destroy(pca_ctx *ctx)
         if (ctx->k1_pin_ev[i]) (void)hipEventDestroy(ctx->k1_pin_ev[i]);
     }
     if (ctx->k1_frames_dev) (void)hipFree(ctx->k1_frames_dev);
+    if (ctx->k1_tiny) (void)hipFree(ctx->k1_tiny);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     if (ctx->heavy_hint) (void)hipHostFree(ctx->heavy_hint);
     prof_fold(ctx);

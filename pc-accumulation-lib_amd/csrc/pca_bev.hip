@@ -107,12 +107,10 @@ __device__ __forceinline__ Window chunk_of(const BevArgs &a)
 // One point of pass A: owed re-transform (returns the stored coordinates), BEV-frame key.  KEY_INVALID = not in the view.
 struct BinPoint { double x, y, z; uint32_t key; };
 struct PendHi { int64_t v[PCA_BEV_MAX_CHAIN]; };           // first point index that does NOT owe transform k
-__device__ __forceinline__ BinPoint bin_point(const BevArgs &a, const Window &w, const PendHi &pend_hi, int64_t p, double X, double Y,
-                                              double Z, uint8_t D)
+// the owed re-transforms of point p, oldest first, each a separate fma chain (the roundings of one K2 pass per
+// transform); returns whether the point owed any
+__device__ __forceinline__ bool apply_owed(const BevArgs &a, const PendHi &pend_hi, int64_t p, double &X, double &Y, double &Z)
 {
-    const pca_bev_params &q = a.prm;
-    BinPoint r;
-    // the owed re-transforms, oldest first, each a separate fma chain (the roundings of one K2 pass per transform)
     bool moved = false;
 #pragma unroll
     for (int k = 0; k < PCA_BEV_MAX_CHAIN; ++k)
@@ -121,6 +119,14 @@ __device__ __forceinline__ BinPoint bin_point(const BevArgs &a, const Window &w,
             X = nx; Y = ny; Z = nz;
             moved = true;
         }
+    return moved;
+}
+__device__ __forceinline__ BinPoint bin_point(const BevArgs &a, const Window &w, const PendHi &pend_hi, int64_t p, double X, double Y,
+                                              double Z, uint8_t D)
+{
+    const pca_bev_params &q = a.prm;
+    BinPoint r;
+    const bool moved = apply_owed(a, pend_hi, p, X, Y, Z);
     if (moved && a.write_back) { a.st.x[p] = X; a.st.y[p] = Y; a.st.z[p] = Z; }
     r.x = X; r.y = Y; r.z = Z;
     const double v = q.view, vlo = -0.5 * v, vhi = 0.5 * v, pxd = (double)q.px, half_px = 0.5 * pxd;
@@ -285,6 +291,7 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_bin(const BevArgs a)
         const uint32_t pos = seg + atomicAdd(&s_cur[rkey[j] >> 7], 1u);
         bin_store<I64>(a, pos, rkey[j], rrgb[j], rz[j], (double)rinten[j]);
     }
+    const bool stale = a.n_pend > 0 && !a.write_back;
     for (int64_t base = reg_hi + threadIdx.x; base < w.c_hi; base += UNR * AB_THREADS) {
         uint32_t key[UNR], pos[UNR], rgbs[UNR];
         double zz[UNR], iv[UNR];
@@ -299,6 +306,10 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_bin(const BevArgs a)
             const bool ok = key[u] != KEY_INVALID;
             rgbs[u] = ok ? a.st.rgbs[p] : 0u;
             zz[u] = ok ? a.st.z[p] : 0.0;
+            if (ok && stale) {                              // transforms still owed and not written back by pass A:
+                double X = a.st.x[p], Y = a.st.y[p];        // the store holds the coordinates from before them
+                apply_owed(a, pend_hi, p, X, Y, zz[u]);
+            }
             if (I64) iv[u] = ok ? a.intensity64[p] : 0.0;
             else iv[u] = ok ? (double)a.st.intensity[p] : 0.0;
             pos[u] = ok ? seg + atomicAdd(&s_cur[key[u] >> 7], 1u) : 0u;
@@ -1032,14 +1043,12 @@ static inline int64_t align256(int64_t v) { return (v + 255) & ~255ll; }
 static inline int tiles_x(int px) { return (px + TS - 1) / TS; }
 static inline int n_groups(int64_t max_points)
 {
-    static int max_g = 0, per_g = 0;
-    if (!max_g) {                                           // PCA_BEV_G / PCA_BEV_CHUNK: tuning overrides
-        const char *e = getenv("PCA_BEV_G"), *c = getenv("PCA_BEV_CHUNK");
-        max_g = e ? atoi(e) : MAX_G;
-        per_g = c ? atoi(c) : 8192;
-        if (max_g < 1 || max_g > 1024) max_g = MAX_G;
-        if (per_g < 1024) per_g = 8192;
-    }
+    // PCA_BEV_G / PCA_BEV_CHUNK: tuning overrides, read on every call (tests switch them to force the memory path)
+    const char *e = getenv("PCA_BEV_G"), *c = getenv("PCA_BEV_CHUNK");
+    int max_g = e ? atoi(e) : MAX_G;
+    int per_g = c ? atoi(c) : 8192;
+    if (max_g < 1 || max_g > 1024) max_g = MAX_G;
+    if (per_g < 1024) per_g = 8192;
     int64_t g = (max_points + per_g - 1) / per_g;
     return (int)(g < 1 ? 1 : (g > max_g ? max_g : g));
 }

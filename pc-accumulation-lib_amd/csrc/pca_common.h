@@ -34,6 +34,8 @@ struct pca_ctx {
     uint32_t epoch = 0;               // 22-bit launch tag of tile_state entries
     void *k1_frames_dev = nullptr;    // dev: K1's frame descriptors of a batched launch
     int64_t k1_frames_cap = 0;        // bytes
+    void *k1_tiny = nullptr;          // dev: 4-byte copies of images smaller than the 4-byte colour gather
+    int64_t k1_tiny_cap = 0;
     void *k1_ws[2] = {nullptr, nullptr};   // dev: counts / kept records of K1's split form, one per sub-batch in flight
     int64_t k1_ws_cap[2] = {0, 0};         // bytes
     K1Frame *k1_pin[2] = {nullptr, nullptr};   // pinned staging of the descriptors, alternating between calls

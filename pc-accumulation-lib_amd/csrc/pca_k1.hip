@@ -2,31 +2,38 @@
 //   fused  velo2frame -> velo2img (frustum mask) -> nearest sample of semseg + RGB -> class filter -> stable append
 //   (sem_pc_accum.py:317-402, kitti360_sem_pc_accum.py:132-156 of the reference), one launch for a batch of frames.
 //
-// What bounds it (measured): per frame the kernel moves 1.9 MB of points, the ~2 MB of image lines its
-// 35 k gathers touch and 1 MB of kept records; it does ~30 f64 operations for the 29 % of the points that fall into
-// the frustum.  So the design is about (1) not fetching an image into eight L2s, (2) not spending vector issue slots
-// on the 71 % of the points that are outside the frustum, (3) enough independent workgroups in flight to cover the
-// chain  ticket -> points -> gathers -> look-back -> stores.
+// What bounds it (measured): per frame the kernel moves 1.9 MB of points, the image lines its ~60 k gathers
+// touch and 1 MB of kept records; it does ~30 f64 operations for the 29 % of the points that fall into the frustum.
+// On scattered points the batch form is bound by its GATHERS, not by HBM: a wave-wide gather pulls 64 distinct lines
+// through the CU's L1 for 64 x (1 or 4) useful bytes (with every gather at pixel 0 the front kernel runs in 31 us instead
+// of 57; without phase 2 at all in 23 us = 5.3 TB/s).  So the design is about (1) not fetching an image into eight L2s,
+// (2) not spending vector issue slots on the 71 % of the points that are outside the frustum, (3) as few gathered lines
+// as the reference's semantics allow, (4) enough independent workgroups in flight to cover the chain
+// descriptor -> points -> class gather -> colour gather -> stores, with every link a single round trip.
 //
 //   * one workgroup = one tile of BLK*PPT consecutive points of one frame.
 //   * phase 1 (every point): 16-byte load, f32 estimate of the three projection rows with a certified error bound,
 //     conservative frustum test -> candidates (a superset of the in-frustum points), compacted into an LDS list.
 //   * phase 2 (candidates only, dense lanes): the exact f64 path -- fma chain, IEEE divide, rint, 6-way mask -- two
 //     gathers (class byte, one unaligned dword for r,g,b), 256-bit class filter from LDS.  The rounds of a tile are
-//     software-pipelined: all point re-loads, then all projections and gathers, then all filters.
+//     software-pipelined: all point re-loads, then all projections and gathers, then all filters; no sweep consumes what
+//     it gathers, so the gathers of all rounds of a wave are in flight together.  Batches gather the colour after the
+//     class filter, for the kept points only (24 % fewer colour gathers; one frame gathers both at once: latency).
 //   * stable compaction inside the tile: ballot ranks + one 64-lane DPP scan per workgroup.
 //   * across tiles, two forms:
 //       FUSED (a launch of at most one tile per CU: every workgroup is resident, tile = blockIdx): decoupled
 //         look-back (8-byte {flag, epoch, value} granules, relaxed agent-scope atomics, bounded spin), then the SoA
-//         stores of the kept records (points re-read from L2).  One launch: this is what integrate() of one frame runs.
-//       SPLIT (batches): no workgroup ever waits for another.  k1_front writes each tile's kept list
-//         (tile-local index | rgb | class, 8 B per kept point) and its count; k1_scan (one workgroup) turns the counts
-//         into store offsets and closes the frames' segments; k1_append streams list + points into the SoA store,
-//         fully coalesced.  Block b of k1_front takes position b / Q of queue b % Q, queue q holding the tiles of the
-//         frames f = q (mod Q): with the round-robin placement of blocks on the 8 XCDs a frame's image lines are
-//         pulled into ONE L2 instead of eight (placement is a speed matter only, nothing depends on it).
-//     Measured on 64 x 120 k points: a single fused launch with tickets and look-back spends its time
-//     in convoys of spinning workgroups (polls alone are TB/s of fabric traffic); the split form has no spin at all.
+//         stores of the kept records.  One launch: this is what integrate() of one frame runs.
+//       SPLIT (batches): no workgroup ever waits for another.  The front kernel writes each tile's kept records
+//         (x, y, z, intensity as loaded + rgb | class: 20 B per kept point) and its count; k1_append adds up the counts
+//         before its tile and streams the records into the SoA store, fully coalesced.  Grid x = queue, queue q holding
+//         the frames f = q (mod Q): with the round-robin placement of workgroups on the 8 XCDs a frame's image lines are
+//         pulled into ONE L2 instead of eight (placement is a speed matter only, nothing depends on it).  The frame
+//         descriptor comes through the scalar cache from a closed-form index (no dependent vector loads).
+//     Measured on 64 x 120 k points: chaining the tiles inside one launch -- tickets + look-back over all
+//     tiles (round 1), or per-frame sums of published counts + frame totals (round 3, 'LINKED') -- makes every tile wait
+//     for the slowest of the ~1000 tiles in flight before it may store (10 us of a 24 us tile lifetime): 107 us against
+//     72 for the split form, which pays 20 B written + 20 B read per kept point instead and never waits.
 #include "pca_common.h"
 #include <cstdlib>
 #include <cstring>
@@ -69,7 +76,8 @@ struct K1Args {
     K1Frame one;
     int n_frames;
     int n_queues;
-    int qframe0[K1_MAXQ + 1];           // SPLIT: frames of queue q = [qframe0[q], qframe0[q+1]) of `frames`
+    int qframe0[K1_MAXQ + 1];           // SPLIT: frames of queue q = [qframe0[q], qframe0[q+1]) of `frames` ...
+    int qbase, qrem;                    // ... = q * qbase + min(q, qrem) (+ qbase + (q < qrem)): n_frames / Q, n_frames % Q
     int qtiles[K1_MAXQ];                // SPLIT: tiles in queue q
     Mat34 P;
     int H, W;
@@ -151,11 +159,48 @@ __device__ __forceinline__ K1Frame k1_find_frame(const K1Frame *frames, int f_lo
 }
 static_assert(sizeof(K1Frame) == 48, "k1_find_frame reads a descriptor as three 16-byte words");
 
+// One descriptor at a workgroup-uniform address, read through the scalar cache (s_load_dwordx4 x 3: one short hop instead
+// of vector loads from the kernel-argument segment -- 2.6 us of a tile's 12.5 were spent waiting for those).  The
+// descriptors are written before the launch (kernel arguments, or an upload on the same stream), never during it.
+__device__ __forceinline__ K1Frame k1_frame_uniform(const K1Frame *f)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)reinterpret_cast<uintptr_t>(f));
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(reinterpret_cast<uintptr_t>(f) >> 32));
+    const __attribute__((address_space(4))) u32x4 *p =
+        reinterpret_cast<const __attribute__((address_space(4))) u32x4 *>(((uintptr_t)hi << 32) | lo);
+    const u32x4 w0 = p[0], w1 = p[1], w2 = p[2];
+    auto ptr = [](uint32_t a, uint32_t b) { return (uintptr_t)(((uint64_t)b << 32) | a); };
+    K1Frame fr;
+    fr.pts = reinterpret_cast<const float *>(ptr(w0.x, w0.y));
+    fr.rgb = reinterpret_cast<const uint8_t *>(ptr(w0.z, w0.w));
+    fr.sem = reinterpret_cast<const uint8_t *>(ptr(w1.x, w1.y));
+    fr.sem_gt = reinterpret_cast<const uint8_t *>(ptr(w1.z, w1.w));
+    fr.n = (int32_t)w2.x; fr.tile0 = (int32_t)w2.y; fr.qpos0 = (int32_t)w2.z; fr.f = (int32_t)w2.w;
+    return fr;
+}
+// qframe0[q] of the kernel arguments without a dynamically indexed load (a select chain on scalar registers)
+template <int N>
+__device__ __forceinline__ int k1_pick(const int (&v)[N], int q)
+{
+    int r = v[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) r = q == i ? v[i] : r;
+    return r;
+}
+
 #define K1_INLINE_FRAMES 64
 struct K1InlineFrames { K1Frame f[K1_INLINE_FRAMES]; };   // descriptors of a small batch travel in the kernel arguments
+// k1_kitti_inl(K1Args a, K1InlineFrames inl): explicit arguments lie in the kernel-argument segment in order, from offset 0
+static_assert(sizeof(K1Args) % alignof(K1InlineFrames) == 0, "inl follows a without padding");
+__device__ __forceinline__ const K1Frame *k1_inline_frames()
+{
+    auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    return reinterpret_cast<const K1Frame *>(reinterpret_cast<uintptr_t>(ka) + sizeof(K1Args));
+}
 
-template <int BLK, int PPT, bool SPLIT, bool BILIN>
-__device__ __forceinline__ void k1_body(const K1Args &a, const K1Frame *inl)
+template <int BLK, int PPT, bool SPLIT, bool BILIN, bool INL>
+__device__ __forceinline__ void k1_body(const K1Args &a)
 {
     constexpr int TILE = BLK * PPT, NW = BLK / PCA_WAVE, NC = PPT * NW;
     static_assert(NC <= 64, "the per-(row, wave) counts are scanned by one wave");
@@ -180,18 +225,27 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const K1Frame *inl)
         fr = a.frames ? k1_find_frame<true>(a.frames, 0, a.n_frames, (int)blockIdx.x, lane) : a.one;
         tin = (int)blockIdx.x - fr.tile0;
     } else {
-        const int q = blockIdx.x, f_lo = a.qframe0[q], f_hi = a.qframe0[q + 1];
+        // frames k = q (mod Q) form queue q, queues laid out one after the other: its range in `frames` in closed form (no load)
+        const int q = blockIdx.x, f_lo = q * a.qbase + (q < a.qrem ? q : a.qrem), f_hi = f_lo + a.qbase + (q < a.qrem ? 1 : 0);
         if (a.tpf) {
             if (f_lo + (int)blockIdx.z >= f_hi) return;                   // queues of unequal length
-            fr = inl ? inl[f_lo + blockIdx.z] : a.frames ? a.frames[f_lo + blockIdx.z] : a.one;   // uniform index: scalar loads
+            // (inline descriptors: addressed through the kernel-argument segment pointer -- taking the address of the
+            // by-value parameter itself would make the compiler copy all 3 KB of it to scratch)
+            fr = INL ? k1_frame_uniform(k1_inline_frames() + f_lo + blockIdx.z)
+                     : a.frames ? k1_frame_uniform(a.frames + f_lo + blockIdx.z) : a.one;
             tin = blockIdx.y;
         } else {
-            if ((int)blockIdx.y >= a.qtiles[q]) return;
+            if ((int)blockIdx.y >= k1_pick(a.qtiles, q)) return;
             fr = k1_find_frame<false>(a.frames, f_lo, f_hi, (int)blockIdx.y, lane);
             tin = (int)blockIdx.y - fr.qpos0;
         }
     }
-    if (threadIdx.x < 8) s_filt[threadIdx.x] = reinterpret_cast<const uint32_t *>(a.filt.w)[threadIdx.x];
+    if (threadIdx.x < 8) {                                 // (a select chain over scalar registers: a dynamically indexed
+        uint32_t w = (uint32_t)a.filt.w[0];                //  read of the kernel arguments is a vector load that wave 0 would
+#pragma unroll                                             //  wait for before it issues its point loads)
+        for (int i = 1; i < 8; ++i) w = (int)threadIdx.x == i ? (uint32_t)(a.filt.w[i >> 1] >> (32 * (i & 1))) : w;
+        s_filt[threadIdx.x] = w;
+    }
     const int tile = fr.tile0 + tin;                       // index in output (frame-major) order
     const int ftiles = fr.n > 0 ? (fr.n + TILE - 1) / TILE : 1;
     const int base_pt = tin * TILE;
@@ -207,11 +261,15 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const K1Frame *inl)
     typedef float f2 __attribute__((ext_vector_type(2)));
     uint64_t cm[PPT];
     float4 v[PPT];
+    if (n_here > 0) {                                      // (uniform) all PPT loads of a lane back to back, no branches:
+#pragma unroll                                             // a lane past the end re-reads the tile's last point
+        for (int k = 0; k < PPT; ++k) {
+            const int idx = k * BLK + (int)threadIdx.x;
+            v[k] = k1_ldg4(pts + 4 * (idx < n_here ? idx : n_here - 1));   // 16 B / lane, fully coalesced
+        }
+    } else {
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int idx = k * BLK + threadIdx.x;
-        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < n_here) v[k] = k1_ldg4(pts + 4 * idx);                 // 16 B / lane, fully coalesced
+        for (int k = 0; k < PPT; ++k) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     {
         const float *cu = a.cull;
@@ -284,22 +342,28 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const K1Frame *inl)
             km[r] = __ballot(act && !((s_filt[c >> 5] >> (c & 31u)) & 1u));
         }
     } else {
-        unsigned cls[PPT], rgb[PPT];
+        unsigned cls[PPT], rgb[PPT], rsh[PPT];
+        int pixr[PPT];
         bool ok[PPT];
-        const int last = a.H * a.W * 3 - 4;                               // last legal 4-byte window of the image
-        auto rgb_at = [&](int pix) -> uint32_t {                          // r | g<<8 | b<<16 of one pixel: ONE unaligned dword
-            int off = pix * 3;
-            if (last >= 0) {
-                const int sh = off > last ? (off - last) * 8 : 0;
-                off = off > last ? last : off;
-                return (k1_ldg_u32_unaligned(fr.rgb + off) >> sh) & 0xffffffu;
-            }                                                              // image smaller than four bytes
-            return (uint32_t)k1_ldg(fr.rgb + off) | ((uint32_t)k1_ldg(fr.rgb + off + 1) << 8) |
-                   ((uint32_t)k1_ldg(fr.rgb + off + 2) << 16);
+        // Batches: the colour is gathered for the KEPT points only, after the class filter (a second, dependent round trip,
+        // 24 % fewer colour gathers).  What bounds the batch form on scattered points is the number of distinct lines its
+        // gathers pull through the L1s -- 64 per wave instruction, a whole line for 1 or 4 useful bytes: every gather at
+        // pixel 0 instead takes the front kernel from 57 to 31 us.  One frame (FUSED) is latency-bound: both at once.
+        constexpr bool dep = SPLIT;
+        const int last = a.H * a.W * 3 < 4 ? 0 : a.H * a.W * 3 - 4;      // last legal 4-byte window of the image
+        // r | g<<8 | b<<16 of one pixel as ONE unaligned dword + the shift that brings the pixel to bit 0.  The shift is
+        // applied in the third sweep: nothing in this one consumes a gathered value, so the gathers of ALL rounds of a
+        // wave are in flight together (consumed inside the round, each round waited for its own round trip).
+        // (an image of fewer than four bytes reaches the kernel as a padded copy: pca_kitti_project_sample_filter_ex)
+        auto rgb_raw = [&](int pix, unsigned &sh) -> uint32_t {
+            const int off = pix * 3;
+            sh = off > last ? (unsigned)(off - last) * 8u : 0u;
+            return k1_ldg_u32_unaligned(fr.rgb + (off > last ? last : off));
         };
+        auto rgb_at = [&](int pix) -> uint32_t { unsigned sh; const uint32_t w = rgb_raw(pix, sh); return (w >> sh) & 0xffffffu; };
 #pragma unroll
         for (int r = 0; r < PPT; ++r) {
-            ok[r] = false; cls[r] = 0; rgb[r] = 0;
+            ok[r] = false; cls[r] = 0; rgb[r] = 0; rsh[r] = 0;
             if ((uint32_t)(r * BLK + wave * PCA_WAVE) < ncand) {       // wave-uniform: a wave without candidates in this round skips it
                 const uint32_t j = (uint32_t)(r * BLK) + threadIdx.x;
                 double qu = 0.0, qv = 0.0;
@@ -309,8 +373,9 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const K1Frame *inl)
                 const int pix = ok[r] ? px : 0;                           // pixel 0 is always a valid address
                 // two gathers per point: the class byte and ONE unaligned dword holding r,g,b
                 cls[r] = k1_ldg(fr.sem + pix);
+                pixr[r] = pix;
                 if (!BILIN) {
-                    rgb[r] = rgb_at(pix);
+                    if (!dep) rgb[r] = rgb_raw(pix, rsh[r]);
                 } else {                                                   // opt-in: bilinear colour, neighbours clamped to the image
                     const Bilin b = bilin_weights<false>(ok[r] ? qu : 0.0, ok[r] ? qv : 0.0);
                     auto cl = [](double v, int n) { return (int)(v < 0.0 ? 0.0 : (v > (double)(n - 1) ? (double)(n - 1) : v)); };
@@ -319,11 +384,25 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const K1Frame *inl)
                 }
             }
         }
+        if (!BILIN && dep) {
+#pragma unroll
+            for (int r = 0; r < PPT; ++r) {
+                const unsigned c = cls[r];
+                ok[r] = ok[r] && !((s_filt[c >> 5] >> (c & 31u)) & 1u);
+                if (ok[r]) rgb[r] = rgb_raw(pixr[r], rsh[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < PPT; ++r) {
+                packed[r] = ((rgb[r] >> rsh[r]) & 0xffffffu) | (cls[r] << 24);
+                km[r] = __ballot(ok[r]);
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < PPT; ++r) {
             const unsigned c = cls[r];
-            packed[r] = (rgb[r] & 0xffffffu) | (c << 24);
+            packed[r] = ((rgb[r] >> rsh[r]) & 0xffffffu) | (c << 24);
             km[r] = __ballot(ok[r] && !((s_filt[c >> 5] >> (c & 31u)) & 1u));
+        }
         }
     }
 #pragma unroll
@@ -396,11 +475,12 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const K1Frame *inl)
 }
 
 template <int BLK, int PPT, bool SPLIT, bool BILIN>
-__global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a) { k1_body<BLK, PPT, SPLIT, BILIN>(a, nullptr); }
+__global__ __launch_bounds__(BLK) void k1_kitti(const K1Args a) { k1_body<BLK, PPT, SPLIT, BILIN, false>(a); }
 
 // same, with the frame descriptors in the kernel arguments (no upload before the launch): equal-sized frames, <= 64 of them
 template <int BLK, int PPT, bool BILIN>
-__global__ __launch_bounds__(BLK) void k1_kitti_inl(const K1Args a, const K1InlineFrames inl) { k1_body<BLK, PPT, true, BILIN>(a, inl.f); }
+__global__ __launch_bounds__(BLK) void k1_kitti_inl(const K1Args a, const K1InlineFrames inl) { k1_body<BLK, PPT, true, BILIN, true>(a); }
+
 
 // SPLIT, second kernel: streams a tile's kept records into the SoA store (consecutive lanes write consecutive
 // records: every store instruction is fully coalesced).  The tile's store offset is the sum of the counts of the
@@ -496,6 +576,14 @@ static int k1_grow(pca_ctx *ctx, void **p, int64_t *cap, int64_t need, hipStream
     return 0;
 }
 
+static int64_t k1_ws_need(int64_t total_tiles, int tile_pts)     // bytes of SPLIT workspace for a sub-batch (see k1_prepare)
+{
+    const int64_t slots = total_tiles * tile_pts;
+    const int64_t o_lastf = (total_tiles * 4 + 255) & ~255ll, o_c = (o_lastf + total_tiles * 4 + 255) & ~255ll,
+                  o_p = (o_c + slots * 4 + 255) & ~255ll;
+    return o_p + slots * 16;
+}
+
 struct K1Plan {
     K1Args fa;
     K1AppendArgs pa;
@@ -546,6 +634,7 @@ static int k1_prepare(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames,
     }
     a.qframe0[K1_MAXQ] = w;
     a.n_queues = Q;
+    a.qbase = n_frames / Q; a.qrem = n_frames % Q;
     a.n_frames = n_frames;
     a.tpf = equal ? tiles_of(frames[0].n) : 0;
     a.sample_mode = sample_mode;
@@ -594,10 +683,11 @@ static int k1_prepare(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames,
         return 0;
     }
     // workspace: counts u32[total] | lastf i32[total] | rec_c u32[total * tile_pts] | rec_p float4[total * tile_pts]
+    // (grown by the caller for the largest sub-batch BEFORE any plan is prepared: the plans hold pointers into it)
     const int64_t slots = (int64_t)total * tile_pts;
     const int64_t o_counts = 0, o_lastf = ((int64_t)total * 4 + 255) & ~255ll, o_c = (o_lastf + (int64_t)total * 4 + 255) & ~255ll,
                   o_p = (o_c + slots * 4 + 255) & ~255ll, need = o_p + slots * 16;
-    if (k1_grow(ctx, &ctx->k1_ws[ws_slot], &ctx->k1_ws_cap[ws_slot], need, s)) return -1;
+    if (need > ctx->k1_ws_cap[ws_slot]) { ctx->err = "k1: workspace not grown for this sub-batch"; return -1; }
     char *ws = reinterpret_cast<char *>(ctx->k1_ws[ws_slot]);
     a.counts = reinterpret_cast<uint32_t *>(ws + o_counts);
     a.lastf = reinterpret_cast<int32_t *>(ws + o_lastf);
@@ -651,6 +741,24 @@ int pca_kitti_project_sample_filter_ex(pca_ctx *ctx, const pca_kitti_frame *fram
         if (frames[k].n < 0 || (frames[k].n > 0 && !frames[k].pts)) { ctx->err = "k1: bad frame"; return -1; }
         if (!frames[k].sem_gt && frames[k].n > 0 && (!frames[k].rgb || !frames[k].sem || H * W == 0)) { ctx->err = "k1: frame needs rgb+sem or sem_gt"; return -1; }
     }
+    // The colour gather is one 4-byte load per point: a one-pixel image (3 bytes) is handed to the kernel as a 4-byte copy
+    std::vector<pca_kitti_frame> padded;
+    if (H * W * 3 < 4 && H * W > 0) {
+        bool any = false;
+        for (int k = 0; k < n_frames; ++k) any = any || (frames[k].rgb && !frames[k].sem_gt);
+        if (any) {
+            if (k1_grow(ctx, &ctx->k1_tiny, &ctx->k1_tiny_cap, (int64_t)n_frames * 4, s)) return -1;
+            PCA_CHECK(ctx, hipMemsetAsync(ctx->k1_tiny, 0, (size_t)n_frames * 4, s));
+            padded.assign(frames, frames + n_frames);
+            for (int k = 0; k < n_frames; ++k)
+                if (frames[k].rgb && !frames[k].sem_gt) {
+                    uint8_t *dst = reinterpret_cast<uint8_t *>(ctx->k1_tiny) + 4 * k;
+                    PCA_CHECK(ctx, hipMemcpyAsync(dst, frames[k].rgb, (size_t)H * W * 3, hipMemcpyDeviceToDevice, s));
+                    padded[k].rgb = dst;
+                }
+            frames = padded.data();
+        }
+    }
     // FUSED when every workgroup of the launch is resident at once (one tile per CU at most), else SPLIT
     auto count_tiles = [&](int k0, int k1, int tile_pts) {
         int64_t t = 0;
@@ -699,6 +807,8 @@ int pca_kitti_project_sample_filter_ex(pca_ctx *ctx, const pca_kitti_frame *fram
         k1_split_config(&blk, &ppt);
         // sub-batches of at most K1_MAX_SPLIT_TILES tiles (k1_append adds up the counts before its tile)
         std::vector<K1Plan> plans;
+        std::vector<int> cuts(1, 0);
+        int64_t max_tiles = 0;
         for (int k0 = 0; k0 < n_frames && rc == 0;) {
             int k1 = k0 + 1;
             int64_t t = count_tiles(k0, k1, blk * ppt);
@@ -708,10 +818,18 @@ int pca_kitti_project_sample_filter_ex(pca_ctx *ctx, const pca_kitti_frame *fram
                 if (t + tn > K1_MAX_SPLIT_TILES) break;
                 t += tn; ++k1;
             }
+            max_tiles = t > max_tiles ? t : max_tiles;
+            cuts.push_back(k1);
+            k0 = k1;
+        }
+        // the sub-batches run one after the other on the stream and share ONE workspace: it is grown once, for the
+        // largest of them, before any plan takes pointers into it
+        if (rc == 0 && k1_grow(ctx, &ctx->k1_ws[0], &ctx->k1_ws_cap[0], k1_ws_need(max_tiles, blk * ppt), s)) rc = -1;
+        for (size_t i = 0; i + 1 < cuts.size() && rc == 0; ++i) {
+            const int k0 = cuts[i], k1 = cuts[i + 1];
             plans.emplace_back();
             rc = k1_prepare(ctx, frames + k0, k1 - k0, P, H, W, filter_mask, store, frame_off, first_slot + k0, false, blk, ppt,
                             0, hf + k0, df + k0, &plans.back(), sample_mode, s);
-            k0 = k1;
         }
         need_upload = false;
         for (const K1Plan &pl : plans) need_upload = need_upload || !pl.inline_frames;

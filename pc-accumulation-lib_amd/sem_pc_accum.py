@@ -46,6 +46,7 @@ class SemanticPointCloudAccumulator:
         self.voxel_dedup = float(env) if env else None
         self.voxel_dedup_every = int(os.environ.get('PCA_VOXEL_DEDUP_EVERY', '1'))
         self._integrated = 0
+        self._aug_worker0 = 0            # number of the first augmentation "worker" of a generate_bev call (see _run_bev)
         # opt-in sample mode of the projection kernels (extension, default = the reference's nearest pixel):
         # 'bilinear' mixes r, g, b of the four neighbours (PCA_SAMPLE_MODE=bilinear), the class stays the nearest pixel's
         self.sample_mode = os.environ.get('PCA_SAMPLE_MODE', 'nearest')
@@ -290,18 +291,21 @@ class SemanticPointCloudAccumulator:
 
     def _run_bev(self, pcs, trajs, bev_num):
         """bev_num samples of one window.  The reference forks a multiprocessing.Pool for bev_num > 1 (pickling the window
-        per worker, kitti360_sem_pc_accum.py:236-241); here the bev_num rasters (each with its own random augmentation,
-        drawn exactly as generate_rand_aug draws it) are enqueued back to back on the device into one [bev_num,21,px,px]
-        tensor and leave it in ONE asynchronous copy: the returned dicts (LazyBev) fill in on first access."""
+        per worker, kitti360_sem_pc_accum.py:236-241); here the bev_num rasters are enqueued back to back on the device
+        into one [bev_num,21,px,px] tensor and leave it in ONE asynchronous copy: the returned dicts (LazyBev) fill in on
+        first access.  Each raster has its own random augmentation, drawn as generate_rand_aug draws it: sample k reseeds
+        as the reference's k-th Pool worker would (pid + k in place of the worker's own pid), so the samples of one
+        window differ although they are drawn in one process within the same second."""
         import torch
         from bev_generator.bev_generator import WindowPart
         gen = self.sem_bev_generator
         if not isinstance(pcs['pc_present'], WindowPart) or os.environ.get('PCA_SYNC_BEV'):
-            return [gen.generate_multiproc((pcs, self._copy_trajs(trajs))) for _ in range(bev_num)]
+            return [gen.generate_multiproc((pcs, self._copy_trajs(trajs)), worker=self._aug_worker0 + k)
+                    for k in range(bev_num)]
         px = gen.pixel_size
         planes = torch.empty((bev_num, 21, px, px), dtype=torch.float16, device=self.store.device)
-        results = [gen.generate_multiproc((pcs, self._copy_trajs(trajs)), device_only=True, out=planes[k])
-                   for k in range(bev_num)]
+        results = [gen.generate_multiproc((pcs, self._copy_trajs(trajs)), device_only=True, out=planes[k],
+                                          worker=self._aug_worker0 + k) for k in range(bev_num)]
         return gen.to_host_async(planes, results)
 
     @staticmethod

@@ -828,17 +828,20 @@ def test_bev_num_batch_equals_single_calls_and_lazy_dicts(golden, monkeypatch, t
         for k in range(4):
             acc.integrate([(dummy, g[f'pc_{k}'], g[f'sem_gt_{k}'])])
         return acc
-    monkeypatch.setattr(np.random, 'seed', lambda *a: None)          # generate_rand_aug reseeds from pid * time
+    # generate_rand_aug reseeds from (pid + worker) * int(time): freeze the clock so that the draws can be repeated
+    import bev_generator.bev_generator as bg
+    monkeypatch.setattr(bg.time, 'time', lambda: 1700000000.25)
     acc = build()
-    np.random.RandomState  # noqa: B018
-    np.random.mtrand._rand.seed(11)
     random.seed(5)
     batch = acc.generate_bev(2, 4, gen_future=True)
     assert len(batch) == 4 and all(isinstance(b, LazyBev) for b in batch)
-    np.random.mtrand._rand.seed(11)
     random.seed(5)
     monkeypatch.setenv('PCA_SYNC_BEV', '1')                          # the one-after-the-other form
-    singles = [acc.generate_bev(2, 1, gen_future=True)[0] for _ in range(4)]
+    singles = []
+    for k in range(4):
+        acc._aug_worker0 = k                                         # sample k of the batch = worker k
+        singles.append(acc.generate_bev(2, 1, gen_future=True)[0])
+    acc._aug_worker0 = 0
     monkeypatch.delenv('PCA_SYNC_BEV')
     assert not any(isinstance(b, LazyBev) for b in singles)
     for b, s in zip(batch, singles):
@@ -848,7 +851,10 @@ def test_bev_num_batch_equals_single_calls_and_lazy_dicts(golden, monkeypatch, t
                 assert len(b[key]) == len(s[key]) and all(np.array_equal(x, y) for x, y in zip(b[key], s[key]))
             else:
                 assert np.array_equal(np.asarray(b[key]).view(np.uint16), np.asarray(s[key]).view(np.uint16)), key
-    assert not np.array_equal(np.asarray(batch[0]['road_full']), np.asarray(batch[1]['road_full']))   # augmentations differ
+    # the augmentations of one window differ from sample to sample (nothing about the seeding is patched but the clock)
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert not np.array_equal(np.asarray(batch[i]['road_full']), np.asarray(batch[j]['road_full'])), (i, j)
     # container: a LazyBev pickles as the reference's plain dict; the writer thread produces the same file
     fresh = acc.generate_bev(2, 1, gen_future=True)[0]
     assert isinstance(fresh, LazyBev)

@@ -863,3 +863,86 @@ def test_bev_chain_of_owed_transforms_equals_eager_retransform(T):
     assert np.array_equal(lazy.rows(), eager.rows())
     lazy.check_status()
     eager.check_status()
+
+
+def _tilting_transform(step):
+    """A re-transform that changes z: yaw + a small pitch + a translation with a z component."""
+    a, b = 0.01 * (step + 1), 0.004 * ((step % 3) - 1) + 0.002
+    Rz = np.array([[np.cos(a), -np.sin(a), 0.], [np.sin(a), np.cos(a), 0.], [0., 0., 1.]])
+    Ry = np.array([[np.cos(b), 0., np.sin(b)], [0., 1., 0.], [-np.sin(b), 0., np.cos(b)]])
+    Tm = np.eye(4)
+    Tm[:3, :3] = Rz @ Ry
+    Tm[:3, 3] = [0.9, -0.05 * step, 0.07 * (1 + step % 2)]
+    return Tm
+
+
+@pytest.mark.parametrize('variant', ['registers', 'memory_path', 'intensity64'])
+def test_bev_chain_with_z_changing_transforms_matches_eager_and_oracle(T, orc, monkeypatch, variant):
+    """The owed transforms of the chain change z (pitch + z translation).  Every record's z has to be the transformed
+    one on all three routes of bev_tile_bin: points kept in registers, the memory path of pass B (forced with one
+    level-1 workgroup: PCA_BEV_G=1 puts 18 000+ points in a chunk, beyond the 12 288 of the registers) and the f64
+    intensity route (no register path at all).  Lazy (write-back every fourth raster) == eager == the oracle."""
+    from pca_amd.device_store import DeviceStore, make_bev_params
+    rng = np.random.default_rng(321)
+    if variant == 'memory_path':
+        monkeypatch.setenv('PCA_BEV_G', '1')
+
+    def frame(n):
+        rows = np.zeros((n, 10))
+        rows[:, 0:2] = rng.uniform(-40, 40, (n, 2))
+        rows[:, 2] = rng.uniform(-2, 2, n)
+        rows[:, 3] = rng.uniform(0, 1, n) if variant == 'intensity64' else rng.integers(0, 256, n)
+        rows[:, 4:7] = rng.integers(0, 256, (n, 3))
+        rows[:, 7] = rng.integers(0, 19, n)
+        rows[:, 9] = rng.integers(0, 2, n)
+        return rows
+    host = [frame(6000) for _ in range(3)]
+    lazy, eager = DeviceStore(capacity=1 << 18, max_frames=32), DeviceStore(capacity=1 << 18, max_frames=32)
+    lazy.CHAIN_K, eager.CHAIN_K = 4, 1
+    i64_l, i64_e = lazy.load_rows(host), eager.load_rows(host)
+    assert (i64_l is not None) == (variant == 'intensity64')
+    allrows = np.concatenate(host)
+    ost = orc.Store.from_rows(allrows)
+    o_i64 = allrows[:, 3].copy() if variant == 'intensity64' else None
+    args = [np.array([0.3, -0.2, 0.1]), np.eye(3), 0., 0., 80., 128, 2.5, 20., 20., 0.5, 0, [13, 14, 15, 17], False, 0]
+    prm = make_bev_params(*args)
+    sizes = [r.shape[0] for r in host]
+    for step in range(9):
+        Tm = _tilting_transform(step)
+        for st in (lazy, eager):
+            st.retransform(Tm, defer=True)
+        orc.retransform(ost, Tm)
+        if step == 4:                                       # no raster here: two transforms are owed at the next one
+            continue
+        pl, pl64 = lazy.bev(2, prm, want_f64=True, intensity64=i64_l)
+        pe, _ = eager.bev(2, prm, want_f64=True, intensity64=i64_e)
+        assert T.equal(pl.view(T.int16), pe.view(T.int16)), step
+        ref = orc.bev(ost, sizes[0] + sizes[1], orc.make_bev_params(*args), intensity64=o_i64)['planes']
+        got = pl64.cpu().numpy()
+        for s in range(3):
+            for k in (0, 2, 3, 4, 5, 6):                    # 6 = elevation: min z of the TRANSFORMED points
+                assert np.array_equal(got[7 * s + k], ref[7 * s + k]), (step, s, k)
+            assert np.abs(got[7 * s + 1] - ref[7 * s + 1]).max() < 1e-12
+    assert np.array_equal(lazy.rows(), eager.rows())
+    assert np.array_equal(lazy.rows(), ost.rows())
+    lazy.check_status()
+    eager.check_status()
+
+
+def test_k1_one_pixel_image(T, orc):
+    """A 1x1 image (3 bytes): the colour gather is one 4-byte load, so the library hands the kernel a padded copy."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    pc = np.stack([rng.uniform(1, 30, n), rng.uniform(-3, 3, n), rng.uniform(-1, 1, n), rng.uniform(0, 1, n)], 1).astype(np.float32)
+    P = np.array([[0.4, 0., 0.5, 0.], [0., 0.4, 0.5, 0.], [0., 0., 1., 0.]]) @ np.array(
+        [[0., -1., 0., 0.], [0., 0., -1., 0.], [1., 0., 0., 0.], [0., 0., 0., 1.]])
+    imgs = [np.array([[[7, 200, 31]]], np.uint8), np.array([[[255, 0, 128]]], np.uint8)]
+    sems = [np.array([[3]], np.uint8), np.array([[13]], np.uint8)]
+    st = dev_store(capacity=4 * n, max_frames=4)
+    st.append_kitti([dict(pts=cu(T, pc), rgb=cu(T, im), sem=cu(T, se)) for im, se in zip(imgs, sems)], P, 1, 1, KITTI_FILTERS)
+    st.check_status()
+    got = st.frame_rows()
+    for im, se, rows in zip(imgs, sems, got):
+        ost = orc.Store(n)
+        orc.kitti_project_sample_filter(ost, pc, P, im, se, None, 1, 1, KITTI_FILTERS)
+        assert ost.n > 10 and np.array_equal(rows, ost.rows())
