@@ -864,3 +864,98 @@ def test_bev_num_batch_equals_single_calls_and_lazy_dicts(golden, monkeypatch, t
         back = pickle.loads(f.read())
     assert type(back) is dict and back['rgb_full'].dtype == np.float16 and back['rgb_full'].shape == (3, 32, 32)
     assert np.array_equal(back['road_present'], fresh['road_present'])
+
+
+def test_config2_shaped_stream_every_step_against_the_oracle_pipeline():
+    """BASELINE configs[1] shape at full frame size: 120 000-point frames with 376x1408 images through the drop-in
+    accumulator -- a 60-frame fill (integrate_many), then 14 steps of integrate() + one 256x256 BEV each, so that owed
+    chains of 1..4 transforms, the write-back and an eviction all occur with real K1 output in the store.  EVERY step's
+    planes and the final stored rows are compared with the oracle pipeline (not with another HIP path)."""
+    import torch
+
+    import sem_pc_accum
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    from oracle import oracle as orc
+    from pca_amd import host_logic as hl
+    H, W, N = 376, 1408, 120_000
+    cam_to_velo = np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418],
+                            [-0.999004371, 0.007784614041, 0.04392796942, 0.2993489574],
+                            [-0.01162548558, -0.9960641394, -0.08786966659, -0.1770225824], [0, 0, 0, 1]])
+    P = np.array([[552.554261, 0, 682.049453, 0], [0, 552.554261, 238.769549, 0], [0, 0, 1, 0]]) @ np.linalg.inv(cam_to_velo)
+
+    def frame(k):
+        rng = np.random.default_rng(4000 + k)
+        pc = np.stack([rng.uniform(-60, 60, N), rng.uniform(-60, 60, N), rng.uniform(-2, 3, N), rng.uniform(0, 1, N)],
+                      1).astype(np.float32)
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        sem = rng.integers(0, 19, (H, W)).astype(np.uint8)
+        sem[rng.random((H, W)) < 0.01] = 255
+        return pc, img, sem
+    pool = [frame(k) for k in range(3)]
+    dev_pool = [(torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda(), torch.from_numpy(s).cuda()) for p, i, s in pool]
+
+    class Resident:
+        def pred(self, rgb):
+            return by_ptr[rgb.data_ptr()][None, None]
+    by_ptr = {d[0].data_ptr(): d[2] for d in dev_pool}
+    sem_pc_accum.SemSegONNX = lambda path: Resident()
+    a = -0.004
+    T = np.array([[np.cos(a), -np.sin(a), 0, 0], [np.sin(a), np.cos(a), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.]]) @ \
+        np.array([[1, 0, 0, -1.0], [0, 1, 0, 0.01], [0, 0, 1, 0.002], [0, 0, 0, 1.]])
+    horizon, bev_h, view, px = 70.0, 30.0, 80, 256
+    bev_params = dict(BEV_KITTI, view_size=view, pixel_size=px)
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': P}
+    acc = Kitti360SemanticPointCloudAccumulator(horizon, calib, 1e3, 'resident', KITTI_FILTERS, SEM_IDXS, False, bev_params)
+    acc._store_args = dict(capacity=1 << 23, max_frames=256)
+    acc.pose_provider = lambda pc: T
+    ost = orc.Store(80 * 40000)
+    track = hl.PoseTrack()
+    sizes, lo, removed_dev, removed_orc = [], 0, [], []
+
+    def oracle_step(k):
+        nonlocal sizes, lo
+        pc, img, sem = pool[k % 3]
+        if len(track):
+            track.apply_transform(T)
+            orc.retransform(ost, T, lo, ost.n)
+        sizes.append(orc.kitti_project_sample_filter(ost, pc, P, img, sem, None, H, W, KITTI_FILTERS))
+        track.append([0., 0., 0.])
+        ev = 0
+        if len(track) > 1:
+            ev = track.evict_beyond(horizon, track.push_segment())
+            lo += int(np.sum(sizes[:ev]))
+            sizes = sizes[ev:]
+        removed_orc.append(ev)
+    fill = 60
+    removed_dev += acc.integrate_many([[(dev_pool[k % 3][0], dev_pool[k % 3][1], None)] for k in range(fill)])
+    for k in range(fill):
+        oracle_step(k)
+    chains = set()
+    for k in range(fill, fill + 14):
+        removed_dev.append(acc.integrate([(dev_pool[k % 3][0], dev_pool[k % 3][1], None)]))
+        oracle_step(k)
+        if k == fill + 6:                                   # a step without a raster: the chain is one longer next time
+            continue
+        d = acc.get_incremental_path_dists()
+        pidx = int(((d - bev_h) > 0).argmax())
+        chains.add(len(acc.store._pending))
+        bev = acc.generate_bev(pidx, 1, gen_future=True)[0]
+        origin = np.array(track.poses[pidx])
+        R = hl.rotation_matrix_3d(hl.heading_rot_ang(np.array(track.poses[:pidx]) - origin))
+        prm = orc.make_bev_params(origin, R, 0., 0., view, px, None, 20., 20., 0.5, 0, [13, 14, 15, 17], False)
+        sub = orc.Store(1)
+        for name in ('x', 'y', 'z', 'intensity', 'rgbs', 'inst', 'dyn'):
+            setattr(sub, name, getattr(ost, name)[lo:ost.n])
+        sub.n = sub.cap = ost.n - lo
+        F = orc.bev(sub, int(np.sum(sizes[:pidx])), prm)['f16']
+        for s, name in enumerate(('present', 'future', 'full')):
+            for key, pl in (('road', 0), ('dynamic', 5), ('elevation', 6)):
+                assert np.array_equal(bev[f'{key}_{name}'].view(np.uint16), F[7 * s + pl].view(np.uint16)), (k, key, name)
+            assert np.array_equal(bev[f'rgb_{name}'].view(np.uint16), F[7 * s + 2:7 * s + 5].view(np.uint16)), (k, name)
+            di = np.abs(bev[f'intensity_{name}'].view(np.uint16).astype(int) - F[7 * s + 1].view(np.uint16).astype(int))
+            assert di.max() <= 1 and (di != 0).mean() < 1e-3, (k, name)
+    assert chains >= {1, 2, 3, 4}, chains                   # every chain length was rasterised at least once
+    assert removed_dev == removed_orc and sum(removed_dev) >= 1
+    assert np.array_equal(np.concatenate(acc.sem_pcs), ost.rows(lo))
+    assert np.array_equal(np.array(acc.poses), np.array(track.poses))
+    acc.store.check_status()
