@@ -143,16 +143,9 @@ class ResidentSemSeg:
 
 
 def present_index(acc):
-    """Sample trigger of run_kitti360_bev_gen.py:218-230: first pose more than 80 m of path behind the newest."""
-    if len(acc.poses) < 2:
-        return None
-    d = acc.get_incremental_path_dists()
-    if d[-1] < BEV_HORIZON_M:
-        return None
-    idx = int(((d - BEV_HORIZON_M) > 0).argmax())
-    if d[-1] - d[idx] < BEV_HORIZON_M:
-        return None
-    return idx
+    """Sample trigger of run_kitti360_bev_gen.py:218-230: first pose more than 80 m of path behind the newest, with 80 m
+    of path ahead of it (conditions 1 and 2; one sample per frame: no minimum spacing).  One call into the pose track."""
+    return acc._track.trigger(BEV_HORIZON_M, 0, 0.0)
 
 
 def device_pool(frame_fn, seq, n, model=None):

@@ -114,6 +114,24 @@ int pca_nusc_sample_filter_transform_ex(pca_ctx *ctx, const double *pc, const in
                                         const double T[16], const uint64_t filter_mask[4], const pca_store *store,
                                         int64_t *frame_off /*dev*/, int slot, int sample_mode, void *stream);
 
+/* The same for a BATCH of frames (a whole scene: run_nuscenes_bev_gen.py:236-237 integrates every sample of a scene before
+ * the first BEV): one front launch over the tiles of all frames + one append launch, the stored rows being exactly those of
+ * n_frames single calls in order (slots first_slot .. first_slot + n_frames - 1; the K3 marks of the tracker are applied
+ * afterwards, in tracker order).  Every frame has its own point rows, camera indices, image stack and T_ego_world; the
+ * image stacks share ncam, H, W.  At most 16384 tiles of 512 points per call. */
+typedef struct {
+    const double *pc;          /* dev [n,7] f64 rows x,y,z,intensity,u,v,inst */
+    const int64_t *cam_idx;    /* dev [n] */
+    const uint8_t *imgs;       /* dev [ncam,H,W,3] */
+    const uint8_t *sems;       /* dev [ncam,H,W] */
+    int32_t n;
+    int32_t reserved;
+    const double *T;           /* host 4x4 row-major f64 (T_ego_world) */
+} pca_nusc_frame;
+int pca_nusc_sample_filter_transform_batch(pca_ctx *ctx, const pca_nusc_frame *frames, int n_frames, int ncam, int H, int W,
+                                           const uint64_t filter_mask[4], const pca_store *store, int64_t *frame_off /*dev*/,
+                                           int first_slot, int sample_mode, void *stream);
+
 /* pts_feat_from_img(pts_uv, img, method='bilinear') of the reference for a 2-D feature map (its bilinear branch only
  * works for those): datasets/nuscenes_utils.py:181-210, the arithmetic to the letter.  map: dev [H,W] f64; uv: dev [n,2]
  * f64 (u along x); out: dev [n] f64.  Raises PCA_STATUS_UV_OUT_OF_IMAGE where the reference's assert fails. */
@@ -279,6 +297,48 @@ int pca_bev_warp(pca_ctx *ctx, const uint16_t *planes_f16 /*dev*/, uint16_t *out
  * ------------------------------------------------------------------------------------------------ */
 int pca_host_ego_to_grid(const double *full, int F, const double R[9], double dx, double dy, double view, int px,
                          double *rows, int32_t *start);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host helper (no device work): the accumulator's pose track -- the per-frame bookkeeping integrate() does on Python
+ * lists in the reference.  Replaces sem_pc_accum.py:156-165 (update_poses), :185-209 (remove_observations), :211-228
+ * (comp_incr_path_dist), :404-415 (dist) and, for runners that replay it, the sample trigger of
+ * run_kitti360_bev_gen.py:218-240.  Bit-identical to the numpy expressions by construction: `cblas_dgemv64` is the
+ * entry point of the cblas_dgemv (64-bit integers) of the OpenBLAS that numpy itself has loaded, so both matrix products
+ * ((4,4)@(4,1) per pose, tri(n)@d) run the very kernel numpy runs; np.sum is restated as numpy's pairwise summation.
+ *   pca_host_track_step      one integrate(): transform stored poses by T_new_prev, append [0,0,0], push the newest
+ *                            segment, evict beyond `horizon`; returns the number of evicted frames, *path_length = the
+ *                            path before the eviction (NaN while there is one pose only)
+ *   pca_host_track_trigger   present index of a BEV sample, -1 if one of the driver's three conditions says no,
+ *                            -2 if previous_idx is out of range (IndexError in the driver)
+ *   pca_host_track_incr      tri(n) @ d into out[n_segments]
+ * poses(): [len][4] doubles x, y, z, 1 (valid until the next mutating call); segments(): [n_segments].
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct pca_host_track pca_host_track;
+/* The (4,4)@(4,1) product per pose: mode 0 calls cblas_dgemv (exact by construction, ~150 ns of call overhead per pose);
+ * modes 1..5 are the closed forms a dgemv kernel can reduce to for a 4-long dot product.  The binding probes them against
+ * numpy on random data (pca_host_gemv4_probe) and selects one only if it agrees everywhere (pca_host_gemv4_mode). */
+int pca_host_gemv4_probe(void *cblas_dgemv64, int mode, const double *T /*[n][16]*/, const double *x /*[n][4]*/, int64_t n,
+                         double *y /*[n][4]*/);
+int pca_host_gemv4_mode(int mode);
+/* tri(n) @ d: the eviction needs its first rows, the trigger its last row and one crossing.  With blocks on, groups of 8
+ * rows (from a multiple of 8) are computed on their own instead of the full n x n product; the binding turns that on only
+ * after pca_host_incr_probe reproduced numpy's full product on random data. */
+int pca_host_incr_probe(void *cblas_dgemv64, const double *d, int64_t n, int64_t r0, int64_t r1, double *out);
+int pca_host_incr_blocks(int on);
+int pca_host_track_create(pca_host_track **out, void *cblas_dgemv64);
+void pca_host_track_destroy(pca_host_track *t);
+int64_t pca_host_track_len(const pca_host_track *t);
+int64_t pca_host_track_n_segments(const pca_host_track *t);
+const double *pca_host_track_poses(const pca_host_track *t);
+const double *pca_host_track_segments(const pca_host_track *t);
+int pca_host_track_set(pca_host_track *t, const double *poses /*[n][3]*/, int64_t n, const double *segs, int64_t nd);
+int pca_host_track_transform(pca_host_track *t, const double T[16]);
+int pca_host_track_append(pca_host_track *t, const double pose[3]);
+int pca_host_track_push_segment(pca_host_track *t, double *path_length);
+int pca_host_track_incr(pca_host_track *t, double *out);
+int64_t pca_host_track_evict_beyond(pca_host_track *t, double horizon, double path_length);
+int64_t pca_host_track_step(pca_host_track *t, const double T_new_prev[16], double horizon, double *path_length);
+int64_t pca_host_track_trigger(pca_host_track *t, double bev_horizon, int64_t previous_idx, double min_step);
 
 /* ------------------------------------------------------------------------------------------------
  * Optional timing with HIP events recorded on the call's stream.  on = 1: every kernel launch is bracketed

@@ -193,6 +193,176 @@ __global__ __launch_bounds__(K1N_BLK) void k1n_nusc(const K1nArgs a)
     if (threadIdx.x == 0 && tile == a.total_tiles - 1) a.frame_off[a.slot + 1] = tile_base + sc.total;
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1n for a BATCH of frames (a whole scene: run_nuscenes_bev_gen.py:236-237 integrates all ~40 samples before the first
+// BEV).  One frame is 68 tiles -- a launch that leaves three quarters of the chip idle and is all latency (9 us); the
+// batch is one front launch over the tiles of all frames and one append launch, in the SPLIT form of K1 (csrc/pca_k1.hip):
+// the front writes each tile's kept records (final values: transformed x, y, z, intensity, rgb | class, instance) at
+// tile-local places of a staging area plus the tile's count, nobody waits for anybody; the append adds up the counts before
+// its tile and streams the records into the store, closing the frames' segments.
+// ---------------------------------------------------------------------------------------------
+struct K1nFrame {              // device-side descriptor of one frame of the batch
+    const double *pc;          // [n,7]
+    const int64_t *cam_idx;    // [n]
+    const uint8_t *imgs;       // [ncam,H,W,3]
+    const uint8_t *sems;       // [ncam,H,W]
+    int32_t n, tile0;          // points; first tile of the frame
+    double T[12];              // top three rows of T_ego_world
+};
+struct K1nBatchArgs {
+    const K1nFrame *frames;    // dev [n_frames]
+    const int32_t *tile_frame; // dev [total_tiles]
+    int n_frames, total_tiles;
+    int ncam, H, W, sample_mode;
+    ClassMask filt;
+    double *sx, *sy, *sz;      // staging [total_tiles * TILE]
+    float *si;
+    uint32_t *sc;
+    int32_t *sn;
+    uint32_t *counts;          // [total_tiles]
+    int32_t *lastf;            // [total_tiles] frame index if the tile is the last of its frame, else -1
+    pca_store st;
+    int64_t *frame_off;
+    int first_slot;
+    uint32_t *status;
+};
+
+__global__ __launch_bounds__(K1N_BLK) void k1n_front_batch(const K1nBatchArgs a)
+{
+    constexpr int TILE_PTS = K1N_PPT * K1N_BLK, NW = K1N_BLK / PCA_WAVE;
+    __shared__ uint32_t s_wtot[K1N_PPT * NW], s_woff[K1N_PPT * NW + 1];
+    const int tile = blockIdx.x;
+    const int f = __builtin_amdgcn_readfirstlane(ldg(a.tile_frame + tile));
+    const K1nFrame *fp = a.frames + f;
+    const double *pc = ldg(&fp->pc);
+    const int64_t *cam_idx = ldg(&fp->cam_idx);
+    const uint8_t *imgs = ldg(&fp->imgs), *sems = ldg(&fp->sems);
+    const int n = ldg(&fp->n), tile0 = ldg(&fp->tile0);
+    const int64_t base_pt = (int64_t)(tile - tile0) * TILE_PTS;
+    int64_t cam[K1N_PPT];
+    double row[K1N_PPT][7];
+#pragma unroll
+    for (int k = 0; k < K1N_PPT; ++k) {
+        const int64_t p = base_pt + k * K1N_BLK + threadIdx.x;
+        cam[k] = -1;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) row[k][i] = 0.0;
+        if (p < n) {
+            cam[k] = ldg(cam_idx + p);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) row[k][i] = ldg(pc + p * 7 + i);
+        }
+    }
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = ldg(&fp->T[i]);
+    bool valid[K1N_PPT], keep[K1N_PPT];
+    uint32_t packed[K1N_PPT];
+    unsigned cls[K1N_PPT];
+    bool bad_uv = false;
+    const int64_t last = (int64_t)a.ncam * a.H * a.W * 3 - 4;           // last legal 4-byte window of the images
+    auto rgb_at = [&](int64_t pix) -> uint32_t {
+        int64_t off = pix * 3;
+        const int sh = off > last ? (int)(off - last) * 8 : 0;
+        off = off > last ? last : off;
+        return (ldg_u32_unaligned(imgs + off) >> sh) & 0xffffffu;
+    };
+#pragma unroll
+    for (int k = 0; k < K1N_PPT; ++k) {
+        const int64_t c = cam[k];
+        const double u = row[k][4], v = row[k][5];
+        valid[k] = c >= 0 && c < a.ncam;                   // else: features stay -1 -> invalid
+        if (valid[k] && !(u > 1.0 && u < (double)a.W - 1.0 && v > 1.0 && v < (double)a.H - 1.0)) { bad_uv = true; valid[k] = false; }
+        const int ui = valid[k] ? (int)rint(u) : 0, vi = valid[k] ? (int)rint(v) : 0;
+        const int64_t img0 = (valid[k] ? c : 0) * a.H;
+        const int64_t pix = (img0 + vi) * a.W + ui;        // pixel 0 of camera 0 for invalid points: a legal address
+        cls[k] = ldg(sems + pix);
+        if (!a.sample_mode) {
+            packed[k] = rgb_at(pix);
+        } else {
+            const Bilin b = bilin_weights<false>(valid[k] ? u : 0.0, valid[k] ? v : 0.0);
+            const int u0 = (int)b.u0, u1 = (int)b.u1, v0 = (int)b.v0, v1 = (int)b.v1;
+            auto at = [&](int vv, int uu) { return rgb_at(valid[k] ? (img0 + vv) * a.W + uu : 0); };
+            packed[k] = bilin_rgb(b, at(v0, u0), at(v1, u1), at(v1, u0), at(v0, u1));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K1N_PPT; ++k) {
+        keep[k] = valid[k] && !in_mask(a.filt, cls[k]);
+        packed[k] |= cls[k] << 24;
+    }
+    if (bad_uv) atomicOr(a.status, PCA_STATUS_UV_OUT_OF_IMAGE);
+    // stable ranks inside the tile (point order = k-major, then thread)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t local[K1N_PPT];
+#pragma unroll
+    for (int k = 0; k < K1N_PPT; ++k) {
+        const uint64_t b = __ballot(keep[k]);
+        local[k] = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wtot[k * NW + wave] = (uint32_t)__popcll(b);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t v = lane < K1N_PPT * NW ? s_wtot[lane] : 0u;
+        const uint32_t inc = wave_incl_scan_add(v);
+        if (lane < K1N_PPT * NW) s_woff[lane] = inc - v;
+        if (lane == 63) s_woff[K1N_PPT * NW] = inc;
+    }
+    __syncthreads();
+    const int64_t sbase = (int64_t)tile * TILE_PTS;
+#pragma unroll
+    for (int k = 0; k < K1N_PPT; ++k) {
+        if (!keep[k]) continue;
+        const int64_t o = sbase + s_woff[k * NW + wave] + local[k];
+        const double x = row[k][0], y = row[k][1], z = row[k][2];
+        a.sx[o] = row4(T + 0, x, y, z);
+        a.sy[o] = row4(T + 4, x, y, z);
+        a.sz[o] = row4(T + 8, x, y, z);
+        a.si[o] = (float)row[k][3];
+        a.sc[o] = packed[k];
+        a.sn[o] = (int32_t)row[k][6];
+    }
+    if (threadIdx.x == 0) {
+        a.counts[tile] = s_woff[K1N_PPT * NW];
+        const int ftiles = n > 0 ? (n + TILE_PTS - 1) / TILE_PTS : 1;
+        a.lastf[tile] = tile - tile0 == ftiles - 1 ? f : -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k1n_append_batch(const K1nBatchArgs a)
+{
+    constexpr int BLK = 256, TILE_PTS = K1N_PPT * K1N_BLK;
+    const int tile = blockIdx.x;
+    __shared__ uint32_t s_w[BLK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t sum = 0;
+    for (int t = threadIdx.x; t < tile; t += BLK) sum += ldg(a.counts + t);
+    sum = wave_reduce_add(sum);
+    if (lane == 0) s_w[wave] = sum;
+    const uint32_t c = a.counts[tile];
+    const int32_t lf = a.lastf[tile];
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < BLK / 64; ++w) before += s_w[w];
+    const int64_t base = a.frame_off[a.first_slot] + before;
+    if (threadIdx.x == 0 && lf >= 0) a.frame_off[a.first_slot + lf + 1] = base + c;
+    const int64_t sbase = (int64_t)tile * TILE_PTS;
+    bool overflow = false;
+    for (uint32_t j = threadIdx.x; j < c; j += BLK) {
+        const int64_t o = base + j;
+        if (o >= a.st.capacity) { overflow = true; continue; }
+        a.st.x[o] = ldg(a.sx + sbase + j);
+        a.st.y[o] = ldg(a.sy + sbase + j);
+        a.st.z[o] = ldg(a.sz + sbase + j);
+        a.st.intensity[o] = ldg(a.si + sbase + j);
+        a.st.rgbs[o] = ldg(a.sc + sbase + j);
+        a.st.inst[o] = ldg(a.sn + sbase + j);
+        a.st.dyn[o] = 0;
+    }
+    if (overflow) atomicOr(a.status, PCA_STATUS_STORE_OVERFLOW);
+}
+
 // pts_feat_from_img(pts_uv, img, 'bilinear') of the reference (datasets/nuscenes_utils.py:181-210) for a 2-D map:
 // the reference's arithmetic to the letter (bilin_weights<true>); raises the UV status bit where the reference asserts.
 struct BilinArgs { const double *map; int H, W; const double *uv; int n; double *out; uint32_t *status; };
@@ -547,6 +717,93 @@ int pca_nusc_sample_filter_transform_ex(pca_ctx *ctx, const double *pc, const in
     a.state = ctx->tile_state; a.ticket = ctx->ticket;
     a.epoch = pca_ctx_next_epoch(ctx, s);
     PCA_LAUNCH(ctx, PCA_K_NUSC, k1n_nusc, dim3(total), dim3(K1N_BLK), s, a);
+    PCA_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+static int accum_grow(pca_ctx *ctx, void **p, int64_t *cap, int64_t need, hipStream_t s)
+{
+    if (need <= *cap) return 0;
+    PCA_CHECK(ctx, hipStreamSynchronize(s));
+    if (*p) PCA_CHECK(ctx, hipFree(*p));
+    *p = nullptr; *cap = 0;
+    const int64_t want = need + need / 4;
+    PCA_CHECK(ctx, hipMalloc(p, (size_t)want));
+    *cap = want;
+    return 0;
+}
+
+#define K1N_MAX_BATCH_TILES 16384       // k1n_append_batch adds up the counts before its tile
+int pca_nusc_sample_filter_transform_batch(pca_ctx *ctx, const pca_nusc_frame *frames, int n_frames, int ncam, int H, int W,
+                                           const uint64_t filter_mask[4], const pca_store *store, int64_t *frame_off,
+                                           int first_slot, int sample_mode, void *stream)
+{
+    if (!ctx) return -1;
+    if (sample_mode != PCA_SAMPLE_NEAREST && sample_mode != PCA_SAMPLE_BILINEAR) { ctx->err = "k1n: unknown sample_mode"; return -1; }
+    if (ncam < 1 || H < 1 || W < 1 || (int64_t)ncam * H * W * 3 < 4) { ctx->err = "k1n: bad image stack"; return -1; }
+    if (!frames || n_frames < 1 || !store || !frame_off) { ctx->err = "k1n: bad arguments"; return -1; }
+    constexpr int TILE_PTS = K1N_PPT * K1N_BLK;
+    int64_t total = 0;
+    for (int k = 0; k < n_frames; ++k) {
+        const pca_nusc_frame &f = frames[k];
+        if (f.n < 0 || (f.n > 0 && (!f.pc || !f.cam_idx || !f.imgs || !f.sems)) || !f.T) { ctx->err = "k1n: bad frame"; return -1; }
+        total += f.n > 0 ? (f.n + TILE_PTS - 1) / TILE_PTS : 1;
+    }
+    if (total > K1N_MAX_BATCH_TILES) { ctx->err = "k1n: batch too large (split it: at most 16384 tiles of 512 points)"; return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    // descriptors + tile -> frame table: built in pinned memory, one asynchronous upload
+    const int64_t desc_bytes = (((int64_t)sizeof(K1nFrame) * n_frames + 255) & ~255ll), table_bytes = ((total * 4 + 255) & ~255ll);
+    const int64_t up_bytes = desc_bytes + table_bytes;
+    if (ctx->k1n_busy) { PCA_CHECK(ctx, hipEventSynchronize(ctx->k1n_ev)); ctx->k1n_busy = false; }
+    if (up_bytes > ctx->k1n_pin_cap) {
+        if (ctx->k1n_pin) PCA_CHECK(ctx, hipHostFree(ctx->k1n_pin));
+        ctx->k1n_pin = nullptr; ctx->k1n_pin_cap = 0;
+        PCA_CHECK(ctx, hipHostMalloc(&ctx->k1n_pin, (size_t)(2 * up_bytes)));
+        ctx->k1n_pin_cap = 2 * up_bytes;
+    }
+    if (!ctx->k1n_ev) PCA_CHECK(ctx, hipEventCreateWithFlags(&ctx->k1n_ev, hipEventDisableTiming));
+    if (accum_grow(ctx, &ctx->k1n_desc_dev, &ctx->k1n_desc_cap, up_bytes, s)) return -1;
+    K1nFrame *hf = reinterpret_cast<K1nFrame *>(ctx->k1n_pin);
+    int32_t *ht = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(ctx->k1n_pin) + desc_bytes);
+    int32_t tile0 = 0;
+    for (int k = 0; k < n_frames; ++k) {
+        const pca_nusc_frame &f = frames[k];
+        hf[k].pc = f.pc; hf[k].cam_idx = f.cam_idx; hf[k].imgs = f.imgs; hf[k].sems = f.sems;
+        hf[k].n = f.n; hf[k].tile0 = tile0;
+        for (int i = 0; i < 12; ++i) hf[k].T[i] = f.T[i];
+        const int nt = f.n > 0 ? (f.n + TILE_PTS - 1) / TILE_PTS : 1;
+        for (int t = 0; t < nt; ++t) ht[tile0 + t] = k;
+        tile0 += nt;
+    }
+    // staging: sx sy sz f64 | si f32 | sc u32 | sn i32 | counts u32 | lastf i32
+    const int64_t slots = total * TILE_PTS;
+    const int64_t need = 3 * slots * 8 + 3 * slots * 4 + 2 * ((total * 4 + 255) & ~255ll) + 1024;
+    if (accum_grow(ctx, &ctx->k1n_ws, &ctx->k1n_ws_cap, need, s)) return -1;
+    if (ctx->profiling == 1) pca_prof_begin(ctx, PCA_K_NUSC, s);
+    PCA_CHECK(ctx, hipMemcpyAsync(ctx->k1n_desc_dev, ctx->k1n_pin, (size_t)up_bytes, hipMemcpyHostToDevice, s));
+    PCA_CHECK(ctx, hipEventRecord(ctx->k1n_ev, s));
+    ctx->k1n_busy = true;
+    K1nBatchArgs a;
+    a.frames = reinterpret_cast<const K1nFrame *>(ctx->k1n_desc_dev);
+    a.tile_frame = reinterpret_cast<const int32_t *>(reinterpret_cast<char *>(ctx->k1n_desc_dev) + desc_bytes);
+    a.n_frames = n_frames; a.total_tiles = (int)total;
+    a.ncam = ncam; a.H = H; a.W = W; a.sample_mode = sample_mode;
+    for (int i = 0; i < 4; ++i) a.filt.w[i] = filter_mask ? filter_mask[i] : 0;
+    char *w = reinterpret_cast<char *>(ctx->k1n_ws);
+    a.sx = reinterpret_cast<double *>(w); w += slots * 8;
+    a.sy = reinterpret_cast<double *>(w); w += slots * 8;
+    a.sz = reinterpret_cast<double *>(w); w += slots * 8;
+    a.si = reinterpret_cast<float *>(w); w += slots * 4;
+    a.sc = reinterpret_cast<uint32_t *>(w); w += slots * 4;
+    a.sn = reinterpret_cast<int32_t *>(w); w += slots * 4;
+    a.counts = reinterpret_cast<uint32_t *>(w); w += (total * 4 + 255) & ~255ll;
+    a.lastf = reinterpret_cast<int32_t *>(w);
+    a.st = *store; a.frame_off = frame_off; a.first_slot = first_slot;
+    a.status = ctx->ticket + 1;
+    hipLaunchKernelGGL(k1n_front_batch, dim3((unsigned)total), dim3(K1N_BLK), 0, s, a);
+    hipLaunchKernelGGL(k1n_append_batch, dim3((unsigned)total), dim3(256), 0, s, a);
+    if (ctx->profiling == 1) pca_prof_end(ctx, s);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }

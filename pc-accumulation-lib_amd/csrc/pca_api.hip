@@ -159,6 +159,10 @@ void pca_ctx_destroy(pca_ctx *ctx)
     }
     if (ctx->k1_frames_dev) (void)hipFree(ctx->k1_frames_dev);
     if (ctx->k1_tiny) (void)hipFree(ctx->k1_tiny);
+    if (ctx->k1n_ws) (void)hipFree(ctx->k1n_ws);
+    if (ctx->k1n_desc_dev) (void)hipFree(ctx->k1n_desc_dev);
+    if (ctx->k1n_pin) (void)hipHostFree(ctx->k1n_pin);
+    if (ctx->k1n_ev) (void)hipEventDestroy(ctx->k1n_ev);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     if (ctx->heavy_hint) (void)hipHostFree(ctx->heavy_hint);
     prof_fold(ctx);

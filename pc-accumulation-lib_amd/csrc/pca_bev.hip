@@ -25,7 +25,9 @@
 #define TS 8                      // tile side [cells]
 #define TCELLS (TS * TS)
 #define NFK (2 * TCELLS)          // fine keys per tile: cell_in_tile*2 + set
+#ifndef AB_THREADS
 #define AB_THREADS 1024           // workgroup size of the hist / scatter kernels
+#endif
 #define MAX_G 512                 // workgroups of the hist / scatter kernels
 #define C_THREADS 256             // workgroup size of the tile kernel
 #define RGB_CAP 4096              // colour records resident in LDS
@@ -89,8 +91,10 @@ __device__ __forceinline__ Window chunk_of(const BevArgs &a)
     const int64_t chunk = (w.hi - w.lo + a.G - 1) / a.G;
     w.c_lo = w.lo + (int64_t)blockIdx.x * chunk;
     w.c_hi = w.c_lo + chunk < w.hi ? w.c_lo + chunk : w.hi;
+    if (w.c_lo > w.hi) w.c_lo = w.c_hi = w.hi;
     return w;
 }
+__host__ __device__ __forceinline__ int64_t seg_stride(int64_t n, int G) { return (n + G - 1) / G; }
 
 // ---------------------------------------------------------------------------------------------
 // level 1: bev_tile_bin -- every workgroup bins its contiguous chunk of the window into the T tiles and leaves the
@@ -121,14 +125,10 @@ __device__ __forceinline__ bool apply_owed(const BevArgs &a, const PendHi &pend_
         }
     return moved;
 }
-__device__ __forceinline__ BinPoint bin_point(const BevArgs &a, const Window &w, const PendHi &pend_hi, int64_t p, double X, double Y,
-                                              double Z, uint8_t D)
+// BEV-frame key of one point (stored coordinates X, Y, Z after the owed transforms): KEY_INVALID = not in the view
+__device__ __forceinline__ uint32_t view_key(const BevArgs &a, const Window &w, int64_t p, double X, double Y, double Z, uint8_t D)
 {
     const pca_bev_params &q = a.prm;
-    BinPoint r;
-    const bool moved = apply_owed(a, pend_hi, p, X, Y, Z);
-    if (moved && a.write_back) { a.st.x[p] = X; a.st.y[p] = Y; a.st.z[p] = Z; }
-    r.x = X; r.y = Y; r.z = Z;
     const double v = q.view, vlo = -0.5 * v, vhi = 0.5 * v, pxd = (double)q.px, half_px = 0.5 * pxd;
     const bool use_h = !(q.height_filter != q.height_filter);
     const double x = X - q.origin[0];
@@ -142,7 +142,7 @@ __device__ __forceinline__ BinPoint bin_point(const BevArgs &a, const Window &w,
     bool keep = (ax > vlo) && (ax < vhi) && (ay > vlo) && (ay < vhi);
     if (use_h) keep = keep && (az < q.height_filter);
     keep = keep && (D != 1);
-    r.key = KEY_INVALID;
+    uint32_t key = KEY_INVALID;
     if (keep) {
         int i = (int)floor(ax / v * pxd + half_px);
         int j = (int)floor(ay / v * pxd + half_px);
@@ -151,8 +151,19 @@ __device__ __forceinline__ BinPoint bin_point(const BevArgs &a, const Window &w,
         const int row = q.px - 1 - j, col = i;
         const uint32_t tile = (uint32_t)((row / TS) * a.tx + (col / TS));
         const uint32_t fk = (uint32_t)(((row % TS) * TS + (col % TS)) * 2) + (p >= w.sp ? 1u : 0u);
-        r.key = (tile << 7) | fk;
+        key = (tile << 7) | fk;
     }
+    return key;
+}
+// One point of pass A (memory path): owed re-transform (returns the stored coordinates), BEV-frame key.
+__device__ __forceinline__ BinPoint bin_point(const BevArgs &a, const Window &w, const PendHi &pend_hi, int64_t p, double X, double Y,
+                                              double Z, uint8_t D)
+{
+    BinPoint r;
+    const bool moved = apply_owed(a, pend_hi, p, X, Y, Z);
+    if (moved && a.write_back) { a.st.x[p] = X; a.st.y[p] = Y; a.st.z[p] = Z; }
+    r.x = X; r.y = Y; r.z = Z;
+    r.key = view_key(a, w, p, X, Y, Z, D);
     return r;
 }
 // packs and stores one kept record (pass B)
@@ -178,20 +189,73 @@ __device__ __forceinline__ void bin_store(const BevArgs &a, uint32_t pos, uint32
     }
 }
 
-// The first REG_P * 1024 points of a chunk stay in REGISTERS between the passes (key, stored z, intensity, colour: the
-// gathers of the kept points are issued in pass A and land while it streams on), so pass B is LDS cursors and 16-byte
-// stores only.  A 200-frame KITTI window is ~10 000 points per chunk: all of it.  Whatever a chunk holds beyond that
+// The view test and cell key of pass A's register path, written for instruction count (the pass is bound by vector
+// issue, not by memory: ~270 instructions per point before, a third of them v_readlane of spilled scalars).  Same values
+// as view_key: R is a rotation about z (checked by the host), so R[2] z, R[5] z, R[6] x and R[7] y are exact zeros and
+// R[8] z is z -- for FINITE z; a point whose z is not finite is dropped here, as the reference drops it (0 * inf = NaN
+// poisons its x and y).
+struct ViewConst { double ox, oy, oz, r0, r1, r3, r4, dx, dy, vlo, vhi, v, rv, pxd, half_px, hf; int px, tx; bool use_h; };
+__device__ __forceinline__ ViewConst view_const(const BevArgs &a)
+{
+    const pca_bev_params &q = a.prm;
+    ViewConst c;
+    c.ox = q.origin[0]; c.oy = q.origin[1]; c.oz = q.origin[2];
+    c.r0 = q.R[0]; c.r1 = q.R[1]; c.r3 = q.R[3]; c.r4 = q.R[4];
+    c.dx = q.dx; c.dy = q.dy;
+    c.v = q.view; c.rv = 1.0 / q.view; c.vlo = -0.5 * q.view; c.vhi = 0.5 * q.view; c.pxd = (double)q.px; c.half_px = 0.5 * c.pxd;
+    c.hf = q.height_filter; c.use_h = !(q.height_filter != q.height_filter);
+    c.px = q.px; c.tx = a.tx;
+    return c;
+}
+__device__ __forceinline__ uint32_t view_key_lean(const ViewConst &c, double X, double Y, double Z, bool live, uint32_t set)
+{
+    const double x = X - c.ox, y = Y - c.oy;
+    const double ax = fma(c.r1, y, c.r0 * x) + c.dx;
+    const double ay = fma(c.r4, y, c.r3 * x) + c.dy;
+    bool keep = live && (ax > c.vlo) && (ax < c.vhi) && (ay > c.vlo) && (ay < c.vhi) && (fabs(Z) < __builtin_huge_val());
+    if (c.use_h) keep = keep && (Z - c.oz < c.hf);
+    uint32_t key = KEY_INVALID;
+    if (keep) {
+        // floor(a / view * px + px / 2), the reference's expression.  The IEEE division (~22 instructions) is replaced by
+        // the quotient estimate  q = a rv,  q += fma(-q, view, a) rv  (within one ulp of the rounded quotient): the floor
+        // can only differ if the sum lands within a few ulps of an integer, and a sum within 1e-9 of one is recomputed
+        // with the real division (about two points in a billion).
+        const double qx0 = ax * c.rv, qy0 = ay * c.rv;
+        const double qx = fma(fma(-qx0, c.v, ax), c.rv, qx0), qy = fma(fma(-qy0, c.v, ay), c.rv, qy0);
+        double tx = qx * c.pxd + c.half_px, ty = qy * c.pxd + c.half_px;
+        double fx = floor(tx), fy = floor(ty);
+        if ((tx - fx < 1e-9) | (fx + 1.0 - tx < 1e-9) | (ty - fy < 1e-9) | (fy + 1.0 - ty < 1e-9)) {
+            fx = floor(ax / c.v * c.pxd + c.half_px);
+            fy = floor(ay / c.v * c.pxd + c.half_px);
+        }
+        int i = (int)fx;
+        int j = (int)fy;
+        i = i > c.px - 1 ? c.px - 1 : (i < 0 ? 0 : i);
+        j = j > c.px - 1 ? c.px - 1 : (j < 0 ? 0 : j);
+        const uint32_t row = (uint32_t)(c.px - 1 - j), col = (uint32_t)i;
+        const uint32_t tile = (row / TS) * (uint32_t)c.tx + (col / TS);
+        key = (tile << 7) | ((((row % TS) * TS + (col % TS)) * 2u) + set);
+    }
+    return key;
+}
+
+// The first REG_P * 1024 points of a chunk stay in REGISTERS between the passes (key and stored z; colour and intensity of
+// the kept points are gathered at the start of pass B, all of a lane's gathers back to back), so pass B is LDS cursors and
+// 16-byte stores.  A 200-frame KITTI window is ~10 000 points per chunk: all of it.  Whatever a chunk holds beyond that
 // (giant windows) takes the memory path: keys to the key buffer, re-read with z / intensity / colour in pass B.
+__device__ unsigned long long g_dbg_stamps[1024][8];   // PCA_BEV_DBG=8|16|32: per-tile / per-chunk phase stamps (diagnostics)
+#define BIN_STAMP(slot) do { if ((a.dbg & 32) && threadIdx.x == 0 && blockIdx.x < 1024) g_dbg_stamps[blockIdx.x][slot] = wall_clock64(); } while (0)
 template <bool I64>
-__global__ __launch_bounds__(AB_THREADS) void bev_tile_bin(const BevArgs a)
+__global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void bev_tile_bin(const BevArgs a)
 {
     constexpr int REG_P = I64 ? 0 : 12;
     constexpr int UNR = 4;          // independent points per thread and iteration (memory-level parallelism)
     extern __shared__ uint32_t s_lds[];                     // [T] histogram, [T] cursors
     __shared__ uint32_t s_wsum[AB_THREADS / 64];
     uint32_t *s_h = s_lds, *s_cur = s_lds + a.T;
+    BIN_STAMP(0);
     const Window w = chunk_of(a);
-    const int64_t chunk = (w.hi - w.lo + a.G - 1) / a.G;
+    const int64_t chunk = seg_stride(w.hi - w.lo, a.G);
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0 && a.frame_off[a.slot_end] - w.lo > a.max_points) atomicOr(a.status, PCA_STATUS_STORE_OVERFLOW);
         if (threadIdx.x < HQ_IDS) a.heavy[threadIdx.x] = 0;  // the heavy queue of this call starts empty
@@ -204,37 +268,89 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_bin(const BevArgs a)
         pend_hi.v[k] = (k < a.n_pend && a.pend_slot_end[k] > a.slot_begin) ? a.frame_off[a.pend_slot_end[k]] : w.lo;
     const int64_t reg_hi = w.c_lo + (int64_t)REG_P * AB_THREADS < w.c_hi ? w.c_lo + (int64_t)REG_P * AB_THREADS : w.c_hi;
     // ---- pass A, register part ----
+    // Every load is issued by every lane, in straight-line code: a lane past the end of the chunk reads the chunk's first
+    // point instead.  (Loads inside divergent branches leave the compiler without a count of what is in flight; it then
+    // waits for EVERYTHING before the next use, which serialised the four points of a batch into four memory round trips.)
+    // Addresses are a workgroup-uniform base (the chunk's first point: scalar registers) + a 32-bit lane offset; everything
+    // per point is relative to the chunk: `i < n` compares of 32-bit numbers.
     uint32_t rkey[REG_P > 0 ? REG_P : 1], rrgb[REG_P > 0 ? REG_P : 1];
     float rinten[REG_P > 0 ? REG_P : 1];
     double rz[REG_P > 0 ? REG_P : 1];
+    const uint32_t n_reg = w.c_lo < reg_hi ? (uint32_t)(reg_hi - w.c_lo) : 0u;
+    auto rel = [&](int64_t p) -> uint32_t {                 // position p relative to the chunk, clamped to [0, n_reg]
+        const int64_t d = p - w.c_lo;
+        return d <= 0 ? 0u : (d < (int64_t)n_reg ? (uint32_t)d : n_reg);
+    };
+    const uint32_t sp_rel = rel(w.sp);                      // lanes i >= sp_rel are 'future' points
+    if (REG_P > 0 && n_reg > 0) {
+        const double *xb = a.st.x + w.c_lo, *yb = a.st.y + w.c_lo, *zb = a.st.z + w.c_lo;
+        const uint8_t *db = a.st.dyn + w.c_lo;
+        const ViewConst vc = view_const(a);
+        // (Issuing the loads of batch b + 1 before batch b is worked on -- two register sets -- was tried: 128 VGPRs with
+        // spills, 6 us slower.  So was dealing the window to the workgroups in round-robin blocks of 1024 points instead of
+        // contiguous chunks, to even out their run times: every workgroup then pays the kept-point work, +4 us.)
+        double XA[UNR], YA[UNR], ZA[UNR];
+        uint32_t DA[UNR];
+        auto issue = [&](int j0, double (&X)[UNR], double (&Y)[UNR], double (&Z)[UNR], uint32_t (&D)[UNR]) {
 #pragma unroll
-    for (int j0 = 0; j0 < REG_P; j0 += UNR) {
-        double X[UNR], Y[UNR], Z[UNR];
-        uint8_t D[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int64_t p = w.c_lo + (int64_t)(j0 + u) * AB_THREADS + threadIdx.x;
-            const bool in = p < reg_hi;
-            X[u] = in ? a.st.x[p] : 0.0;
-            Y[u] = in ? a.st.y[p] : 0.0;
-            Z[u] = in ? a.st.z[p] : 0.0;
-            D[u] = in ? a.st.dyn[p] : (uint8_t)1;
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int64_t p = w.c_lo + (int64_t)(j0 + u) * AB_THREADS + threadIdx.x;
-            rkey[j0 + u] = KEY_INVALID; rrgb[j0 + u] = 0u; rinten[j0 + u] = 0.f; rz[j0 + u] = 0.0;
-            if (p >= reg_hi) continue;
-            const BinPoint b = bin_point(a, w, pend_hi, p, X[u], Y[u], Z[u], D[u]);
-            rkey[j0 + u] = b.key;
-            rz[j0 + u] = b.z;
-            if (b.key != KEY_INVALID) {
-                atomicAdd(&s_h[b.key >> 7], 1u);
-                rrgb[j0 + u] = a.st.rgbs[p];
-                rinten[j0 + u] = a.st.intensity[p];
+            for (int u = 0; u < UNR; ++u) {
+                const uint32_t i = (uint32_t)(j0 + u) * AB_THREADS + threadIdx.x, ic = i < n_reg ? i : 0u;
+                X[u] = xb[ic];
+                Y[u] = yb[ic];
+                Z[u] = zb[ic];
+                D[u] = db[ic];
             }
+        };
+        auto work = [&](int j0, double (&X)[UNR], double (&Y)[UNR], double (&Z)[UNR], uint32_t (&D)[UNR]) {
+            // the owed re-transforms, oldest first, each a separate fma chain (the roundings of one K2 pass per transform).
+            // Transform k's twelve coefficients are fetched (scalar loads) when its turn comes instead of all forty-eight
+            // living in scalar registers through the whole pass; applied branch-free: all but the newest frames' points
+            // owe every pending transform, and UNR independent chains interleave.
+            uint32_t n_moved = 0;                           // lanes i < n_moved were moved by some transform
+#pragma unroll 1
+            for (int k = 0; k < a.n_pend; ++k) {
+                const Mat34 &Tk = a.pend_T[k];
+                const uint32_t n_owe = rel(k == 0 ? pend_hi.v[0] : k == 1 ? pend_hi.v[1] : k == 2 ? pend_hi.v[2] : pend_hi.v[3]);
+                if (n_owe == 0) continue;                   // (uniform)
+                n_moved = n_owe > n_moved ? n_owe : n_moved;
+                const double t0 = Tk.m[0], t1 = Tk.m[1], t2 = Tk.m[2], t3 = Tk.m[3], t4 = Tk.m[4], t5 = Tk.m[5], t6 = Tk.m[6],
+                             t7 = Tk.m[7], t8 = Tk.m[8], t9 = Tk.m[9], t10 = Tk.m[10], t11 = Tk.m[11];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const uint32_t i = (uint32_t)(j0 + u) * AB_THREADS + threadIdx.x;
+                    const bool owed = i < n_owe;
+                    const double nx = fma(t2, Z[u], fma(t1, Y[u], t0 * X[u])) + t3;
+                    const double ny = fma(t6, Z[u], fma(t5, Y[u], t4 * X[u])) + t7;
+                    const double nz = fma(t10, Z[u], fma(t9, Y[u], t8 * X[u])) + t11;
+                    X[u] = owed ? nx : X[u]; Y[u] = owed ? ny : Y[u]; Z[u] = owed ? nz : Z[u];
+                }
+            }
+            if (a.write_back && n_moved > 0) {
+                double *xw = a.st.x + w.c_lo, *yw = a.st.y + w.c_lo, *zw = a.st.z + w.c_lo;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const uint32_t i = (uint32_t)(j0 + u) * AB_THREADS + threadIdx.x;
+                    if (i < n_moved) { xw[i] = X[u]; yw[i] = Y[u]; zw[i] = Z[u]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const uint32_t i = (uint32_t)(j0 + u) * AB_THREADS + threadIdx.x;
+                rkey[j0 + u] = view_key_lean(vc, X[u], Y[u], Z[u], i < n_reg && D[u] != 1u, i >= sp_rel ? 1u : 0u);
+                rz[j0 + u] = Z[u];
+                if (rkey[j0 + u] != KEY_INVALID) atomicAdd(&s_h[rkey[j0 + u] >> 7], 1u);
+            }
+        };
+#pragma unroll
+        for (int j0 = 0; j0 < REG_P; j0 += UNR) {
+            issue(j0, XA, YA, ZA, DA);
+            work(j0, XA, YA, ZA, DA);
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < REG_P; ++j) { rkey[j] = KEY_INVALID; rz[j] = 0.0; }
     }
+    BIN_STAMP(1);
     // ---- pass A, memory part (what the chunk holds beyond the registers) ----
     for (int64_t base = reg_hi + threadIdx.x; base < w.c_hi; base += UNR * AB_THREADS) {
         double X[UNR], Y[UNR], Z[UNR];
@@ -258,6 +374,7 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_bin(const BevArgs a)
         }
     }
     __syncthreads();
+    BIN_STAMP(2);
     // ---- exclusive scan of the histogram: thread t owns `per` consecutive tiles ----
     {
         const int per = (a.T + AB_THREADS - 1) / AB_THREADS;
@@ -283,14 +400,29 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_bin(const BevArgs a)
         }
     }
     __syncthreads();
+    BIN_STAMP(3);
     // ---- pass B: the chunk's records into its segment, tile by tile ----
     const uint32_t seg = (uint32_t)((int64_t)blockIdx.x * chunk);
+    if (REG_P > 0 && n_reg > 0) {
+        // colour and intensity of the kept points: all of a lane's gathers issued back to back, before the first is used
+        // (a point outside the view re-reads the chunk's first point: no branch around a load).  Issuing them before the
+        // barrier, to fly during the scan, costs 24 more live registers: spills, slower.
+        const uint32_t *cb = a.st.rgbs + w.c_lo;
+        const float *ib = a.st.intensity + w.c_lo;
 #pragma unroll
-    for (int j = 0; j < REG_P; ++j) {
-        if (rkey[j] == KEY_INVALID) continue;
-        const uint32_t pos = seg + atomicAdd(&s_cur[rkey[j] >> 7], 1u);
-        bin_store<I64>(a, pos, rkey[j], rrgb[j], rz[j], (double)rinten[j]);
+        for (int j = 0; j < REG_P; ++j) {
+            const uint32_t i = (uint32_t)j * AB_THREADS + threadIdx.x, ic = rkey[j] != KEY_INVALID ? i : 0u;
+            rrgb[j] = cb[ic];
+            rinten[j] = ib[ic];
+        }
+#pragma unroll
+        for (int j = 0; j < REG_P; ++j) {
+            if (rkey[j] == KEY_INVALID) continue;
+            const uint32_t pos = seg + atomicAdd(&s_cur[rkey[j] >> 7], 1u);
+            bin_store<I64>(a, pos, rkey[j], rrgb[j], rz[j], (double)rinten[j]);
+        }
     }
+    BIN_STAMP(4);
     const bool stale = a.n_pend > 0 && !a.write_back;
     for (int64_t base = reg_hi + threadIdx.x; base < w.c_hi; base += UNR * AB_THREADS) {
         uint32_t key[UNR], pos[UNR], rgbs[UNR];
@@ -318,6 +450,8 @@ __global__ __launch_bounds__(AB_THREADS) void bev_tile_bin(const BevArgs a)
         for (int u = 0; u < UNR; ++u)
             if (key[u] != KEY_INVALID) bin_store<I64>(a, pos[u], key[u], rgbs[u], zz[u], iv[u]);
     }
+    BIN_STAMP(5);
+    if ((a.dbg & 32) && threadIdx.x == 0 && blockIdx.x < 1024) { g_dbg_stamps[blockIdx.x][6] = (unsigned long long)a.n_pend * 2 + a.write_back; g_dbg_stamps[blockIdx.x][7] = __smid(); }
 }
 
 // A tile's records lie in up to G pieces, one per level-1 workgroup.  RecMap (LDS) turns the tile-local record number
@@ -333,7 +467,7 @@ __device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, in
 {
     const int64_t lo = a.frame_off[a.slot_begin], hi0 = a.frame_off[a.slot_end];
     const int64_t n = hi0 - lo > a.max_points ? a.max_points : hi0 - lo;
-    const uint32_t chunk = (uint32_t)((n + a.G - 1) / a.G);
+    const uint32_t chunk = (uint32_t)seg_stride(n, a.G);
     const int per = (a.G + nthreads - 1) / nthreads;
     const int g0 = threadIdx.x * per;
     const uint32_t *cnt = a.bh + (int64_t)tile * a.G, *off = a.boff + (int64_t)tile * a.G;
@@ -761,7 +895,6 @@ __device__ __forceinline__ void cells_drain(const BevArgs &a, TileLds &L, unsign
     }
 }
 
-__device__ unsigned long long g_dbg_stamps[1024][8];   // PCA_BEV_DBG=8|16: per-tile phase stamps (diagnostics)
 #define DBG_STAMP(bit, slot) do { if ((a.dbg & (bit)) && threadIdx.x == 0 && tile < 1024) g_dbg_stamps[tile][slot] = wall_clock64(); } while (0)
 template <bool I64>
 __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)

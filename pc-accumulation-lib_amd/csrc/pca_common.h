@@ -34,6 +34,14 @@ struct pca_ctx {
     uint32_t epoch = 0;               // 22-bit launch tag of tile_state entries
     void *k1_frames_dev = nullptr;    // dev: K1's frame descriptors of a batched launch
     int64_t k1_frames_cap = 0;        // bytes
+    void *k1n_ws = nullptr;           // dev: staging of the batched K1n (kept records + counts)
+    int64_t k1n_ws_cap = 0;
+    void *k1n_desc_dev = nullptr;     // dev: its frame descriptors + tile -> frame table
+    int64_t k1n_desc_cap = 0;
+    void *k1n_pin = nullptr;          // pinned staging of those
+    int64_t k1n_pin_cap = 0;
+    hipEvent_t k1n_ev = nullptr;
+    bool k1n_busy = false;
     void *k1_tiny = nullptr;          // dev: 4-byte copies of images smaller than the 4-byte colour gather
     int64_t k1_tiny_cap = 0;
     void *k1_ws[2] = {nullptr, nullptr};   // dev: counts / kept records of K1's split form, one per sub-batch in flight

@@ -123,17 +123,19 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         self.T_prev_origin = np.matmul(self.T_prev_origin, T_new_prev)
         frame, semseg, H, W = self._frame_tensors(rgb, pc, sem_gt)
 
-        if len(self._track) > 0:          # move everything stored so far into the new ego frame
-            self.update_poses(T_new_prev)
+        if len(self._track) > 0:          # move everything stored so far into the new ego frame (K2, owed to the next reader)
             self.update_sem_pcs(T_new_prev)
         self.store.append_kitti([frame], self.P_velo_frame, H, W, self.semseg_filters, sample_mode=self.sample_mode)
-        self._track.append([0., 0., 0.])
+        # the pose bookkeeping of the frame in one call: update_poses, the new pose [0,0,0], the newest path segment and
+        # the horizon eviction (sem_pc_accum.py:156-228; kitti360_sem_pc_accum.py:60-88)
+        idx, path_length = self._track.step(T_new_prev, self.horizon_dist)
         self.rgbs.append(rgb)
         self.semsegs.append(semseg)
-
-        idx = 0
-        if len(self._track) > 1:
-            idx, path_length = self.remove_observations()
+        if idx:
+            self.store.evict(idx)
+            self.rgbs = self.rgbs[idx:]
+            self.semsegs = self.semsegs[idx:]
+        if path_length is not None:
             print(f'    #pc {self.store.n_frames} |', f'path length {path_length:.2f}')
         self._after_integrate()
         return idx
@@ -174,14 +176,9 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         self.store.retransform_batch(np.stack(Ts), len(frames))
         removed, total = [], 0
         for T_new_prev in Ts:                           # host bookkeeping, frame by frame as integrate() does
-            if len(self._track) > 0:
-                self.update_poses(T_new_prev)
-            self._track.append([0., 0., 0.])
-            idx = 0
-            if len(self._track) > 1:
-                path_length = self._track.push_segment()
-                idx = self._track.evict_beyond(self.horizon_dist, path_length)
-                print(f'    #pc {len(self._track)} |', f'path length {path_length:.2f}')
+            idx, path_length = self._track.step(T_new_prev, self.horizon_dist)
+            if path_length is not None:
+                print(f'    #pc {len(self._track) + idx} |', f'path length {path_length:.2f}')
             removed.append(idx)
             total += idx
             self._integrated += 1

@@ -97,9 +97,10 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
         pose[2] += ego_pose_z
         return T_ego_world, pose
 
-    def _append_frame(self, rgbs, pc, pc_cam_idx, T_ego_global, ego_pose_z):
+    def _frame_inputs(self, rgbs, pc, pc_cam_idx):
+        """Device tensors of one observation: (pc (n,7) f64, cam_idx (n,) i64, imgs (ncam,H,W,3) u8, sems (ncam,H,W) u8) and
+        the semseg maps as the model returned them.  Tensors that are on the device already (pca_amd.ingest) pass through."""
         import torch
-        T_ego_world, pose = self._ego_world(T_ego_global, ego_pose_z)
         dev = self.store.device
         semsegs = [self.semseg_model.pred(rgb)[0, 0] for rgb in rgbs]
         dev_sems = [getattr(m, 'dev', m) for m in semsegs]          # utils.onnx_utils.DeviceMap: already in HBM
@@ -109,17 +110,57 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
                 return a.to(device=dev, dtype=t_dtype).contiguous()
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np_dtype)).to(dev)
 
-        if isinstance(rgbs, torch.Tensor):
-            imgs = up(rgbs, np.uint8, torch.uint8)
+        stack = getattr(rgbs, 'dev', rgbs)                          # pca_amd.ingest.DeviceImages: the six images as one tensor
+        if isinstance(stack, torch.Tensor):
+            imgs = up(stack, np.uint8, torch.uint8)
         else:
             imgs = up(np.stack([np.array(rgb) for rgb in rgbs]), np.uint8, torch.uint8)
         if isinstance(dev_sems[0], torch.Tensor):
             sems = torch.stack([s.to(device=dev, dtype=torch.uint8) for s in dev_sems]).contiguous()
         else:
             sems = up(np.stack(semsegs), np.uint8, torch.uint8)
-        self.store.append_nusc(up(pc, np.float64, torch.float64), up(pc_cam_idx, np.int64, torch.int64), imgs, sems,
-                               T_ego_world, self.semseg_filters, sample_mode=self.sample_mode)
+        return up(pc, np.float64, torch.float64), up(pc_cam_idx, np.int64, torch.int64), imgs, sems, semsegs
+
+    def _append_frame(self, rgbs, pc, pc_cam_idx, T_ego_global, ego_pose_z):
+        T_ego_world, pose = self._ego_world(T_ego_global, ego_pose_z)
+        pc_d, cam_d, imgs, sems, semsegs = self._frame_inputs(rgbs, pc, pc_cam_idx)
+        self.store.append_nusc(pc_d, cam_d, imgs, sems, T_ego_world, self.semseg_filters, sample_mode=self.sample_mode)
         return pose, semsegs
+
+    def integrate_many(self, batch: list):
+        """Extension (no reference counterpart): integrates a list of observation lists -- what integrate() would be handed
+        call by call; the reference's driver integrates a whole scene before its first BEV (run_nuscenes_bev_gen.py:236-237)
+        -- with ONE batched K1n call (front + append launch over the tiles of all frames) and ONE K3 launch for all the
+        tracker's marks, instead of a latency-bound launch pair per frame.  Stored points, poses, segment distances, tracker
+        state and dynamic flags are those of the call-by-call form, bit for bit."""
+        if self.voxel_dedup:                           # the opt-in de-duplication runs between frames: keep that order
+            for observations in batch:
+                self.integrate(observations)
+            return
+        frames, marks = [], []
+        for observations in batch:
+            obs = observations[0]
+            T_ego_global = obs['ego_at_lidar_ts']
+            if self.T_global_world is None:
+                self.T_global_world = np.linalg.inv(T_ego_global)
+                if self.get_gt_lanes:
+                    self.gt_lane_poses = [homo_transform(self.T_global_world, lane) for lane in self.gt_lane_poses]
+            T_ego_world, pose = self._ego_world(T_ego_global, self.ego_pose_z)
+            pc_d, cam_d, imgs, sems, semsegs = self._frame_inputs(obs['images'], obs['pc'], obs['pc_cam_idx'])
+            frames.append(dict(pc=pc_d, cam_idx=cam_d, imgs=imgs, sems=sems, T=T_ego_world))
+            self._track.append(pose)
+            self.rgbs.append(obs['images'])
+            self.semsegs.append(semsegs)
+            self.ego_global_xs.append(obs['ego_global_x'])
+            self.ego_global_ys.append(obs['ego_global_y'])
+            centers = [homo_transform(self.T_global_world, np.expand_dims(c, 0))[0] for c in obs['inst_center']]
+            marks += list(self._tracker.observe(self.ts, obs['inst_tokens'], obs['inst_cls'], centers))
+            path_length = self._track.push_segment() if len(self._track) > 1 else 0
+            print(f'    ts {self.ts} | #pc {self.store.n_frames + len(frames)} |', f'path length {path_length:.2f}')
+            self.ts += 1
+            self._integrated += 1
+        self.store.append_nusc_many(frames, self.semseg_filters, sample_mode=self.sample_mode)
+        self.store.mark_dynamic(marks)                 # flags only ever go from 0 to 1: the order of the marks is immaterial
 
     def obs2sem_vec_space(self, rgbs, pc, pc_cam_idx, T_ego_global, ego_pose_z: float = 0) -> tuple:
         """Host-array form: ((M,10) rows, pose, semsegs).  Raises AssertionError like the reference if a

@@ -18,9 +18,13 @@ SAMPLE_MODES = {'nearest': 0, 'bilinear': 1}
 
 EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error', 'pca_status',
            'pca_kitti_project_sample_filter', 'pca_kitti_project_sample_filter_ex',
-           'pca_nusc_sample_filter_transform', 'pca_nusc_sample_filter_transform_ex', 'pca_sample_bilinear', 'pca_nusc_project_cams', 'pca_retransform', 'pca_retransform_batch_tail',
+           'pca_nusc_sample_filter_transform', 'pca_nusc_sample_filter_transform_ex', 'pca_nusc_sample_filter_transform_batch', 'pca_sample_bilinear', 'pca_nusc_project_cams', 'pca_retransform', 'pca_retransform_batch_tail',
            'pca_mark_dynamic',
            'pca_bev_workspace_bytes', 'pca_bev_generate', 'pca_bev_generate_ex', 'pca_bev_generate_chain', 'pca_bev_warp', 'pca_image_to_nchw_f32', 'pca_voxel_dedup_workspace_bytes', 'pca_voxel_dedup', 'pca_icp_workspace_bytes', 'pca_icp_register', 'pca_host_ego_to_grid',
+           'pca_host_gemv4_probe', 'pca_host_gemv4_mode', 'pca_host_incr_probe', 'pca_host_incr_blocks', 'pca_host_track_create', 'pca_host_track_destroy', 'pca_host_track_len', 'pca_host_track_n_segments',
+           'pca_host_track_poses', 'pca_host_track_segments', 'pca_host_track_set', 'pca_host_track_transform',
+           'pca_host_track_append', 'pca_host_track_push_segment', 'pca_host_track_incr', 'pca_host_track_evict_beyond',
+           'pca_host_track_step', 'pca_host_track_trigger',
            'pca_profile_enable', 'pca_profile_read')
 
 KERNEL_IDS = ('kitti_project_sample_filter', 'nusc_sample_filter_transform', 'nusc_project_cams', 'retransform',
@@ -36,6 +40,11 @@ class PcaStore(C.Structure):
 class PcaKittiFrame(C.Structure):
     _fields_ = [('pts', C.c_void_p), ('rgb', C.c_void_p), ('sem', C.c_void_p), ('sem_gt', C.c_void_p),
                 ('n', C.c_int32), ('reserved', C.c_int32)]
+
+
+class PcaNuscFrame(C.Structure):
+    _fields_ = [('pc', C.c_void_p), ('cam_idx', C.c_void_p), ('imgs', C.c_void_p), ('sems', C.c_void_p),
+                ('n', C.c_int32), ('reserved', C.c_int32), ('T', C.POINTER(C.c_double))]
 
 
 class PcaBevParams(C.Structure):
@@ -94,6 +103,9 @@ def load():
         vp, vp, vp, C.c_int32, vp, vp, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
         C.POINTER(PcaStore), vp, i32, i32, vp
     ]
+    lib.pca_nusc_sample_filter_transform_batch.argtypes = [
+        vp, C.POINTER(PcaNuscFrame), i32, i32, i32, i32, C.POINTER(C.c_uint64), C.POINTER(PcaStore), vp, i32, i32, vp
+    ]
     lib.pca_sample_bilinear.argtypes = [vp, vp, i32, i32, vp, C.c_int32, vp, vp]
     lib.pca_nusc_sample_filter_transform.argtypes = [
         vp, vp, vp, C.c_int32, vp, vp, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
@@ -129,6 +141,31 @@ def load():
                                      C.c_double, vp, i64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(C.c_int), vp]
     lib.pca_host_ego_to_grid.argtypes = [vp, i32, vp, C.c_double, C.c_double, C.c_double, i32, vp, vp]
+    dp = C.POINTER(C.c_double)
+    lib.pca_host_gemv4_probe.argtypes = [vp, i32, vp, vp, i64, vp]
+    lib.pca_host_gemv4_mode.argtypes = [i32]
+    lib.pca_host_incr_probe.argtypes = [vp, vp, i64, i64, i64, vp]
+    lib.pca_host_incr_blocks.argtypes = [i32]
+    lib.pca_host_track_create.argtypes = [C.POINTER(vp), vp]
+    lib.pca_host_track_destroy.argtypes = [vp]
+    lib.pca_host_track_destroy.restype = None
+    for name in ('pca_host_track_len', 'pca_host_track_n_segments'):
+        getattr(lib, name).argtypes = [vp]
+        getattr(lib, name).restype = i64
+    for name in ('pca_host_track_poses', 'pca_host_track_segments'):
+        getattr(lib, name).argtypes = [vp]
+        getattr(lib, name).restype = vp
+    lib.pca_host_track_set.argtypes = [vp, vp, i64, vp, i64]
+    lib.pca_host_track_transform.argtypes = [vp, vp]
+    lib.pca_host_track_append.argtypes = [vp, vp]
+    lib.pca_host_track_push_segment.argtypes = [vp, dp]
+    lib.pca_host_track_incr.argtypes = [vp, vp]
+    lib.pca_host_track_evict_beyond.argtypes = [vp, C.c_double, C.c_double]
+    lib.pca_host_track_evict_beyond.restype = i64
+    lib.pca_host_track_step.argtypes = [vp, vp, C.c_double, dp]
+    lib.pca_host_track_step.restype = i64
+    lib.pca_host_track_trigger.argtypes = [vp, C.c_double, i64, C.c_double]
+    lib.pca_host_track_trigger.restype = i64
     lib.pca_profile_enable.argtypes = [vp, i32]
     lib.pca_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = lib

@@ -195,6 +195,50 @@ class DeviceStore:
         self._ub.append(n)
         self._ub_sum += n
 
+    def append_nusc_many(self, frames, filters, sample_mode='nearest'):
+        """frames: list of dicts {pc (n,7) f64 cuda, cam_idx (n,) i64 cuda, imgs (ncam,H,W,3) u8 cuda, sems (ncam,H,W) u8
+        cuda, T (4,4) T_ego_world}.  ONE front + one append launch for all of them (pca_nusc_sample_filter_transform_batch):
+        the stored rows are those of len(frames) append_nusc calls in order."""
+        lib, ctx = self.ctx.lib, self.ctx
+        if not frames:
+            return
+        ncam, H, W = (int(v) for v in frames[0]['sems'].shape)
+        max_tiles = 16384
+        b0 = 0
+        while b0 < len(frames):                               # the C call takes at most 16384 tiles of 512 points
+            tiles, b1 = 0, b0
+            while b1 < len(frames):
+                t = max((int(frames[b1]['pc'].shape[0]) + 511) // 512, 1)
+                if b1 > b0 and tiles + t > max_tiles:
+                    break
+                tiles += t
+                b1 += 1
+            part = frames[b0:b1]
+            n_in = sum(int(f['pc'].shape[0]) for f in part)
+            self.reserve(n_in, len(part))
+            descs = (_lib.PcaNuscFrame * len(part))()
+            keep = []
+            for k, f in enumerate(part):
+                assert f['pc'].dtype == torch.float64 and f['pc'].is_contiguous() and f['cam_idx'].dtype == torch.int64
+                assert tuple(f['sems'].shape) == (ncam, H, W) and f['imgs'].is_contiguous() and f['sems'].is_contiguous()
+                n = int(f['pc'].shape[0])
+                Tc = _lib.f64_array(f['T'], 16)
+                keep.append(Tc)
+                descs[k].pc = f['pc'].data_ptr() if n else None
+                descs[k].cam_idx = f['cam_idx'].data_ptr() if n else None
+                descs[k].imgs, descs[k].sems = f['imgs'].data_ptr(), f['sems'].data_ptr()
+                descs[k].n = n
+                descs[k].T = C.cast(Tc, C.POINTER(C.c_double))
+            st = self.c_store()
+            ctx.check(lib.pca_nusc_sample_filter_transform_batch(ctx.h, descs, len(part), ncam, H, W, _lib.class_mask(filters),
+                                                                 C.byref(st), self.frame_off.data_ptr(), self.tail,
+                                                                 _lib.SAMPLE_MODES[sample_mode], ctx.stream()))
+            self.tail += len(part)
+            self.ub_tail += n_in
+            self._ub += [int(f['pc'].shape[0]) for f in part]
+            self._ub_sum += n_in
+            b0 = b1
+
     # ---- K2 / K3 --------------------------------------------------------------------------
     def retransform(self, Ts, defer=False):
         """Applies the 4x4 transform(s) to every live point, in order (Ts: (4,4) or (k,4,4)).

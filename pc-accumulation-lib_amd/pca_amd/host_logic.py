@@ -76,8 +76,9 @@ class ArrayList(Sequence):
         return repr(self._a.tolist())
 
 
-class PoseTrack:
-    """Ego poses of the live frames and the segment distances between them.
+class NumpyPoseTrack:
+    """Ego poses of the live frames and the segment distances between them -- the numpy form, expression by expression
+    what the reference evaluates (the C form below is checked against it when the library is bound).
 
     Stored as one (F,3) f64 array; ``poses`` hands out the reference's list-of-lists form.  The pose
     update keeps the reference's arithmetic -- one (4,4)@(4,1) product PER POSE (numpy routes those to
@@ -149,6 +150,225 @@ class PoseTrack:
         self._H = self._H[k:]
         self._D = self._D[k:]
         return k
+
+    def incr(self):
+        return incremental_path_dists(self._D)
+
+    def step(self, T_new_prev, horizon_dist):
+        """The pose bookkeeping of one integrate(): returns (frames evicted, path length or None)."""
+        if len(self) > 0:
+            self.apply_transform(T_new_prev)
+        self.append([0., 0., 0.])
+        if len(self) < 2:
+            return 0, None
+        path_length = self.push_segment()
+        return self.evict_beyond(horizon_dist, path_length), path_length
+
+    def trigger(self, bev_horizon, previous_idx, min_step):
+        """Sample trigger of run_kitti360_bev_gen.py:218-240 on the track as it stands: present index or None."""
+        if len(self) < 2:
+            return None
+        d = self.incr()
+        if d[-1] < bev_horizon:
+            return None
+        present_idx = int(((d - bev_horizon) > 0).argmax())
+        if d[-1] - d[present_idx] < bev_horizon:
+            return None
+        if pose_dist(self.pose(previous_idx), self.pose(present_idx)) < min_step:
+            return None
+        return present_idx
+
+
+def _numpy_gemv_entry():
+    """Address of the cblas_dgemv (64-bit integer interface) of the OpenBLAS numpy has loaded, or None."""
+    import ctypes as C
+    try:
+        from threadpoolctl import threadpool_info
+        paths = [p['filepath'] for p in threadpool_info() if p.get('user_api') == 'blas' and p.get('filepath')]
+    except Exception:
+        return None
+    for path in paths:
+        try:
+            blas = C.CDLL(path)
+        except OSError:
+            continue
+        for sym in ('scipy_cblas_dgemv64_', 'cblas_dgemv64_'):
+            fn = getattr(blas, sym, None)
+            if fn is not None:
+                return C.cast(fn, C.c_void_p).value, blas
+    return None
+
+
+class CPoseTrack:
+    """The same track kept by the C library (pca_host_track_*, csrc/pca_host.hip): one call per integrate() instead of a
+    dozen numpy expressions.  Same numbers bit for bit: the matrix products go through numpy's own BLAS entry point."""
+    _lib = None
+    _gemv = None
+    _blas = None
+
+    def __init__(self):
+        import ctypes as C
+        self._C = C
+        h = C.c_void_p()
+        if self._lib.pca_host_track_create(C.byref(h), self._gemv) != 0:
+            raise RuntimeError('pca_host_track_create failed')
+        self._h = h
+        self._pl = C.c_double(0.0)
+
+    def __del__(self):
+        try:
+            self._lib.pca_host_track_destroy(self._h)
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self._lib.pca_host_track_len(self._h)
+
+    def _view(self, ptr, n, width):
+        if n == 0:
+            return np.zeros((0, width)) if width > 1 else np.zeros(0)
+        a = np.ctypeslib.as_array((self._C.c_double * (n * width)).from_address(ptr))
+        return a.reshape(n, width) if width > 1 else a
+
+    def as_array(self):
+        n = len(self)
+        return self._view(self._lib.pca_host_track_poses(self._h), n, 4)[:, :3].copy()
+
+    def pose(self, idx):
+        n = len(self)
+        i = int(idx)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError('pose index out of range')
+        return self._view(self._lib.pca_host_track_poses(self._h), n, 4)[i, :3].copy()
+
+    def seg_array(self):
+        nd = self._lib.pca_host_track_n_segments(self._h)
+        return self._view(self._lib.pca_host_track_segments(self._h), nd, 1).copy()
+
+    @property
+    def poses(self):
+        return ArrayList(self.as_array())
+
+    @poses.setter
+    def poses(self, value):
+        P = np.ascontiguousarray(np.array(value, dtype=np.float64).reshape(-1, 3))
+        D = self.seg_array()
+        self._lib.pca_host_track_set(self._h, P.ctypes.data, P.shape[0], D.ctypes.data, D.shape[0])
+
+    @property
+    def seg_dists(self):
+        return ArrayList(self.seg_array())
+
+    @seg_dists.setter
+    def seg_dists(self, value):
+        D = np.ascontiguousarray(np.array(value, dtype=np.float64).reshape(-1))
+        P = np.ascontiguousarray(self.as_array())
+        self._lib.pca_host_track_set(self._h, P.ctypes.data, P.shape[0], D.ctypes.data, D.shape[0])
+
+    def apply_transform(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        self._lib.pca_host_track_transform(self._h, T.ctypes.data)
+
+    def append(self, pose):
+        p = np.ascontiguousarray(np.asarray(pose, dtype=np.float64).reshape(3))
+        self._lib.pca_host_track_append(self._h, p.ctypes.data)
+
+    def push_segment(self):
+        if self._lib.pca_host_track_push_segment(self._h, self._C.byref(self._pl)) != 0:
+            raise IndexError('push_segment needs two poses')
+        return np.float64(self._pl.value)
+
+    def evict_beyond(self, horizon_dist, path_length):
+        return int(self._lib.pca_host_track_evict_beyond(self._h, float(horizon_dist), float(path_length)))
+
+    def incr(self):
+        out = np.empty(self._lib.pca_host_track_n_segments(self._h))
+        self._lib.pca_host_track_incr(self._h, out.ctypes.data)
+        return out
+
+    def step(self, T_new_prev, horizon_dist):
+        T = np.ascontiguousarray(T_new_prev, dtype=np.float64)
+        k = self._lib.pca_host_track_step(self._h, T.ctypes.data, float(horizon_dist), self._C.byref(self._pl))
+        pl = self._pl.value
+        return int(k), (None if pl != pl else np.float64(pl))
+
+    def trigger(self, bev_horizon, previous_idx, min_step):
+        k = self._lib.pca_host_track_trigger(self._h, float(bev_horizon), int(previous_idx), float(min_step))
+        if k == -2:
+            raise IndexError('pose index out of range')
+        return None if k < 0 else int(k)
+
+
+def _bind_c_track():
+    """CPoseTrack if the library is built, numpy's BLAS entry point is found AND a randomised run agrees with the numpy
+    form bit for bit; else None (the numpy form stays)."""
+    import os
+    if os.environ.get('PCA_HOST_TRACK', 'c') == 'numpy':
+        return None
+    lib = _c_library()
+    entry = _numpy_gemv_entry()
+    if lib is None or entry is None or not hasattr(lib, 'pca_host_track_step'):
+        return None
+    CPoseTrack._lib, CPoseTrack._gemv, CPoseTrack._blas = lib, entry[0], entry[1]
+    rng = np.random.default_rng(20261004)
+    # the per-pose (4,4)@(4,1) product: a closed form instead of a BLAS call per pose, if one reproduces numpy's bits here
+    n = 4096
+    Tm = rng.normal(size=(n, 4, 4)) * rng.choice([1e-3, 1., 1e3], size=(n, 1, 1))
+    Tm[::3, 3] = [0., 0., 0., 1.]                                     # rigid transforms' last row
+    X = np.ones((n, 4, 1))
+    X[:, :3, 0] = rng.normal(size=(n, 3)) * rng.choice([1e-2, 1., 1e2, 1e4], size=(n, 1))
+    want = np.concatenate([np.matmul(Tm[i], X[i:i + 1]) for i in range(n)])[:, :, 0]
+    got = np.empty((n, 4))
+    lib.pca_host_gemv4_mode(0)
+    for mode in (1, 2, 3, 4, 5):
+        lib.pca_host_gemv4_probe(entry[0], mode, Tm.ctypes.data, np.ascontiguousarray(X[:, :, 0]).ctypes.data, n, got.ctypes.data)
+        if np.array_equal(got, want):
+            lib.pca_host_gemv4_mode(mode)
+            break
+    # tri(n) @ d in groups of 8 rows instead of the full product, if the groups come out as numpy's full product does
+    lib.pca_host_incr_blocks(0)
+    ok = True
+    for n in (2, 7, 8, 9, 63, 64, 65, 127, 200, 201, 255, 333, 512, 1000):
+        d = np.ascontiguousarray(rng.uniform(0.2, 1.7, n))
+        want = np.matmul(np.tri(n), d)
+        out = np.empty(8)
+        for r0 in sorted({0, 8 * ((n - 1) // 8), 8 * (n // 16), 8 * (n // 24)}):
+            r1 = min(r0 + 8, n)
+            lib.pca_host_incr_probe(entry[0], d.ctypes.data, n, r0, r1, out.ctypes.data)
+            ok = ok and np.array_equal(out[:r1 - r0], want[r0:r1])
+    lib.pca_host_incr_blocks(1 if ok else 0)
+    a, b = CPoseTrack(), NumpyPoseTrack()
+    prev = 0
+    for f in range(160):
+        ang = rng.uniform(-0.05, 0.05)
+        T = np.eye(4)
+        T[:2, :2] = [[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]
+        T[:3, 3] = rng.uniform(-1.5, 0.5, 3) * [1.0, 0.05, 0.01]
+        ra, rb = a.step(T, 37.5), b.step(T, 37.5)
+        prev -= ra[0]
+        ta, tb = (a.trigger(11.0, prev, 1.0), b.trigger(11.0, prev, 1.0)) if -len(b) <= prev < len(b) else (None, None)
+        if ra != rb or ta != tb or not np.array_equal(a.as_array(), b.as_array()) \
+                or not np.array_equal(a.seg_array(), b.seg_array()) or not np.array_equal(a.incr(), b.incr()):
+            return None
+        if ta is not None:
+            prev = ta
+    return CPoseTrack
+
+
+_TRACK_CLASS = []
+
+
+def PoseTrack():
+    """The accumulator's pose track: the C form when it is available and agrees with numpy on this machine (checked once
+    per process), else the numpy form.  PCA_HOST_TRACK=numpy forces the latter."""
+    if not _TRACK_CLASS:
+        try:
+            _TRACK_CLASS.append(_bind_c_track() or NumpyPoseTrack)
+        except Exception:
+            _TRACK_CLASS.append(NumpyPoseTrack)
+    return _TRACK_CLASS[0]()
 
 
 # ----------------------------------------------------------------------------------------------

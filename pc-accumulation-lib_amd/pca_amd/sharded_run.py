@@ -35,24 +35,12 @@ def replay(Ts, accum_horizon=200., bev_horizon=80., min_spacing=1.):
     track = hl.PoseTrack()
     oldest, evicted, previous_idx, samples = [], 0, 0, []
     for f in range(Ts.shape[0]):
-        if len(track) > 0:
-            track.apply_transform(Ts[f])
-        track.append([0., 0., 0.])
-        removed = 0
-        if len(track) > 1:
-            removed = track.evict_beyond(accum_horizon, track.push_segment())
+        removed, _ = track.step(Ts[f], accum_horizon)
         evicted += removed
         oldest.append(evicted)
         previous_idx -= removed
-        if len(track) < 2:
-            continue
-        d = hl.incremental_path_dists(track.seg_array())
-        if d[-1] < bev_horizon:
-            continue
-        present_idx = int(((d - bev_horizon) > 0).argmax())
-        if d[-1] - d[present_idx] < bev_horizon:
-            continue
-        if hl.pose_dist(track.pose(previous_idx), track.pose(present_idx)) < min_spacing:
+        present_idx = track.trigger(bev_horizon, previous_idx, min_spacing)
+        if present_idx is None:
             continue
         previous_idx = present_idx
         samples.append((f, evicted + present_idx))

@@ -131,7 +131,7 @@ class SemanticPointCloudAccumulator:
         return self._track.seg_array().tolist()
 
     def get_incremental_path_dists(self) -> np.array:
-        return hl.incremental_path_dists(self._track.seg_array())
+        return self._track.incr()
 
     def get_pose(self, idx: int = None) -> np.array:
         return self._track.as_array() if idx is None else self._track.pose(idx)

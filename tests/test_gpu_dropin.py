@@ -959,3 +959,77 @@ def test_config2_shaped_stream_every_step_against_the_oracle_pipeline():
     assert np.array_equal(np.concatenate(acc.sem_pcs), ost.rows(lo))
     assert np.array_equal(np.array(acc.poses), np.array(track.poses))
     acc.store.check_status()
+
+
+def test_nuscenes_integrate_many_equals_integrate_call_by_call(golden):
+    """integrate_many of the NuScenes class (one batched K1n front + append launch, one K3 launch for all the tracker's
+    marks) leaves the state call-by-call integrate() leaves: the golden scene with retroactive dynamic marking, once as a
+    whole and once split 3 + 4, rows incl. the dynamic flags, poses, tracker, and the BEV."""
+    from PIL import Image
+
+    from nuscenes_oracle_sem_pc_accum import NuScenesOracleSemanticPointCloudAccumulator
+    g = golden('nusc_oracle')
+    F = int(g['F'])
+
+    def obs_of(k):
+        T = g[f'T_{k}']
+        return [dict(images=[Image.fromarray(im) for im in g[f'imgs_{k}']], pc=g[f'pc_{k}'], pc_cam_idx=g[f'cam_idx_{k}'],
+                     ego_at_lidar_ts=T, ego_global_x=T[0, 3], ego_global_y=T[1, 3],
+                     inst_tokens=str(g['inst_tokens'][k]).split(','), inst_cls=list(g[f'inst_cls_{k}']),
+                     inst_center=list(g[f'inst_center_{k}']))]
+    for cuts in ([F], [3, F - 3], [1, 1, F - 2]):
+        acc = NuScenesOracleSemanticPointCloudAccumulator('fake.onnx', NUSC_FILTERS, SEM_IDXS, False, dict(BEV_NUSC),
+                                                          'boston', False, None)
+        k = 0
+        for n in cuts:
+            assert acc.integrate_many([obs_of(j) for j in range(k, k + n)]) is None
+            k += n
+        assert np.array_equal(np.array([a.shape[0] for a in acc.sem_pcs]), g['sizes'])
+        assert np.array_equal(np.concatenate(acc.sem_pcs), g['sem_pcs'])          # incl. retroactive dyn flags
+        assert np.array_equal(np.array(acc.poses), g['poses'])
+        assert np.array_equal(np.array(acc.seg_dists), g['seg_dists'])
+        assert list(g['dyn_instances']) == acc.dyn_instances
+        assert len(acc.ego_global_xs) == F and acc.ts == F
+        bev = acc.generate_bev(int(g['present_idx']), 1, gen_future=True)[0]
+        check_bev(bev, g)
+        acc.store.check_status()
+
+
+def test_nuscenes_batched_k1n_full_size_ragged_frames_match_oracle():
+    """pca_nusc_sample_filter_transform_batch at BASELINE configs[2] frame size (34 720 points, 6 x 900x1600 images) with
+    ragged frames -- empty, one point, around the 512-point tile -- each with its own image stack and T_ego_world: every
+    frame's rows equal the oracle's."""
+    import torch
+    from oracle import oracle as orc
+    from pca_amd.device_store import DeviceStore
+    rng = np.random.default_rng(31)
+    ncam, H, W = 6, 900, 1600
+    sizes = [34720, 0, 1, 511, 512, 513, 34720, 2049]
+    stacks = [(rng.integers(0, 256, (ncam, H, W, 3), dtype=np.uint8), rng.integers(0, 19, (ncam, H, W)).astype(np.uint8))
+              for _ in range(2)]
+    frames, host = [], []
+    for k, n in enumerate(sizes):
+        pc = np.stack([rng.uniform(-50, 50, n), rng.uniform(-50, 50, n), rng.uniform(-2, 4, n),
+                       rng.integers(0, 256, n).astype(float), rng.uniform(1.01, W - 1.01, n), rng.uniform(1.01, H - 1.01, n),
+                       rng.integers(-1, 5, n).astype(float)], 1).reshape(n, 7)
+        cam = rng.integers(-1, ncam, n)
+        a = 0.01 * k
+        T = np.eye(4)
+        T[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        T[:3, 3] = [1.0 * k, -0.3 * k, 0.02 * k]
+        imgs, sems = stacks[k % 2]
+        host.append((pc, cam, imgs, sems, T))
+    dev_stacks = [(torch.from_numpy(i).cuda(), torch.from_numpy(s).cuda()) for i, s in stacks]
+    for k, (pc, cam, imgs, sems, T) in enumerate(host):
+        frames.append(dict(pc=torch.from_numpy(pc).cuda(), cam_idx=torch.from_numpy(cam).cuda(), imgs=dev_stacks[k % 2][0],
+                           sems=dev_stacks[k % 2][1], T=T))
+    st = DeviceStore(capacity=sum(sizes) + 16, max_frames=16, intensity_div255=True)
+    st.append_nusc_many(frames[:3], NUSC_FILTERS)
+    st.append_nusc_many(frames[3:], NUSC_FILTERS)
+    st.check_status()
+    got = st.frame_rows()
+    assert len(got) == len(sizes)
+    for (pc, cam, imgs, sems, T), rows in zip(host, got):
+        ost = orc.Store(max(pc.shape[0], 1), intensity_div255=True)
+        orc.nusc_sample_filter_transform(ost, pc, cam, imgs, sems, T, NUSC_FILTERS)
+        assert np.array_equal(rows, ost.rows())

@@ -1,5 +1,6 @@
 """Host-side helpers that have no golden fixture of their own (CPU, no GPU needed)."""
 import numpy as np
+import pytest
 
 
 def test_conv_semantic_ids_lookup_equals_sequential_masking():
@@ -23,3 +24,73 @@ def test_conv_semantic_ids_lookup_equals_sequential_masking():
     assert np.array_equal(conv_semantic_ids(a.copy(), chain), sequential(a.copy(), chain))
     wide = rng.integers(0, 50, (1000, 3)).astype(np.int16)                 # not (N,1): whole rows are assigned
     assert np.array_equal(conv_semantic_ids(wide.copy(), m), sequential(wide.copy(), m))
+
+
+def _random_T(rng):
+    a = rng.uniform(-0.06, 0.06)
+    T = np.eye(4)
+    T[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+    T[:3, 3] = rng.uniform(-1.6, 0.4, 3) * [1.0, 0.05, 0.01]
+    return T
+
+
+def test_c_pose_track_equals_the_numpy_expressions_bit_for_bit():
+    """pca_host_track_* (one C call per integrate()) against the numpy form that restates the reference's expressions:
+    poses, segment distances, path length, evictions, incremental path distances and the driver's sample trigger --
+    every value bit-equal over long random drives, incl. a track set from Python lists and negative previous_idx."""
+    from pca_amd import host_logic as hl
+    cls = hl._bind_c_track()
+    assert cls is hl.CPoseTrack, 'the C track did not bind (library not built, or numpy\'s BLAS entry point not found)'
+    rng = np.random.default_rng(77)
+    for horizon, bev_h in ((37.5, 11.0), (200.0, 80.0), (5.0, 1.5)):
+        c, n = hl.CPoseTrack(), hl.NumpyPoseTrack()
+        prev = 0
+        for f in range(420):
+            T = _random_T(rng)
+            rc, rn = c.step(T, horizon), n.step(T, horizon)
+            assert rc == rn
+            prev -= rc[0]
+            if -len(n) <= prev < len(n):
+                tc, tn = c.trigger(bev_h, prev, 1.0), n.trigger(bev_h, prev, 1.0)
+                assert tc == tn
+                if tn is not None:
+                    prev = tn
+            assert len(c) == len(n)
+            assert np.array_equal(c.as_array(), n.as_array())
+            assert np.array_equal(c.seg_array(), n.seg_array())
+            if f % 7 == 0:
+                assert np.array_equal(c.incr(), n.incr())
+                assert c.poses == n.poses and c.seg_dists == n.seg_dists
+    # the piecewise API the reference's methods map to, and assignment from lists
+    c, n = hl.CPoseTrack(), hl.NumpyPoseTrack()
+    for tr in (c, n):
+        tr.poses = [[1., 2., 3.], [2., 2.5, 3.], [3.5, 2., 3.1]]
+        tr.seg_dists = [1.1, 1.6]
+        tr.apply_transform(_random_T(np.random.default_rng(5)))
+        tr.append([0., 0., 0.])
+        pl = tr.push_segment()
+        tr.evict_beyond(2.0, pl)
+    assert np.array_equal(c.as_array(), n.as_array()) and np.array_equal(c.seg_array(), n.seg_array())
+    assert np.array_equal(c.pose(-1), n.pose(-1)) and len(c) == len(n)
+    with pytest.raises(IndexError):
+        c.pose(17)
+
+
+def test_c_pose_track_full_product_fallbacks_agree():
+    """With the closed form of the per-pose product and the row groups switched off (what a machine whose BLAS kernels
+    differ gets), the C track still equals numpy: those paths call numpy's own dgemv."""
+    from pca_amd import host_logic as hl
+    assert hl._bind_c_track() is hl.CPoseTrack
+    lib = hl.CPoseTrack._lib
+    mode, blocks = lib.pca_host_gemv4_mode(0), lib.pca_host_incr_blocks(0)
+    try:
+        rng = np.random.default_rng(3)
+        c, n = hl.CPoseTrack(), hl.NumpyPoseTrack()
+        for f in range(150):
+            T = _random_T(rng)
+            assert c.step(T, 30.0) == n.step(T, 30.0)
+            assert c.trigger(9.0, 0, 0.5) == n.trigger(9.0, 0, 0.5)
+        assert np.array_equal(c.as_array(), n.as_array()) and np.array_equal(c.incr(), n.incr())
+    finally:
+        lib.pca_host_gemv4_mode(mode)
+        lib.pca_host_incr_blocks(blocks)

@@ -40,7 +40,7 @@ from pca_amd import host_logic as hl, device_store  # noqa: E402
 from bev_generator import bev_generator as bg, sem_bev  # noqa: E402
 K = kitti360_sem_pc_accum.Kitti360SemanticPointCloudAccumulator
 S = sem_pc_accum.SemanticPointCloudAccumulator
-for owner, names in ((K, ['integrate', '_frame_tensors']), (S, ['update_poses', 'update_sem_pcs', 'remove_observations', '_window_inputs', '_after_integrate', 'get_incremental_path_dists']),
+for owner, names in ((K, ['integrate', '_frame_tensors']), (S, ["update_poses", "update_sem_pcs", "remove_observations", "_window_inputs", "_after_integrate", "get_incremental_path_dists", "_run_bev"]),
                      (device_store.DeviceStore, ['append_kitti', 'bev', 'retransform', 'evict', 'max_window_points', 'c_store']),
                      (bg.BEVGenerator, ['generate', '_raster_params', 'rasterise']), (sem_bev.SemBEVGenerator, ['generate_bev']),
                      (hl, ['transform_ego_split', 'incremental_path_dists', 'heading_rot_ang', 'rotation_matrix_3d', 'pose_dist']),
