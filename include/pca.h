@@ -269,6 +269,21 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
                            int64_t workspace_bytes, double *planes /*dev*/, uint16_t *planes_f16 /*dev*/,
                            double *extra_planes /*dev, may be NULL*/, void *stream);
 
+/* Several rasters of ONE store in one launch of each kernel: the sweep over present_idx of a finished scene
+ * (run_nuscenes_bev_gen.py:245-271 walks present_idx over a store that no longer changes) or the bev_num augmented samples
+ * of one window (kitti360_sem_pc_accum.py:236-241, a multiprocessing.Pool in the reference).  Each job is what one
+ * pca_bev_generate call takes (slots, parameters, output planes); no owed transforms; workspace:
+ * n_jobs * round_up(pca_bev_workspace_bytes(max_points, px), 256) + 256 bytes.  Results equal n_jobs single calls. */
+typedef struct {
+    int32_t slot_begin, slot_split, slot_end, reserved;
+    pca_bev_params prm;
+    double *planes;            /* dev [21,px,px] f64 or NULL */
+    uint16_t *planes_f16;      /* dev [21,px,px] f16 or NULL */
+} pca_bev_job;
+int pca_bev_generate_many(pca_ctx *ctx, const pca_store *store, const double *intensity64 /*dev or NULL*/,
+                          const int64_t *frame_off /*dev*/, const pca_bev_job *jobs, int n_jobs, int64_t max_points,
+                          void *workspace /*dev*/, int64_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Input normalisation of the semseg CNN on the device.  Replaces utils/onnx_utils.py:26-29, :35-36
  *     (torchvision ToTensor + Normalize on the host): out[c][y][x] = (rgb[y][x][c] / 255 - mean[c]) / std[c] in IEEE f32.

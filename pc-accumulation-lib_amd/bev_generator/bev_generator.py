@@ -86,11 +86,42 @@ class BEVGenerator(ABC):
         self._frame = None
         self._device_only = False
         self._out16 = None
+        self._defer = None                  # a list while rasters are being collected for ONE launch (raster_batch)
 
     def __getstate__(self):                 # device handles never travel through pickle
         d = dict(self.__dict__)
         d['_tmp'] = {}
+        d['_defer'] = None
         return d
+
+    class _RasterBatch:
+        def __init__(self, gen):
+            self.gen = gen
+
+        def __enter__(self):
+            self.gen._defer = []
+            return self
+
+        def __exit__(self, exc_type, exc, tb):
+            jobs, self.gen._defer = self.gen._defer, None
+            if exc_type is None and jobs:
+                store = jobs[0][0]
+                assert all(j[0] is store for j in jobs)
+                outs = [j[2] for j in jobs]
+                base = outs[0]._base if outs[0]._base is not None else outs[0]
+                px = int(jobs[0][1][1].px)
+                contiguous = all(o.data_ptr() == base.data_ptr() + k * 21 * px * px * 2 for k, o in enumerate(outs))
+                if len(jobs) > 1 and contiguous and base.numel() >= len(jobs) * 21 * px * px:
+                    store.bev_many([j[1] for j in jobs], base.view(-1)[:len(jobs) * 21 * px * px].view(len(jobs), 21, px, px))
+                else:                           # a single raster (owed transforms ride along), or outputs scattered in memory
+                    for _, (split, prm, first, last), out in jobs:
+                        store.bev(split, prm, first_frame=first, last_frame=last, out16=out)
+            return False
+
+    def raster_batch(self):
+        """Context manager: device_only generate() calls made inside it (with `out=` slices of one [k,21,px,px] tensor, no
+        warp) only RECORD their raster; leaving the block launches all of them at once (DeviceStore.bev_many)."""
+        return BEVGenerator._RasterBatch(self)
 
     # ------------------------------------------------------------------ raster (device) ----
     def _raster_params(self, origin, rot_mat, dx, dy, aug_view_size, intensity_div255):
@@ -128,6 +159,10 @@ class BEVGenerator(ABC):
         if isinstance(pc_present, WindowPart):
             w = pc_present.window
             prm = self._raster_params(w.origin, rot_mat, dx, dy, aug_view_size, w.store.intensity_div255)
+            if self._defer is not None and out16 is not None and not want_f64 and not w.future_is_present:
+                from pca_amd._lib import PcaBevParams
+                self._defer.append((w.store, (w.split, PcaBevParams.from_buffer_copy(prm), w.first, w.last), out16))
+                return out16, None
             return w.store.bev(w.split, prm, want_f64=want_f64, first_frame=w.first, last_frame=w.last, out16=out16)
         # host arrays: 'present' and 'future' share one launch; 'full' is an independent input in the
         # reference's interface, so it gets its own launch (as the present set of a second window)

@@ -246,7 +246,7 @@ __device__ __forceinline__ uint32_t view_key_lean(const ViewConst &c, double X, 
 __device__ unsigned long long g_dbg_stamps[1024][8];   // PCA_BEV_DBG=8|16|32: per-tile / per-chunk phase stamps (diagnostics)
 #define BIN_STAMP(slot) do { if ((a.dbg & 32) && threadIdx.x == 0 && blockIdx.x < 1024) g_dbg_stamps[blockIdx.x][slot] = wall_clock64(); } while (0)
 template <bool I64>
-__global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void bev_tile_bin(const BevArgs a)
+__device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
 {
     constexpr int REG_P = I64 ? 0 : 12;
     constexpr int UNR = 4;          // independent points per thread and iteration (memory-level parallelism)
@@ -825,7 +825,7 @@ __device__ __forceinline__ void cells_drain(const BevArgs &a, TileLds &L, unsign
         if (__hip_atomic_fetch_add(&a.heavy[HQ_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
             __threadfence();
             for (int c = 0; c < HQ_CLASSES; ++c) n += __hip_atomic_load(&a.heavy[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (n != a.heavy_hint_known) *a.heavy_hint = n;
+            if (a.heavy_hint && n != a.heavy_hint_known) *a.heavy_hint = n;
         }
         s_drain_n = n;
     }
@@ -897,7 +897,7 @@ __device__ __forceinline__ void cells_drain(const BevArgs &a, TileLds &L, unsign
 
 #define DBG_STAMP(bit, slot) do { if ((a.dbg & (bit)) && threadIdx.x == 0 && tile < 1024) g_dbg_stamps[tile][slot] = wall_clock64(); } while (0)
 template <bool I64>
-__global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a)
+__device__ __forceinline__ void bev_tile_cells_body(const BevArgs &a)
 {
     __shared__ TileLds L;
     __shared__ __align__(16) unsigned char s_buf[RGB_CAP * 4 > OUT_STAGE_BYTES ? RGB_CAP * 4 : OUT_STAGE_BYTES];
@@ -1067,7 +1067,7 @@ __device__ __forceinline__ void tile_cell_medians32(TileStats &S, uint32_t (*his
 }
 
 template <bool I64>
-__global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs a)
+__device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
 {
     unsigned long long t_begin = wall_clock64();
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs 
     const uint32_t n_heavy = s_cls[HQ_CLASSES];
     // the count goes to host-visible memory only when it differs from what the host already knows (a write over PCIe
     // holds the kernel's end back by microseconds; in steady state nothing changes)
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n_heavy != a.heavy_hint_known) *a.heavy_hint = n_heavy;
+    if (a.heavy_hint && blockIdx.x == 0 && threadIdx.x == 0 && n_heavy != a.heavy_hint_known) *a.heavy_hint = n_heavy;
     // Work items are (tile, half of its cells): the two halves of a tile are independent (every statistic is per cell),
     // so a 12 000-record tile is two items of half the time each, drawn one at a time by whichever workgroup is free --
     // the kernel ends with its slowest ITEM, and most CUs would otherwise idle behind the few densest tiles.
@@ -1169,6 +1169,34 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs 
     }
 }
 
+// ---- the kernels: one sample per launch (arguments in the kernel-argument segment), or many (pca_bev_generate_many:
+// blockIdx.y = sample, its arguments read from a device array -- a NuScenes-size window is 108 level-1 workgroups and
+// three dependent launches of pure latency; S samples in one launch of each kernel take little longer than one) ----
+template <bool I64>
+__global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void bev_tile_bin(const BevArgs a) { bev_tile_bin_body<I64>(a); }
+template <bool I64>
+__global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a) { bev_tile_cells_body<I64>(a); }
+template <bool I64>
+__global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs a) { bev_tile_cells_heavy_body<I64>(a); }
+template <bool I64>
+__global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void bev_tile_bin_many(const BevArgs *__restrict__ args)
+{
+    const BevArgs a = args[blockIdx.y];
+    if ((int)blockIdx.x < a.G) bev_tile_bin_body<I64>(a);
+}
+template <bool I64>
+__global__ __launch_bounds__(C_THREADS) void bev_tile_cells_many(const BevArgs *__restrict__ args)
+{
+    const BevArgs a = args[blockIdx.y];
+    bev_tile_cells_body<I64>(a);
+}
+template <bool I64>
+__global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy_many(const BevArgs *__restrict__ args)
+{
+    const BevArgs a = args[blockIdx.y];
+    bev_tile_cells_heavy_body<I64>(a);
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
@@ -1216,13 +1244,13 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
                                   extra_planes, stream);
 }
 
-int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *intensity64, const int64_t *frame_off,
-                           int slot_begin, int slot_split, int slot_end, int64_t max_points, const pca_bev_params *prm,
-                           const double *pending_Ts, const int *pending_slot_ends, int n_pending, int write_back,
-                           void *workspace, int64_t workspace_bytes, double *planes, uint16_t *planes_f16,
-                           double *extra_planes, void *stream)
+// Checks one raster's arguments and fills the kernels' argument block (everything but the heavy-tile bookkeeping)
+static int bev_prepare(pca_ctx *ctx, const pca_store *store, const double *intensity64, const int64_t *frame_off,
+                       int slot_begin, int slot_split, int slot_end, int64_t max_points, const pca_bev_params *prm,
+                       const double *pending_Ts, const int *pending_slot_ends, int n_pending, int write_back,
+                       void *workspace, int64_t workspace_bytes, double *planes, uint16_t *planes_f16,
+                       double *extra_planes, BevArgs &a)
 {
-    if (!ctx) return -1;
     if (n_pending < 0 || n_pending > PCA_BEV_MAX_CHAIN || (n_pending > 0 && (!pending_Ts || !pending_slot_ends))) {
         ctx->err = "bev: bad chain of owed transforms";
         return -1;
@@ -1235,12 +1263,8 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
         return -1;
     }
     if (!(slot_begin <= slot_split && slot_split <= slot_end)) { ctx->err = "bev: need slot_begin <= slot_split <= slot_end"; return -1; }
-    if (max_points < 1) max_points = 1;
     if (max_points >= (1ll << 32)) { ctx->err = "bev: window too large for 32-bit positions"; return -1; }
     if (workspace_bytes < pca_bev_workspace_bytes(max_points, prm->px)) { ctx->err = "bev: workspace too small"; return -1; }
-    hipStream_t s = (hipStream_t)stream;
-    PCA_CHECK(ctx, hipSetDevice(ctx->device));
-    BevArgs a;
     a.st = *store;
     a.intensity64 = intensity64;
     a.frame_off = frame_off;
@@ -1272,19 +1296,6 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
     a.extra = extra_planes;
     { static int hm = -1; if (hm < 0) { const char *e = getenv("PCA_BEV_HEAVY_MIN"); hm = e ? atoi(e) : HEAVY_MIN_DEFAULT; if (hm < 1 || hm > RGB_CAP) hm = RGB_CAP; } a.heavy_min = hm; }
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("PCA_BEV_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
-    const size_t lds = (size_t)a.T * 8;                     // bev_tile_bin: histogram + cursors
-    static bool lds_set = false;                            // > 64 KiB of dynamic LDS has to be asked for once
-    if (!lds_set) {
-        PCA_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&bev_tile_cells_heavy<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAVY_LDS_BYTES));
-        PCA_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&bev_tile_cells_heavy<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAVY_LDS_BYTES));
-        PCA_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&bev_tile_bin<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        PCA_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&bev_tile_bin<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        lds_set = true;
-    }
     a.status = ctx->ticket + 1;
     {
         auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
@@ -1292,6 +1303,44 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
         while (m > 1 && gcd(m, a.T) != 1) m -= 2;
         a.tile_mult = m < 1 ? 1 : m;
     }
+    a.heavy_hint = nullptr; a.heavy_hint_known = 0; a.heavy_launched = 1;
+    return 0;
+}
+
+static int bev_set_lds_attributes(pca_ctx *ctx)
+{
+    static bool lds_set = false;                            // > 64 KiB of dynamic LDS has to be asked for once
+    if (lds_set) return 0;
+#define PCA_BEV_LDS_ATTR(k, bytes) PCA_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
+    PCA_BEV_LDS_ATTR(bev_tile_cells_heavy<false>, HEAVY_LDS_BYTES);
+    PCA_BEV_LDS_ATTR(bev_tile_cells_heavy<true>, HEAVY_LDS_BYTES);
+    PCA_BEV_LDS_ATTR(bev_tile_cells_heavy_many<false>, HEAVY_LDS_BYTES);
+    PCA_BEV_LDS_ATTR(bev_tile_cells_heavy_many<true>, HEAVY_LDS_BYTES);
+    PCA_BEV_LDS_ATTR(bev_tile_bin<false>, 128 * 1024);
+    PCA_BEV_LDS_ATTR(bev_tile_bin<true>, 128 * 1024);
+    PCA_BEV_LDS_ATTR(bev_tile_bin_many<false>, 128 * 1024);
+    PCA_BEV_LDS_ATTR(bev_tile_bin_many<true>, 128 * 1024);
+#undef PCA_BEV_LDS_ATTR
+    lds_set = true;
+    return 0;
+}
+
+int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *intensity64, const int64_t *frame_off,
+                           int slot_begin, int slot_split, int slot_end, int64_t max_points, const pca_bev_params *prm,
+                           const double *pending_Ts, const int *pending_slot_ends, int n_pending, int write_back,
+                           void *workspace, int64_t workspace_bytes, double *planes, uint16_t *planes_f16,
+                           double *extra_planes, void *stream)
+{
+    if (!ctx) return -1;
+    if (max_points < 1) max_points = 1;
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    BevArgs a;
+    if (bev_prepare(ctx, store, intensity64, frame_off, slot_begin, slot_split, slot_end, max_points, prm, pending_Ts,
+                    pending_slot_ends, n_pending, write_back, workspace, workspace_bytes, planes, planes_f16, extra_planes, a))
+        return -1;
+    const size_t lds = (size_t)a.T * 8;                     // bev_tile_bin: histogram + cursors
+    if (bev_set_lds_attributes(ctx)) return -1;
     // one resident workgroup per CU draws from the queue -- when the previous call had no heavy tile (uniform data)
     // only a few are launched: any number of them drains the queue, and 256 idle 110-KiB workgroups cost ~5 us
     const int heavy_grid = a.T < ctx->n_cu ? a.T : ctx->n_cu;
@@ -1316,6 +1365,68 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
         if (a.heavy_launched) PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, bev_tile_cells_heavy<false>, dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a);
     }
     if (ctx->profiling == 2) pca_prof_end(ctx, s);
+    PCA_CHECK(ctx, hipGetLastError());
+    return 0;
+}
+
+// Several rasters of ONE store in one launch of each kernel (blockIdx.y = sample): the sweep over present_idx of a
+// finished scene (run_nuscenes_bev_gen.py:245-271), or the bev_num augmented samples of one window
+// (kitti360_sem_pc_accum.py:236-241).  No owed transforms (the caller flushes them first); every sample has its own
+// workspace slice of pca_bev_workspace_bytes(max_points, px) bytes and its own output planes.
+int pca_bev_generate_many(pca_ctx *ctx, const pca_store *store, const double *intensity64, const int64_t *frame_off,
+                          const pca_bev_job *jobs, int n_jobs, int64_t max_points, void *workspace,
+                          int64_t workspace_bytes, void *stream)
+{
+    if (!ctx) return -1;
+    if (!jobs || n_jobs < 1) { ctx->err = "bev: bad job list"; return -1; }
+    if (n_jobs > 65535) { ctx->err = "bev: at most 65535 rasters per call"; return -1; }
+    if (max_points < 1) max_points = 1;
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    const int px = jobs[0].prm.px;
+    const int64_t per = (pca_bev_workspace_bytes(max_points, px) + 255) & ~255ll;
+    if (workspace_bytes < per * n_jobs + 256) { ctx->err = "bev: workspace too small for this many rasters"; return -1; }
+    // argument blocks: built in pinned memory, one asynchronous upload
+    const int64_t up_bytes = (int64_t)sizeof(BevArgs) * n_jobs;
+    if (ctx->bevm_busy) { PCA_CHECK(ctx, hipEventSynchronize(ctx->bevm_ev)); ctx->bevm_busy = false; }
+    if (up_bytes > ctx->bevm_cap) {
+        if (ctx->bevm_pin) PCA_CHECK(ctx, hipHostFree(ctx->bevm_pin));
+        if (ctx->bevm_dev) { PCA_CHECK(ctx, hipStreamSynchronize(s)); PCA_CHECK(ctx, hipFree(ctx->bevm_dev)); }
+        ctx->bevm_pin = nullptr; ctx->bevm_dev = nullptr; ctx->bevm_cap = 0;
+        PCA_CHECK(ctx, hipHostMalloc(&ctx->bevm_pin, (size_t)(2 * up_bytes)));
+        PCA_CHECK(ctx, hipMalloc(&ctx->bevm_dev, (size_t)(2 * up_bytes)));
+        ctx->bevm_cap = 2 * up_bytes;
+    }
+    if (!ctx->bevm_ev) PCA_CHECK(ctx, hipEventCreateWithFlags(&ctx->bevm_ev, hipEventDisableTiming));
+    BevArgs *ha = reinterpret_cast<BevArgs *>(ctx->bevm_pin);
+    char *ws = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    int G = 0, T = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        const pca_bev_job &j = jobs[k];
+        if (j.prm.px != px) { ctx->err = "bev: the rasters of one call share the grid size"; return -1; }
+        if (bev_prepare(ctx, store, intensity64, frame_off, j.slot_begin, j.slot_split, j.slot_end, max_points, &j.prm, nullptr,
+                        nullptr, 0, 1, ws + per * k, per, j.planes, j.planes_f16, nullptr, ha[k]))
+            return -1;
+        G = ha[k].G; T = ha[k].T;
+    }
+    if (bev_set_lds_attributes(ctx)) return -1;
+    const size_t lds = (size_t)T * 8;
+    const int heavy_grid = T < ctx->n_cu ? T : ctx->n_cu;
+    if (ctx->profiling) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
+    PCA_CHECK(ctx, hipMemcpyAsync(ctx->bevm_dev, ctx->bevm_pin, (size_t)up_bytes, hipMemcpyHostToDevice, s));
+    PCA_CHECK(ctx, hipEventRecord(ctx->bevm_ev, s));
+    ctx->bevm_busy = true;
+    const BevArgs *da = reinterpret_cast<const BevArgs *>(ctx->bevm_dev);
+    if (intensity64) {
+        hipLaunchKernelGGL(bev_tile_bin_many<true>, dim3(G, n_jobs), dim3(AB_THREADS), lds, s, da);
+        hipLaunchKernelGGL(bev_tile_cells_many<true>, dim3(T, n_jobs), dim3(C_THREADS), 0, s, da);
+        hipLaunchKernelGGL(bev_tile_cells_heavy_many<true>, dim3(heavy_grid, n_jobs), dim3(H_THREADS), HEAVY_LDS_BYTES, s, da);
+    } else {
+        hipLaunchKernelGGL(bev_tile_bin_many<false>, dim3(G, n_jobs), dim3(AB_THREADS), lds, s, da);
+        hipLaunchKernelGGL(bev_tile_cells_many<false>, dim3(T, n_jobs), dim3(C_THREADS), 0, s, da);
+        hipLaunchKernelGGL(bev_tile_cells_heavy_many<false>, dim3(heavy_grid, n_jobs), dim3(H_THREADS), HEAVY_LDS_BYTES, s, da);
+    }
+    if (ctx->profiling) pca_prof_end(ctx, s);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }

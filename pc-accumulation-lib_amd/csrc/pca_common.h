@@ -42,6 +42,10 @@ struct pca_ctx {
     int64_t k1n_pin_cap = 0;
     hipEvent_t k1n_ev = nullptr;
     bool k1n_busy = false;
+    void *bevm_pin = nullptr, *bevm_dev = nullptr;   // argument blocks of pca_bev_generate_many (pinned staging, device copy)
+    int64_t bevm_cap = 0;
+    hipEvent_t bevm_ev = nullptr;
+    bool bevm_busy = false;
     void *k1_tiny = nullptr;          // dev: 4-byte copies of images smaller than the 4-byte colour gather
     int64_t k1_tiny_cap = 0;
     void *k1_ws[2] = {nullptr, nullptr};   // dev: counts / kept records of K1's split form, one per sub-batch in flight

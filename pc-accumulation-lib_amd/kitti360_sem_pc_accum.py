@@ -82,37 +82,55 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
 
     # ---- device inputs -------------------------------------------------------------------------
     def _frame_tensors(self, rgb, pc, sem_gt):
-        """Uploads one observation (or passes cuda tensors through).  Returns (frame dict, semseg, H, W)."""
+        """Uploads one observation (or passes cuda tensors through).  Returns (frame dict, semseg, H, W).  Host arrays go
+        through the pinned staging of pca_amd.ingest.PinnedUploader: all of an observation's arrays in ONE call, their
+        host-side copies side by side."""
         import torch
         dev = self.store.device
+        dtype_np = {torch.float32: np.float32, torch.uint8: np.uint8}
+        want, host = {}, []                     # name -> device tensor / position in `host`
 
-        def up(a, dtype, kind):
+        def up(name, a, dtype):
             a = getattr(a, 'dev', a)             # pca_amd.ingest.DeviceImage
             if isinstance(a, torch.Tensor):
-                return a.to(device=dev, dtype=dtype).contiguous()
-            if self._uploader is None:
-                from pca_amd.ingest import PinnedUploader
-                self._uploader = PinnedUploader(dev)
-            return self._uploader(kind, np.ascontiguousarray(a, dtype=dtype_np[dtype]))
+                if a.device != dev or a.dtype != dtype or not a.is_contiguous():
+                    a = a.to(device=dev, dtype=dtype).contiguous()
+                want[name] = a
+            else:
+                want[name] = len(host)
+                host.append((name, np.ascontiguousarray(a, dtype=dtype_np[dtype])))
 
-        dtype_np = {torch.float32: np.float32, torch.uint8: np.uint8}
-        frame = {'pts': up(pc, torch.float32, 'pts')}
+        up('pts', pc, torch.float32)
         semseg = None
         if sem_gt is None:
             # (np.asarray: a PIL image is converted as the reference's np.array(rgb) does, an ndarray is not copied again)
             img = rgb if isinstance(rgb, torch.Tensor) or hasattr(rgb, 'dev') else np.asarray(rgb)
-            frame['rgb'] = up(img, torch.uint8, 'rgb')
+            up('rgb', img, torch.uint8)
             # a model that works on the device gets the uploaded image: one H2D serves the CNN and K1, and its class map
             # (utils.onnx_utils.DeviceMap) goes to K1 without ever visiting the host
-            feed = frame['rgb'] if getattr(self.semseg_model, 'accepts_device', False) else rgb
-            semseg = self.semseg_model.pred(feed)[0, 0]
-            frame['sem'] = up(semseg, torch.uint8, 'sem')
-            H, W = frame['sem'].shape
+            if getattr(self.semseg_model, 'accepts_device', False):
+                if not isinstance(want['rgb'], torch.Tensor):
+                    want['rgb'] = self._upload(host[want['rgb']:want['rgb'] + 1])[0]
+                    host.pop()
+                semseg = self.semseg_model.pred(want['rgb'])[0, 0]
+            else:
+                semseg = self.semseg_model.pred(rgb)[0, 0]
+            up('sem', semseg, torch.uint8)
         else:
             sg = sem_gt if isinstance(sem_gt, torch.Tensor) else np.asarray(sem_gt)[:, -1]
-            frame['sem_gt'] = up(sg, torch.uint8, 'sem_gt')       # trainIds 0..18 and 255
-            H = W = 1
+            up('sem_gt', sg, torch.uint8)       # trainIds 0..18 and 255
+        if host:
+            for (name, _), t in zip(host, self._upload(host)):
+                want[name] = t
+        frame = want
+        H, W = tuple(frame['sem'].shape) if sem_gt is None else (1, 1)
         return frame, semseg, H, W
+
+    def _upload(self, items):
+        if self._uploader is None:
+            from pca_amd.ingest import PinnedUploader
+            self._uploader = PinnedUploader(self.store.device)
+        return self._uploader.upload_many(items)
 
     # ---- integrate -----------------------------------------------------------------------------
     def integrate(self, observations: list):

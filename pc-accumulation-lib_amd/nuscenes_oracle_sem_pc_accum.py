@@ -186,12 +186,26 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
         return out
 
     # ---- BEV -----------------------------------------------------------------------------------
-    def generate_bev(self, present_idx: int = None, bev_num: int = 1, gen_future: bool = False):
+    def _window_inputs_for(self, present_idx, gen_future):
         others = self.get_split_dyn_obj_trajs(present_idx)
         lanes = self.gt_lane_poses if self.get_gt_lanes else None
-        pcs, trajs = self._window_inputs(present_idx, gen_future, others, lanes)
-        self.store.check_status()
+        return self._window_inputs(present_idx, gen_future, others, lanes)
+
+    def generate_bev(self, present_idx: int = None, bev_num: int = 1, gen_future: bool = False):
+        pcs, trajs = self._window_inputs_for(present_idx, gen_future)
+        self._check_status_once()
         return self._run_bev(pcs, trajs, bev_num)
+
+    def generate_bev_many(self, present_idxs, gen_future: bool = True):
+        self._check_status_once()
+        return super().generate_bev_many(present_idxs, gen_future)
+
+    def _check_status_once(self):
+        """The reference asserts on a pixel coordinate outside the image inside integrate(); here the kernels raise a status
+        bit that is read -- one stream synchronisation -- before the first BEV after new frames, not before every sample."""
+        if getattr(self, '_status_checked_at', -1) != self.ts:
+            self.store.check_status()
+            self._status_checked_at = self.ts
 
     @staticmethod
     def get_tf_pose(inst_tf: np.array) -> np.array:

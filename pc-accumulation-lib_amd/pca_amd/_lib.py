@@ -20,7 +20,7 @@ EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error',
            'pca_kitti_project_sample_filter', 'pca_kitti_project_sample_filter_ex',
            'pca_nusc_sample_filter_transform', 'pca_nusc_sample_filter_transform_ex', 'pca_nusc_sample_filter_transform_batch', 'pca_sample_bilinear', 'pca_nusc_project_cams', 'pca_retransform', 'pca_retransform_batch_tail',
            'pca_mark_dynamic',
-           'pca_bev_workspace_bytes', 'pca_bev_generate', 'pca_bev_generate_ex', 'pca_bev_generate_chain', 'pca_bev_warp', 'pca_image_to_nchw_f32', 'pca_voxel_dedup_workspace_bytes', 'pca_voxel_dedup', 'pca_icp_workspace_bytes', 'pca_icp_register', 'pca_host_ego_to_grid',
+           'pca_bev_workspace_bytes', 'pca_bev_generate', 'pca_bev_generate_ex', 'pca_bev_generate_chain', 'pca_bev_generate_many', 'pca_bev_warp', 'pca_image_to_nchw_f32', 'pca_voxel_dedup_workspace_bytes', 'pca_voxel_dedup', 'pca_icp_workspace_bytes', 'pca_icp_register', 'pca_host_ego_to_grid',
            'pca_host_gemv4_probe', 'pca_host_gemv4_mode', 'pca_host_incr_probe', 'pca_host_incr_blocks', 'pca_host_track_create', 'pca_host_track_destroy', 'pca_host_track_len', 'pca_host_track_n_segments',
            'pca_host_track_poses', 'pca_host_track_segments', 'pca_host_track_set', 'pca_host_track_transform',
            'pca_host_track_append', 'pca_host_track_push_segment', 'pca_host_track_incr', 'pca_host_track_evict_beyond',
@@ -53,6 +53,11 @@ class PcaBevParams(C.Structure):
                 ('int_sep_scaler', C.c_double), ('int_mid_threshold', C.c_double), ('rgb_fill', C.c_double),
                 ('px', C.c_int32), ('road_class', C.c_int32), ('dynobj_mask', C.c_uint64 * 4),
                 ('intensity_div255', C.c_int32), ('pad', C.c_int32)]
+
+
+class PcaBevJob(C.Structure):
+    _fields_ = [('slot_begin', C.c_int32), ('slot_split', C.c_int32), ('slot_end', C.c_int32), ('reserved', C.c_int32),
+                ('prm', PcaBevParams), ('planes', C.c_void_p), ('planes_f16', C.c_void_p)]
 
 
 def class_mask(classes):
@@ -131,6 +136,7 @@ def load():
     lib.pca_image_to_nchw_f32.argtypes = [vp, vp, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp]
     a = list(lib.pca_bev_generate_ex.argtypes)
     lib.pca_bev_generate_chain.argtypes = a[:9] + [vp, vp, i32, i32] + a[11:]
+    lib.pca_bev_generate_many.argtypes = [vp, C.POINTER(PcaStore), vp, vp, C.POINTER(PcaBevJob), i32, i64, vp, i64, vp]
     lib.pca_bev_warp.argtypes = [vp, vp, vp, i32, i32, C.c_double, C.c_double, C.c_double, C.c_double, vp]
     lib.pca_voxel_dedup_workspace_bytes.restype = C.c_int64
     lib.pca_voxel_dedup_workspace_bytes.argtypes = [i64, i32]

@@ -42,6 +42,7 @@ class DeviceStore:
         self._pending = []       # [(T 16 doubles, end slot)], oldest first: re-transforms owed to slots [head, end slot)
         self._k1_cache = None
         self._ws = None
+        self._ws_many = None
         self._ws_points, self._ws_px = 0, 0
         self._dedup_ws = None
 
@@ -363,6 +364,35 @@ class DeviceStore:
         if self._pending and write_back:
             self._pending = []                 # only now: a failed call above leaves the owed re-transforms owed
         return p16, p64
+
+    def bev_many(self, jobs, out16):
+        """jobs: [(split_frame, prm, first_frame, last_frame | None)]; out16: cuda float16 [len(jobs),21,px,px].  All rasters
+        in ONE launch of each kernel (pca_bev_generate_many): equal to len(jobs) bev() calls.  Owed transforms are applied
+        first (K2)."""
+        ctx, lib = self.ctx, self.ctx.lib
+        n = len(jobs)
+        if n == 0:
+            return out16
+        self.flush_pending()
+        px = int(jobs[0][1].px)
+        assert out16.dtype == torch.float16 and out16.is_contiguous() and tuple(out16.shape) == (n, 21, px, px)
+        max_points = self.max_window_points()
+        per = (int(lib.pca_bev_workspace_bytes(max_points, px)) + 255) & ~255
+        need = per * n + 512
+        if self._ws_many is None or self._ws_many.numel() < need:
+            self._ws_many = torch.empty(int(need * 1.25), dtype=torch.uint8, device=self.device)
+        cj = (_lib.PcaBevJob * n)()
+        plane_bytes = 21 * px * px * 2
+        for k, (split, prm, first, last) in enumerate(jobs):
+            last = self.n_frames if last is None else last
+            cj[k].slot_begin, cj[k].slot_split, cj[k].slot_end = self.head + first, self.head + split, self.head + last
+            C.memmove(C.addressof(cj[k].prm), C.addressof(prm), C.sizeof(PcaBevParams))
+            cj[k].planes = None
+            cj[k].planes_f16 = out16.data_ptr() + k * plane_bytes
+        st = self.c_store()
+        ctx.check(lib.pca_bev_generate_many(ctx.h, C.byref(st), None, self.frame_off.data_ptr(), cj, n, max_points,
+                                            self._ws_many.data_ptr(), self._ws_many.numel(), ctx.stream()))
+        return out16
 
     # ---- host views (synchronise) -----------------------------------------------------------
     def rows(self, frame=None):

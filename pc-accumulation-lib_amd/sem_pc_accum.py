@@ -304,8 +304,32 @@ class SemanticPointCloudAccumulator:
                     for k in range(bev_num)]
         px = gen.pixel_size
         planes = torch.empty((bev_num, 21, px, px), dtype=torch.float16, device=self.store.device)
-        results = [gen.generate_multiproc((pcs, self._copy_trajs(trajs)), device_only=True, out=planes[k],
-                                          worker=self._aug_worker0 + k) for k in range(bev_num)]
+        with gen.raster_batch():                  # bev_num > 1: ONE launch of each kernel for all the samples
+            results = [gen.generate_multiproc((pcs, self._copy_trajs(trajs)), device_only=True, out=planes[k],
+                                              worker=self._aug_worker0 + k) for k in range(bev_num)]
+        return gen.to_host_async(planes, results)
+
+    def _window_inputs_for(self, present_idx, gen_future):
+        """(pcs, trajs) of one sample as generate_bev builds them (overridden where other agents' trajectories exist)."""
+        return self._window_inputs(present_idx, gen_future)
+
+    def generate_bev_many(self, present_idxs, gen_future: bool = True):
+        """Extension (no reference counterpart): the samples generate_bev(idx, 1, gen_future)[0] would return for every idx of
+        `present_idxs`, rasterised in ONE launch of each kernel (the store does not change between them: the driver's sweep
+        over present_idx of a finished scene, run_nuscenes_bev_gen.py:245-271) and copied to the host in one asynchronous
+        transfer.  Returns the list of dicts (LazyBev)."""
+        import torch
+        gen = self.sem_bev_generator
+        present_idxs = list(present_idxs)
+        if not present_idxs:
+            return []
+        px = gen.pixel_size
+        planes = torch.empty((len(present_idxs), 21, px, px), dtype=torch.float16, device=self.store.device)
+        with gen.raster_batch():
+            results = []
+            for k, idx in enumerate(present_idxs):
+                pcs, trajs = self._window_inputs_for(idx, gen_future)
+                results.append(gen.generate_multiproc((pcs, self._copy_trajs(trajs)), device_only=True, out=planes[k]))
         return gen.to_host_async(planes, results)
 
     @staticmethod

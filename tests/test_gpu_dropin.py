@@ -1033,3 +1033,57 @@ def test_nuscenes_batched_k1n_full_size_ragged_frames_match_oracle():
         ost = orc.Store(max(pc.shape[0], 1), intensity_div255=True)
         orc.nusc_sample_filter_transform(ost, pc, cam, imgs, sems, T, NUSC_FILTERS)
         assert np.array_equal(rows, ost.rows())
+
+
+def test_generate_bev_many_equals_single_calls(golden):
+    """generate_bev_many(idxs): all samples of a sweep over present_idx in ONE launch of each raster kernel and one
+    asynchronous copy -- every dict equal to generate_bev(idx, 1, gen_future=True)[0] (planes bit for bit, trajectories),
+    for the NuScenes class (other agents' trajectories, dynamic flags) and for the KITTI class; bev_num copies go through
+    the same batched launch."""
+    from PIL import Image
+
+    from bev_generator.sem_bev import LazyBev
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    from nuscenes_oracle_sem_pc_accum import NuScenesOracleSemanticPointCloudAccumulator
+    g = golden('nusc_oracle')
+    F = int(g['F'])
+    acc = NuScenesOracleSemanticPointCloudAccumulator('fake.onnx', NUSC_FILTERS, SEM_IDXS, False, dict(BEV_NUSC), 'boston',
+                                                      False, None)
+    batch = []
+    for k in range(F):
+        T = g[f'T_{k}']
+        batch.append([dict(images=[Image.fromarray(im) for im in g[f'imgs_{k}']], pc=g[f'pc_{k}'], pc_cam_idx=g[f'cam_idx_{k}'],
+                           ego_at_lidar_ts=T, ego_global_x=T[0, 3], ego_global_y=T[1, 3],
+                           inst_tokens=str(g['inst_tokens'][k]).split(','), inst_cls=list(g[f'inst_cls_{k}']),
+                           inst_center=list(g[f'inst_center_{k}']))])
+    acc.integrate_many(batch)
+    idxs = list(range(1, F))
+    many = acc.generate_bev_many(idxs, gen_future=True)
+    assert len(many) == len(idxs) and all(isinstance(b, LazyBev) for b in many)
+
+    def same(b, s):
+        assert set(b.keys()) == set(s.keys())
+        for key in s:
+            if key.startswith('trajs') or key == 'gt_lanes':
+                assert len(b[key]) == len(s[key]) and all(np.array_equal(x, y) for x, y in zip(b[key], s[key])), key
+            else:
+                assert np.array_equal(np.asarray(b[key]).view(np.uint16), np.asarray(s[key]).view(np.uint16)), key
+    for idx, b in zip(idxs, many):
+        same(b, acc.generate_bev(idx, 1, gen_future=True)[0])
+    check_bev(many[idxs.index(int(g['present_idx']))], g)
+    # KITTI class + bev_num copies
+    gk = golden('kitti_gtsem')
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': gk['P']}
+    kacc = Kitti360SemanticPointCloudAccumulator(50., calib, 1e3, None, KITTI_FILTERS, SEM_IDXS, True, dict(BEV_KITTI))
+    queue = list(gk['Ts'])
+    kacc.pose_provider = lambda pc: queue.pop(0)
+    dummy = Image.fromarray(np.zeros((64, 96, 3), np.uint8))
+    for k in range(4):
+        kacc.integrate([(dummy, gk[f'pc_{k}'], gk[f'sem_gt_{k}'])])
+    km = kacc.generate_bev_many([1, 2, 3], gen_future=True)
+    for idx, b in zip([1, 2, 3], km):
+        same(b, kacc.generate_bev(idx, 1, gen_future=True)[0])
+    check_bev(km[1], gk)
+    copies = kacc.generate_bev(2, 3, gen_future=True)
+    for c in copies:
+        same(c, km[1])
