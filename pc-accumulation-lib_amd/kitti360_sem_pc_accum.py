@@ -188,6 +188,8 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
             Ts.append(T_new_prev)
             self.rgbs.append(rgb)
             self.semsegs.append(semseg)
+        from pca_amd.ingest import check_ring_lifetime     # a prefetching loader reuses its buffers every few batches
+        check_ring_lifetime([t for f in frames for t in f.values()], len(frames))
         self.store.flush_pending()
         self.store.append_kitti(frames, self.P_velo_frame, shape[0], shape[1], self.semseg_filters,
                                 sample_mode=self.sample_mode)

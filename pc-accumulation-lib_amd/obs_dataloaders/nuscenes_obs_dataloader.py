@@ -56,9 +56,10 @@ class NuScenesDataloader(ObservationDataloader):
         return [NuScenesCamera(self.nusc, self.nusc.get('sample_data', sample['data'][ch])) for ch in self.cam_channels]
 
     # ---- one observation -------------------------------------------------------------------------------------
-    def read_obs(self, idx):
-        """dict with the reference's keys: images, pc (N,7) [x,y,z (ego), intensity, u, v, instance idx], pc_cam_idx
-        (N,), ego_at_lidar_ts (4,4), meta, inst_tokens, inst_cls, inst_center, ego_global_x, ego_global_y."""
+    def read_host(self, idx):
+        """Everything of one observation that needs no GPU: sample records, the merged sweeps, sensor poses and intrinsics,
+        the camera images (as the sensor objects hold them).  `finish_obs` turns it into the reference's observation; the
+        ingest pipeline (pca_amd.ingest.NuScenesPrefetchingLoader) runs this part on reader threads, ahead of the GPU."""
         sample_token = self.sample_tokens[idx]
         sample = self.nusc.get('sample', sample_token)
         obs = {'meta': {'sample_token': sample_token, 'scene_token': sample['scene_token'],
@@ -74,25 +75,34 @@ class NuScenesDataloader(ObservationDataloader):
             'map_point_feat2idx': {'sweep_idx': self.sweep_idx, 'inst_idx': self.inst_idx, 'cls_idx': self.cls_idx},
         }
         out = self._sweeps(sample_token, cfg)
-        pc = np.asarray(out['points'])                      # lidar frame
-
         lidar = self._lidar(sample)
         cameras = self._cameras(sample)
         obs['ego_at_lidar_ts'] = lidar.glob_from_ego
         obs['images'] = [cam.img for cam in cameras]
-        pc_in_ego, pc_uv, pc_cam_idx = project_to_cameras(
-            pc[:, :3], lidar.ego_from_self, lidar.glob_from_ego, [cam.glob_from_self for cam in cameras],
-            [cam.cam_K for cam in cameras], [cam.img_wh for cam in cameras])
-        obs['pc_cam_idx'] = pc_cam_idx
-        obs['pc'] = np.concatenate([pc_in_ego, pc[:, self.int_idx:self.int_idx + 1], pc_uv,
-                                    pc[:, self.inst_idx:self.inst_idx + 1]], axis=1)
-
         obs['inst_tokens'] = out['instances_token']
         obs['inst_cls'] = [int(cls.item()) for cls in out['instances_name']]
         obs['inst_center'] = out['instances_center']
-
         sd = self.nusc.get('sample_data', sample['data']['LIDAR_TOP'])
         x, y, _ = self.nusc.get('ego_pose', sd['ego_pose_token'])['translation']
         obs['ego_global_x'] = x
         obs['ego_global_y'] = y
+        geom = dict(pc=np.asarray(out['points']),               # lidar frame, (N, >= 7) sweep matrix
+                    ego_from_lidar=lidar.ego_from_self, glob_from_ego=lidar.glob_from_ego,
+                    cams_glob_from_self=[cam.glob_from_self for cam in cameras], cams_K=[cam.cam_K for cam in cameras],
+                    cams_wh=[cam.img_wh for cam in cameras])
+        return obs, geom
+
+    def finish_obs(self, obs, geom):
+        """Projection onto the cameras (K0n on the device) and the (N,7) point rows, as host arrays."""
+        pc = geom['pc']
+        pc_in_ego, pc_uv, pc_cam_idx = project_to_cameras(pc[:, :3], geom['ego_from_lidar'], geom['glob_from_ego'],
+                                                          geom['cams_glob_from_self'], geom['cams_K'], geom['cams_wh'])
+        obs['pc_cam_idx'] = pc_cam_idx
+        obs['pc'] = np.concatenate([pc_in_ego, pc[:, self.int_idx:self.int_idx + 1], pc_uv,
+                                    pc[:, self.inst_idx:self.inst_idx + 1]], axis=1)
         return obs
+
+    def read_obs(self, idx):
+        """dict with the reference's keys: images, pc (N,7) [x,y,z (ego), intensity, u, v, instance idx], pc_cam_idx
+        (N,), ego_at_lidar_ts (4,4), meta, inst_tokens, inst_cls, inst_center, ego_global_x, ego_global_y."""
+        return self.finish_obs(*self.read_host(idx))

@@ -28,6 +28,11 @@ class ObservationDataloader(ABC):
             # batches it yields hold device tensors, which the accumulators take in place of numpy / PIL inputs
             from pca_amd.ingest import PrefetchingLoader
             return iter(PrefetchingLoader(self, depth=int(os.environ.get('PCA_PREFETCH_DEPTH', '4'))))
+        if os.environ.get('PCA_PREFETCH', '0') not in ('', '0') and hasattr(self, 'read_host'):
+            # NuScenes: sweep merging and image decoding on reader threads, the six images through a pinned ring, projection
+            # (K0n) and the point rows left on the device
+            from pca_amd.ingest import NuScenesPrefetchingLoader
+            return iter(NuScenesPrefetchingLoader(self, depth=int(os.environ.get('PCA_PREFETCH_DEPTH', '3'))))
         return self
 
     def __next__(self):

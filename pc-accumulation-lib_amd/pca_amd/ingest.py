@@ -116,6 +116,16 @@ class PinnedUploader:
         return out
 
 
+def check_ring_lifetime(tensors, n_batches):
+    """Raises if `n_batches` batches of a prefetching loader are about to be used together although the loader reuses its
+    device buffers sooner: tensors it yields carry `_pca_ring` = the number of batches its ring holds."""
+    ring = min((getattr(t, '_pca_ring', 1 << 30) for t in tensors), default=1 << 30)
+    if n_batches > ring - 1:
+        raise ValueError(f'these observations come from a prefetching loader that reuses its device buffers every {ring} '
+                         f'batches: at most {ring - 1} of them can be integrated in one call (the earlier ones have been '
+                         f'overwritten by now); integrate as they arrive, or enlarge the ring (PCA_PREFETCH_RING)')
+
+
 def compose_label_lut(idx2idx, lo=-1, hi=255):
     """The reference remaps labels with a SEQUENCE of in-place masked assignments (conv_semantic_ids): a later pair
     sees the result of an earlier one.  Returns the composed table as an array indexed by (label - lo)."""
@@ -130,7 +140,12 @@ class PrefetchingLoader:
     """Ring of slots, each with pinned host staging AND device buffers allocated once and reused (a fresh device / pinned
     allocation costs milliseconds when the allocator cache has no free block).  A slot's device buffers are overwritten
     by the copy of a later batch only after an event recorded on the consumer's stream when it came back for the next
-    batch: everything it did with the slot has been enqueued by then (a GPU-side wait, nobody blocks on the host)."""
+    batch: everything it did with the slot has been enqueued by then (a GPU-side wait, nobody blocks on the host).
+    Lifetime of what is yielded: the device tensors of a batch are views of a ring of RING reused buffers -- valid for work
+    ENQUEUED before the loader is asked for the batch RING - 1 batches later (integrate() per batch: always).  A consumer
+    that collects many batches first and integrates them together (integrate_many) is bounded by the ring: the tensors carry
+    `_pca_ring` = RING and the accumulators' batch paths refuse more than RING - 1 of them at once (`check_ring_lifetime`)
+    instead of reading overwritten frames.  PCA_PREFETCH_RING enlarges the ring."""
 
     RING = 4                                 # batches: being used, staged ahead, and two of slack
 
@@ -138,6 +153,7 @@ class PrefetchingLoader:
         import torch
         from . import _lib
         _lib.Context.get(device)            # no GPU / no library: fail here, loudly (there is no CPU fallback)
+        self.RING = max(int(os.environ.get('PCA_PREFETCH_RING', self.RING)), 2)
         self.loader = loader
         self.depth = depth
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
@@ -189,6 +205,7 @@ class PrefetchingLoader:
                 # took 1-3 ms per call here
                 np.copyto(pin.numpy(), a)
                 d.copy_(pin, non_blocking=True)
+                d._pca_ring = self.RING          # a view of a reused buffer: see "lifetime" in the class docstring
                 dev[name] = d
             ev = torch.cuda.Event()
             ev.record(stream)
@@ -270,3 +287,133 @@ class PrefetchingLoader:
                     cur.wait_event(ev)
             ahead = stage()                      # the next batch's copies travel while this one is being integrated
             yield [obs for obs, _, _ in item]
+
+
+class DeviceImages(list):
+    """The camera images of one NuScenes observation: a list of the host images (what the reference's observation holds:
+    viz and the semseg model read those) whose stacked device copy [ncam,H,W,3] u8 is already on its way (`dev`).
+    NOTE on lifetime: `dev` (and the `pc` / `pc_cam_idx` tensors of the same observation) are views of a ring of RING
+    reused device buffers (default 64 batches = more than a scene; PCA_PREFETCH_RING); the loader overwrites a slot RING
+    batches later, in stream order after everything the consumer had enqueued by then.  The tensors carry `_pca_ring` = RING:
+    integrate_many refuses to take more than RING - 1 batches at once instead of reading overwritten frames."""
+
+    def __init__(self, host_images, dev):
+        super().__init__(host_images)
+        self.dev = dev
+
+
+class NuScenesPrefetchingLoader:
+    """Ingest pipeline of the NuScenes flow (reference: obs_dataloaders/nuscenes_obs_dataloader.py:103-220).
+    Reader threads run `loader.read_host` -- sample records, sweep merging, image decode -- up to `depth` batches ahead, in
+    order.  The consumer's thread (the only one that talks to HIP) stages the six decoded images into ONE pinned block (the
+    host copies side by side on the staging pool) and enqueues one 26 MB H2D copy instead of a pageable, blocking
+    `.to(device)` of an `np.stack`; the lidar points go up once, K0n projects them on the device and the (N,7) rows the
+    accumulator takes are assembled there -- nothing of the observation comes back to the host."""
+
+    RING = 64                                # batches: a whole scene (~40 samples) can be collected and integrated at once
+
+    def __init__(self, loader, depth=3, device=None):
+        import torch
+        from . import _lib
+        self.ctx = _lib.Context.get(device)
+        self.RING = max(int(os.environ.get('PCA_PREFETCH_RING', self.RING)), 2)
+        self.loader = loader
+        self.depth = depth
+        self.device = torch.device('cuda', self.ctx.device_index)
+        bs = max(int(getattr(loader, 'batch_size', 1)), 1)
+        self._ring = [dict(pin={}, dev={}, copied=None) for _ in range(self.RING * bs)]
+        self._next = 0
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _buffers(self, slot, name, shape, dtype):
+        import torch
+        n = int(np.prod(shape))
+        pin, dev = slot['pin'].get(name), slot['dev'].get(name)
+        if pin is None or pin.numel() < n or pin.dtype != dtype:
+            pin = slot['pin'][name] = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+            dev = slot['dev'][name] = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+        return pin[:n].view(*shape), dev[:n].view(*shape)
+
+    def _host_part(self, idx):
+        obs, geom = self.loader.read_host(idx)
+        imgs = [np.asarray(im, dtype=np.uint8) if not isinstance(im, str) else im for im in obs['images']]   # decode here
+        return obs, geom, imgs
+
+    def _to_device(self, item):
+        import ctypes as C
+
+        import torch
+        from . import _lib
+        obs, geom, imgs = item
+        slot = self._ring[self._next % len(self._ring)]
+        self._next += 1
+        if slot['copied'] is not None:
+            slot['copied'].synchronize()                   # the copies out of this slot's pinned blocks, RING batches ago
+        lib, ctx = self.ctx.lib, self.ctx
+        pc = np.ascontiguousarray(geom['pc'], dtype=np.float64)
+        n, ncam = pc.shape[0], len(geom['cams_K'])
+        pin_pc, dev_pc = self._buffers(slot, 'pc', pc.shape, torch.float64)
+        jobs = []
+        images = obs['images']
+        real = all(isinstance(im, np.ndarray) and im.ndim == 3 for im in imgs) and len({im.shape for im in imgs}) == 1
+        if real:
+            pin_im, dev_im = self._buffers(slot, 'img', (len(imgs), ) + imgs[0].shape, torch.uint8)
+            pool = PinnedUploader._copy_pool()
+            jobs = [pool.submit(np.copyto, pin_im[k].numpy(), imgs[k]) for k in range(1, len(imgs))]
+            np.copyto(pin_im[0].numpy(), imgs[0])
+        np.copyto(pin_pc.numpy(), pc)
+        for j in jobs:
+            j.result()
+        dev_pc.copy_(pin_pc, non_blocking=True)
+        if real:
+            dev_im.copy_(pin_im, non_blocking=True)
+            images = DeviceImages(obs['images'], dev_im)
+        ev = torch.cuda.Event()
+        ev.record()
+        slot['copied'] = ev
+        # projection (K0n) on the device, rows [x, y, z (ego), intensity, u, v, instance] assembled there
+        xyz = dev_pc[:, :3].contiguous()
+        _, ego = self._buffers(slot, 'ego', (n, 3), torch.float64)
+        _, uv = self._buffers(slot, 'uv', (n, 2), torch.float64)
+        _, cam = self._buffers(slot, 'cam', (n, ), torch.int64)
+        _, rows = self._buffers(slot, 'rows', (n, 7), torch.float64)
+        cam_from_glob = np.stack([np.linalg.inv(T) for T in geom['cams_glob_from_self']])
+        ctx.check(lib.pca_nusc_project_cams(
+            ctx.h, xyz.data_ptr(), n, _lib.f64_array(geom['ego_from_lidar'], 16), _lib.f64_array(geom['glob_from_ego'], 16),
+            _lib.f64_array(cam_from_glob, 16 * ncam), _lib.f64_array(np.stack(geom['cams_K']), 9 * ncam),
+            _lib.f64_array(np.stack(geom['cams_wh']), 2 * ncam), ncam, ego.data_ptr(), uv.data_ptr(), cam.data_ptr(),
+            ctx.stream()))
+        ld = self.loader
+        rows[:, 0:3] = ego
+        rows[:, 3] = dev_pc[:, ld.int_idx]
+        rows[:, 4:6] = uv
+        rows[:, 6] = dev_pc[:, ld.inst_idx]
+        for t in (rows, cam) + ((dev_im, ) if real else ()):
+            t._pca_ring = self.RING                # views of reused buffers (see DeviceImages)
+        out = dict(obs)
+        out['images'] = images
+        out['pc'] = rows
+        out['pc_cam_idx'] = cam
+        return out
+
+    def __iter__(self):
+        import torch
+        n, bs = len(self.loader), self.loader.batch_size
+        torch.cuda.set_device(self.device)
+        n_threads = int(os.environ.get('PCA_INGEST_THREADS', '8'))
+        pool = ThreadPoolExecutor(max_workers=max(n_threads, 1))
+        pending = collections.deque()
+        idx = 0
+        try:
+            while True:
+                while idx + bs <= n and len(pending) < max(self.depth, 1):
+                    pending.append([pool.submit(self._host_part, idx + k) for k in range(bs)])
+                    idx += bs
+                if not pending:
+                    return
+                batch = [f.result() for f in pending.popleft()]
+                yield [self._to_device(item) for item in batch]
+        finally:
+            pool.shutdown(wait=False)

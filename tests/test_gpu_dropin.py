@@ -1087,3 +1087,108 @@ def test_generate_bev_many_equals_single_calls(golden):
     copies = kacc.generate_bev(2, 3, gen_future=True)
     for c in copies:
         same(c, km[1])
+
+
+def test_nuscenes_prefetching_loader_equals_plain_loader_and_feeds_the_accumulator(golden, monkeypatch):
+    """PCA_PREFETCH=1 on the NuScenes loader: read_host on reader threads, the six images through ONE pinned block, K0n and
+    the (N,7) rows on the device.  Every observation equals the plain loader's (rows, camera indices, images, metadata), and
+    an accumulator fed from it -- frame by frame, and through integrate_many with more batches collected than the loader's
+    ring holds -- ends in the state the plain loader produces."""
+    from types import SimpleNamespace
+
+    import torch
+
+    from nuscenes_oracle_sem_pc_accum import NuScenesOracleSemanticPointCloudAccumulator
+    from obs_dataloaders.nuscenes_obs_dataloader import NuScenesDataloader
+    from pca_amd.ingest import DeviceImages
+    g = golden('utils')
+    n = g['c6_pc'].shape[0]
+    W, H = int(g['pp_wh'][0]), int(g['pp_wh'][1])
+    n_samples = 7
+    rng = np.random.default_rng(14)
+    sweeps, images = [], []
+    for k in range(n_samples):
+        sw = np.zeros((n, 8))
+        sw[:, :3] = g['c6_pc'] + rng.normal(0, 0.05, (n, 3))
+        sw[:, 3] = rng.integers(0, 256, n)
+        sw[:, 6] = rng.integers(-1, 3, n)
+        sweeps.append(sw)
+        images.append([rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(6)])
+    toks = [f's{k}' for k in range(n_samples)]
+
+    class FakeNusc:
+        scene = [{'first_sample_token': 's0'}]
+
+        def get(self, table, token):
+            if table == 'sample':
+                k = toks.index(token)
+                return {'next': toks[k + 1] if k + 1 < n_samples else '', 'scene_token': 'sc', 'data': {'LIDAR_TOP': 'l' + token[1:]}}
+            if table == 'sample_data':
+                return {'ego_pose_token': 'e' + token[1:]}
+            k = int(token[1:])
+            return {'translation': [411.5 + 0.8 * k, 1180.25 - 0.1 * k, 0.0]}
+
+    def glob_from_ego(k):
+        T = np.array(g['c6_glob_from_ego'])
+        T[0, 3] += 0.8 * k
+        T[1, 3] -= 0.1 * k
+        return T
+
+    class Loader(NuScenesDataloader):
+        def _lidar(self, sample):
+            k = int(sample['data']['LIDAR_TOP'][1:])
+            return SimpleNamespace(ego_from_self=g['c6_ego_from_lidar'], glob_from_ego=glob_from_ego(k))
+
+        def _cameras(self, sample):
+            k = int(sample['data']['LIDAR_TOP'][1:])
+            return [SimpleNamespace(img=images[k][j], glob_from_self=g['c6_glob_from_cam'][j], cam_K=g['pp_K'], img_wh=g['pp_wh'])
+                    for j in range(6)]
+
+    def provider(nusc, token, **cfg):
+        k = toks.index(token)
+        return {'points': sweeps[k], 'instances_token': ['a', 'b'], 'instances_name': [np.int64(0), np.int64(3)],
+                'instances_center': [np.array([5.0 + 0.6 * k, 1.0, 0.5]), np.ones(3)]}
+
+    def make_loader():
+        ld = Loader(FakeNusc(), scene_ids=[0], batch_size=1, num_sweeps=5)
+        ld.sweep_provider = provider
+        return ld
+    plain = [b[0] for b in make_loader()]
+    monkeypatch.setenv('PCA_PREFETCH', '1')
+    fast = [b[0] for b in make_loader()]
+    monkeypatch.delenv('PCA_PREFETCH')
+    assert len(plain) == len(fast) == n_samples
+    for k in range(n_samples):                              # (the ring holds 64 batches: all seven are still intact)
+        p, f = plain[k], fast[k]
+        assert isinstance(f['images'], DeviceImages) and isinstance(f['pc'], torch.Tensor)
+        assert np.array_equal(f['pc'].cpu().numpy(), p['pc']) and np.array_equal(f['pc_cam_idx'].cpu().numpy(), p['pc_cam_idx'])
+        assert np.array_equal(f['images'].dev.cpu().numpy(), np.stack(p['images']))
+        assert all(np.array_equal(a, b) for a, b in zip(f['images'], p['images']))
+        for key in ('meta', 'inst_tokens', 'inst_cls', 'ego_global_x', 'ego_global_y'):
+            assert f[key] == p[key]
+        assert np.array_equal(f['ego_at_lidar_ts'], p['ego_at_lidar_ts'])
+
+    def run(loader_env, many):
+        if loader_env:
+            monkeypatch.setenv('PCA_PREFETCH', '1')
+        acc = NuScenesOracleSemanticPointCloudAccumulator('fake.onnx', NUSC_FILTERS, SEM_IDXS, False, dict(BEV_NUSC), 'boston',
+                                                          False, None)
+        ld = make_loader()
+        if many:
+            acc.integrate_many(list(ld))                    # all seven batches collected first: more than the ring holds
+        else:
+            for observations in ld:
+                acc.integrate(observations)
+        if loader_env:
+            monkeypatch.delenv('PCA_PREFETCH')
+        acc.store.check_status()
+        return np.concatenate(acc.sem_pcs), np.array(acc.poses), acc.dyn_instances
+    want = run(False, False)
+    assert want[0].shape[0] > 1000
+    for loader_env, many in ((True, False), (True, True), (False, True)):
+        got = run(loader_env, many)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+    # a ring smaller than what is collected is refused, not read after it was overwritten
+    monkeypatch.setenv('PCA_PREFETCH_RING', '4')
+    with pytest.raises(ValueError, match='reuses its device buffers'):
+        run(True, True)
