@@ -362,6 +362,142 @@ def nuscenes_pass(frames=40, reps=10):
             'note': 'single small launches: latency-, not bandwidth-bound at 35 k points per frame'}
 
 
+def nuscenes_scene_pass(frames=40, reps=5):
+    """BASELINE configs[2] end to end through the drop-in NuScenesOracleSemanticPointCloudAccumulator: one synthetic scene
+    (40 frames x 34 720 points, 6 x 900x1600 images, two GT instances, one of them moving) is
+    integrated and swept for BEV samples as run_nuscenes_bev_gen.py:234-271 does it (conditions 1-3 with a 10 m horizon,
+    1 m spacing).  Three forms, wall clock per scene:
+      batched   device-resident observations, integrate_many (ONE K1n front + append launch, one K3 launch) and
+                generate_bev_many (ONE launch of each raster kernel for all samples), planes stay in HBM until awaited;
+      stepwise  the same observations through integrate() per frame and generate_bev() per sample (the unchanged driver's
+                call sequence on device inputs);
+      pcie      host arrays in (6 x 4.3 MB images + points per frame), host fp16 dicts out, every sample awaited."""
+    import torch
+    import sem_pc_accum
+    from nuscenes_oracle_sem_pc_accum import NuScenesOracleSemanticPointCloudAccumulator
+    from pca_amd import _lib
+    from pca_amd.ingest import DeviceImages
+    n, ncam, H, W = 34_720, 6, 900, 1600
+    gdev = torch.Generator(device='cuda').manual_seed(33)
+    stacks = [(torch.randint(0, 256, (ncam, H, W, 3), device='cuda', dtype=torch.uint8, generator=gdev),
+               torch.randint(0, 19, (ncam, H, W), device='cuda', dtype=torch.uint8, generator=gdev)) for _ in range(4)]
+    host_stacks = [(i.cpu().numpy(), s.cpu().numpy()) for i, s in stacks]
+    rng = np.random.default_rng(33)
+    filters = [10, 11, 12, 16, 18]
+
+    class Model:                                             # stand-in for the CNN: the class map resident where the image is
+        def __init__(self):
+            self.by_id = {}
+
+        def pred(self, rgb):
+            return self.by_id[id(rgb)][None, None]
+    model = Model()
+    dev_obs, host_obs = [], []
+    for k in range(frames):
+        pc = np.stack([rng.uniform(-50, 50, n), rng.uniform(-50, 50, n), rng.uniform(-2, 4, n),
+                       rng.integers(0, 256, n).astype(float), rng.uniform(1.01, W - 1.01, n), rng.uniform(1.01, H - 1.01, n),
+                       rng.integers(-1, 5, n).astype(float)], 1)
+        cam = rng.integers(-1, ncam, n)
+        a = 0.002 * k
+        T = np.eye(4)
+        T[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        T[:3, 3] = [1000.0 + 1.0 * k, 500.0, 0.0]
+        meta = dict(ego_at_lidar_ts=T, ego_global_x=T[0, 3], ego_global_y=T[1, 3], inst_tokens=['car_a', 'car_b'],
+                    inst_cls=[0, 0], inst_center=[np.array([1010.0 + 0.5 * k, 505.0, 0.5]), np.array([1020.0, 495.0, 0.5])])
+        imgs_d, sems_d = stacks[k % 4]
+        handles = [object() for _ in range(ncam)]            # what the model is asked about, camera by camera
+        for j, h in enumerate(handles):
+            model.by_id[id(h)] = sems_d[j]
+        dev_obs.append([dict(meta, images=DeviceImages(handles, imgs_d), pc=torch.from_numpy(pc).cuda(),
+                             pc_cam_idx=torch.from_numpy(cam).cuda())])
+        imgs_h, sems_h = host_stacks[k % 4]
+        himgs = [imgs_h[j] for j in range(ncam)]
+        for j, im in enumerate(himgs):
+            model.by_id[id(im)] = sems_h[j]
+        host_obs.append([dict(meta, images=himgs, pc=pc, pc_cam_idx=cam)])
+    sem_pc_accum.SemSegONNX = lambda path: model
+    bev_params = dict(type='sem', view_size=51.2, pixel_size=256, max_trans_radius=0., zoom_thresh=0., do_warp=False,
+                      int_scaler=1., int_sep_scaler=30., int_mid_threshold=0.12, height_filter=3.)
+
+    def new_acc():
+        acc = NuScenesOracleSemanticPointCloudAccumulator('resident', filters, SEM_IDXS, False, dict(bev_params), 'synthetic',
+                                                          False, None)
+        acc._store_args = dict(intensity_div255=True, capacity=(frames + 2) * n, max_frames=frames + 8)
+        return acc
+
+    def sample_idxs(acc, horizon=10.0, spacing=1.0):        # the driver's sweep, run_nuscenes_bev_gen.py:242-262
+        d = acc.get_incremental_path_dists()
+        out, prev = [], 0
+        for idx in range(len(acc.poses) - 1):
+            if d[idx] < horizon or d[-1] - d[idx] < horizon:
+                continue
+            if acc.dist(acc.get_pose(prev), acc.get_pose(idx)) < spacing:
+                continue
+            prev = idx
+            out.append(idx)
+        return out
+
+    def batched():
+        acc = new_acc()
+        acc.integrate_many(dev_obs)
+        bevs = acc.generate_bev_many(sample_idxs(acc), gen_future=True)
+        assert bevs[-1]['rgb_full'].shape == (3, 256, 256)               # awaits the one copy of all samples
+        return acc, len(bevs)
+
+    def stepwise(obs):
+        acc = new_acc()
+        for o in obs:
+            acc.integrate(o)
+        bevs = [acc.generate_bev(idx, 1, gen_future=True)[0] for idx in sample_idxs(acc)]
+        for b in bevs:
+            assert b['rgb_full'].shape == (3, 256, 256)
+        return acc, len(bevs)
+    out = {'workload': '%d frames x %d points x 7 f64, 6 x %dx%d images per frame, 256^2 BEV at view 51.2 m, height filter 3 m; '
+                       'sample sweep with a 10 m horizon and 1 m spacing' % (frames, n, H, W)}
+    ctx = _lib.Context.get()
+    for name, fn in (('batched', batched), ('stepwise', lambda: stepwise(dev_obs)), ('pcie', lambda: stepwise(host_obs))):
+        fn()                                                             # warm-up (allocations, pinned blocks)
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(reps if name != 'pcie' else 2):
+            t0 = time.perf_counter()
+            acc, n_bev = fn()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        dt = float(np.median(times))
+        out[name] = {'ms_per_scene': 1e3 * dt, 'Mpoints_per_s': frames * n / dt / 1e6, 'bev_frames_per_s': n_bev / dt,
+                     'bev_samples': n_bev}
+    # the batched K1n unit by HIP events (front + append) against its algorithmic bytes
+    acc = new_acc()
+    acc.integrate_many(dev_obs)
+    torch.cuda.synchronize()
+    ctx.profile(True)
+    for _ in range(reps):
+        acc = new_acc()
+        acc.integrate_many(dev_obs)
+    ev = ctx.profile_read()['nusc_sample_filter_transform']
+    ctx.profile(False)
+    sizes = acc.store.sizes()
+    m_on_cam = sum(int((o[0]['pc_cam_idx'] >= 0).sum().item()) for o in dev_obs)
+    alg = 56.0 * n * frames + 4.0 * m_on_cam + 40.0 * float(sizes.sum())
+    us = 1e3 * ev[0] / ev[1]
+    out['k1n_batched'] = {'frames_per_call': frames, 'us_per_call_hip_events': us, 'alg_bytes': alg, 'GBps': alg / us / 1e3,
+                          'frac': alg / us / 1e3 / HBM_PEAK_GBS, 'kept': int(sizes.sum())}
+    ctx.profile(2)
+    acc.generate_bev_many(sample_idxs(acc), gen_future=True)
+    n_bev = len(sample_idxs(acc))
+    for _ in range(reps):
+        acc.generate_bev_many(sample_idxs(acc), gen_future=True)
+    unit = ctx.profile_read()['bev_unit']
+    ctx.profile(False)
+    stored = int(sizes.sum())
+    alg_bev = n_bev * (40.0 * stored + 21.0 * 256 * 256 * 4.0)
+    us = 1e3 * unit[0] / unit[1]
+    out['bev_many'] = {'samples_per_call': n_bev, 'us_per_call_hip_events': us, 'us_per_sample': us / max(n_bev, 1),
+                       'alg_bytes': alg_bev, 'frac': alg_bev / us / 1e3 / HBM_PEAK_GBS}
+    return out
+
+
 def config4_pass(frames=100, n=1_000_000, px=512, view=160.0):
     """BASELINE configs[3] with the frame count scaled to the bench's time budget: `frames` x 1 M
     points, every point kept, 512^2 grid, view 160 m.  One steady-state step = evict + owed re-transform fused into the
@@ -897,6 +1033,7 @@ def main():
         side['k1_batched_distinct'] = k1_batched_pass(big, 64)
         del big
         side['nuscenes'] = nuscenes_pass()
+        side['nuscenes']['scene'] = nuscenes_scene_pass()
         side['config4'] = config4_pass()
         if not args.no_ring and args.scene == 'uniform':
             side['ring_model'] = ring_model_pass(min(args.steps, 50))

@@ -18,6 +18,15 @@ __device__ __forceinline__ T ldg(const T *p)
 {
     return *reinterpret_cast<const __attribute__((address_space(1))) T *>(reinterpret_cast<uintptr_t>(p));
 }
+// a value at a workgroup-uniform address in memory that nobody writes during the launch: one scalar load (s_load)
+template <typename T>
+__device__ __forceinline__ T sload(const T *p)
+{
+    const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(((uintptr_t)hi << 32) | lo);
+}
 struct __attribute__((packed)) U32u { uint32_t v; };
 __device__ __forceinline__ uint32_t ldg_u32_unaligned(const uint8_t *p)     // one global_load_dword at any byte address
 {
@@ -231,34 +240,55 @@ __global__ __launch_bounds__(K1N_BLK) void k1n_front_batch(const K1nBatchArgs a)
 {
     constexpr int TILE_PTS = K1N_PPT * K1N_BLK, NW = K1N_BLK / PCA_WAVE;
     __shared__ uint32_t s_wtot[K1N_PPT * NW], s_woff[K1N_PPT * NW + 1];
+    __shared__ __align__(16) double s_rows[TILE_PTS * 7];   // the tile's rows [x y z i u v inst], as they lie in memory (28 KB)
     const int tile = blockIdx.x;
-    const int f = __builtin_amdgcn_readfirstlane(ldg(a.tile_frame + tile));
+    // tile -> frame -> descriptor through the scalar cache (both tables are written before the launch, never during it):
+    // two short hops instead of two vector-memory round trips in front of the first point load
+    const int f = sload(a.tile_frame + tile);
     const K1nFrame *fp = a.frames + f;
-    const double *pc = ldg(&fp->pc);
-    const int64_t *cam_idx = ldg(&fp->cam_idx);
-    const uint8_t *imgs = ldg(&fp->imgs), *sems = ldg(&fp->sems);
-    const int n = ldg(&fp->n), tile0 = ldg(&fp->tile0);
+    const double *pc = sload(&fp->pc);
+    const int64_t *cam_idx = sload(&fp->cam_idx);
+    const uint8_t *imgs = sload(&fp->imgs), *sems = sload(&fp->sems);
+    const int n = sload(&fp->n), tile0 = sload(&fp->tile0);
     const int64_t base_pt = (int64_t)(tile - tile0) * TILE_PTS;
+    const int n_here = n - base_pt < TILE_PTS ? (int)(n - base_pt) : TILE_PTS;      // points of this tile (0: an empty frame)
+    // The rows are an array of structures (7 x f64 = 56 B per point): a lane-per-point load touches 28 cache lines per
+    // instruction, seven times over.  The tile's rows are ONE contiguous 28 KB range instead: 16-byte loads, consecutive
+    // lanes on consecutive addresses, into LDS; every lane then picks its own rows out of LDS.
+    {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const double *src = pc + base_pt * 7;
+        const int total = n_here * 7;
+        for (int i = 2 * (int)threadIdx.x; i < total; i += 2 * K1N_BLK) {
+            if (i + 1 < total) {
+                const d2 v = *reinterpret_cast<const __attribute__((address_space(1))) d2 *>(reinterpret_cast<uintptr_t>(src + i));
+                s_rows[i] = v.x; s_rows[i + 1] = v.y;
+            } else {
+                s_rows[i] = ldg(src + i);
+            }
+        }
+    }
     int64_t cam[K1N_PPT];
-    double row[K1N_PPT][7];
 #pragma unroll
     for (int k = 0; k < K1N_PPT; ++k) {
-        const int64_t p = base_pt + k * K1N_BLK + threadIdx.x;
-        cam[k] = -1;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) row[k][i] = 0.0;
-        if (p < n) {
-            cam[k] = ldg(cam_idx + p);
-#pragma unroll
-            for (int i = 0; i < 7; ++i) row[k][i] = ldg(pc + p * 7 + i);
-        }
+        const int p = k * K1N_BLK + (int)threadIdx.x;
+        cam[k] = p < n_here ? ldg(cam_idx + base_pt + p) : -1;
     }
     double T[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = ldg(&fp->T[i]);
+    for (int i = 0; i < 12; ++i) T[i] = sload(&fp->T[i]);
+    __syncthreads();
+    double row[K1N_PPT][7];
+#pragma unroll
+    for (int k = 0; k < K1N_PPT; ++k) {
+        const int p = k * K1N_BLK + (int)threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) row[k][i] = p < n_here ? s_rows[p * 7 + i] : 0.0;
+    }
     bool valid[K1N_PPT], keep[K1N_PPT];
     uint32_t packed[K1N_PPT];
     unsigned cls[K1N_PPT];
+    int64_t pixk[K1N_PPT];
     bool bad_uv = false;
     const int64_t last = (int64_t)a.ncam * a.H * a.W * 3 - 4;           // last legal 4-byte window of the images
     auto rgb_at = [&](int64_t pix) -> uint32_t {
@@ -275,22 +305,28 @@ __global__ __launch_bounds__(K1N_BLK) void k1n_front_batch(const K1nBatchArgs a)
         if (valid[k] && !(u > 1.0 && u < (double)a.W - 1.0 && v > 1.0 && v < (double)a.H - 1.0)) { bad_uv = true; valid[k] = false; }
         const int ui = valid[k] ? (int)rint(u) : 0, vi = valid[k] ? (int)rint(v) : 0;
         const int64_t img0 = (valid[k] ? c : 0) * a.H;
-        const int64_t pix = (img0 + vi) * a.W + ui;        // pixel 0 of camera 0 for invalid points: a legal address
-        cls[k] = ldg(sems + pix);
+        pixk[k] = (img0 + vi) * a.W + ui;                  // pixel 0 of camera 0 for invalid points: a legal address
+        cls[k] = ldg(sems + pixk[k]);
+    }
+    // the colour is gathered for the KEPT points only (a second, dependent gather: a wave-wide gather pulls 64 lines through
+    // the L1 for 64 x 4 useful bytes -- what bounds this kernel on scattered points, as it bounds K1's batch form)
+#pragma unroll
+    for (int k = 0; k < K1N_PPT; ++k) {
+        keep[k] = valid[k] && !in_mask(a.filt, cls[k]);
+        const int64_t pix = keep[k] ? pixk[k] : 0;
         if (!a.sample_mode) {
             packed[k] = rgb_at(pix);
         } else {
-            const Bilin b = bilin_weights<false>(valid[k] ? u : 0.0, valid[k] ? v : 0.0);
+            const double u = row[k][4], v = row[k][5];
+            const Bilin b = bilin_weights<false>(keep[k] ? u : 0.0, keep[k] ? v : 0.0);
             const int u0 = (int)b.u0, u1 = (int)b.u1, v0 = (int)b.v0, v1 = (int)b.v1;
-            auto at = [&](int vv, int uu) { return rgb_at(valid[k] ? (img0 + vv) * a.W + uu : 0); };
+            const int64_t img0 = (keep[k] ? cam[k] : 0) * a.H;
+            auto at = [&](int vv, int uu) { return rgb_at(keep[k] ? (img0 + vv) * a.W + uu : 0); };
             packed[k] = bilin_rgb(b, at(v0, u0), at(v1, u1), at(v1, u0), at(v0, u1));
         }
     }
 #pragma unroll
-    for (int k = 0; k < K1N_PPT; ++k) {
-        keep[k] = valid[k] && !in_mask(a.filt, cls[k]);
-        packed[k] |= cls[k] << 24;
-    }
+    for (int k = 0; k < K1N_PPT; ++k) packed[k] |= cls[k] << 24;
     if (bad_uv) atomicOr(a.status, PCA_STATUS_UV_OUT_OF_IMAGE);
     // stable ranks inside the tile (point order = k-major, then thread)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -160,7 +160,6 @@ void pca_ctx_destroy(pca_ctx *ctx)
     if (ctx->k1_frames_dev) (void)hipFree(ctx->k1_frames_dev);
     if (ctx->k1_tiny) (void)hipFree(ctx->k1_tiny);
     if (ctx->bevm_pin) (void)hipHostFree(ctx->bevm_pin);
-    if (ctx->bevm_dev) (void)hipFree(ctx->bevm_dev);
     if (ctx->bevm_ev) (void)hipEventDestroy(ctx->bevm_ev);
     if (ctx->k1n_ws) (void)hipFree(ctx->k1n_ws);
     if (ctx->k1n_desc_dev) (void)hipFree(ctx->k1n_desc_dev);

@@ -1178,23 +1178,26 @@ template <bool I64>
 __global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a) { bev_tile_cells_body<I64>(a); }
 template <bool I64>
 __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs a) { bev_tile_cells_heavy_body<I64>(a); }
+// (the samples' argument blocks live in CONSTANT memory: the kernels read them through the scalar cache exactly as they read
+// kernel arguments.  Copies out of a global array ended up in scratch -- the blocks are indexed dynamically -- and made
+// level 1 three times slower than a launch per sample.)
+#define PCA_BEV_MANY_MAX 48
+__constant__ BevArgs g_bev_many[PCA_BEV_MANY_MAX];
 template <bool I64>
-__global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void bev_tile_bin_many(const BevArgs *__restrict__ args)
+__global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void bev_tile_bin_many()
 {
-    const BevArgs a = args[blockIdx.y];
+    const BevArgs &a = g_bev_many[blockIdx.y];
     if ((int)blockIdx.x < a.G) bev_tile_bin_body<I64>(a);
 }
 template <bool I64>
-__global__ __launch_bounds__(C_THREADS) void bev_tile_cells_many(const BevArgs *__restrict__ args)
+__global__ __launch_bounds__(C_THREADS) void bev_tile_cells_many()
 {
-    const BevArgs a = args[blockIdx.y];
-    bev_tile_cells_body<I64>(a);
+    bev_tile_cells_body<I64>(g_bev_many[blockIdx.y]);
 }
 template <bool I64>
-__global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy_many(const BevArgs *__restrict__ args)
+__global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy_many()
 {
-    const BevArgs a = args[blockIdx.y];
-    bev_tile_cells_heavy_body<I64>(a);
+    bev_tile_cells_heavy_body<I64>(g_bev_many[blockIdx.y]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1386,15 +1389,13 @@ int pca_bev_generate_many(pca_ctx *ctx, const pca_store *store, const double *in
     const int px = jobs[0].prm.px;
     const int64_t per = (pca_bev_workspace_bytes(max_points, px) + 255) & ~255ll;
     if (workspace_bytes < per * n_jobs + 256) { ctx->err = "bev: workspace too small for this many rasters"; return -1; }
-    // argument blocks: built in pinned memory, one asynchronous upload
+    // argument blocks: built in pinned memory, copied to the constant array PCA_BEV_MANY_MAX samples at a time
     const int64_t up_bytes = (int64_t)sizeof(BevArgs) * n_jobs;
     if (ctx->bevm_busy) { PCA_CHECK(ctx, hipEventSynchronize(ctx->bevm_ev)); ctx->bevm_busy = false; }
     if (up_bytes > ctx->bevm_cap) {
         if (ctx->bevm_pin) PCA_CHECK(ctx, hipHostFree(ctx->bevm_pin));
-        if (ctx->bevm_dev) { PCA_CHECK(ctx, hipStreamSynchronize(s)); PCA_CHECK(ctx, hipFree(ctx->bevm_dev)); }
-        ctx->bevm_pin = nullptr; ctx->bevm_dev = nullptr; ctx->bevm_cap = 0;
+        ctx->bevm_pin = nullptr; ctx->bevm_cap = 0;
         PCA_CHECK(ctx, hipHostMalloc(&ctx->bevm_pin, (size_t)(2 * up_bytes)));
-        PCA_CHECK(ctx, hipMalloc(&ctx->bevm_dev, (size_t)(2 * up_bytes)));
         ctx->bevm_cap = 2 * up_bytes;
     }
     if (!ctx->bevm_ev) PCA_CHECK(ctx, hipEventCreateWithFlags(&ctx->bevm_ev, hipEventDisableTiming));
@@ -1411,21 +1412,24 @@ int pca_bev_generate_many(pca_ctx *ctx, const pca_store *store, const double *in
     }
     if (bev_set_lds_attributes(ctx)) return -1;
     const size_t lds = (size_t)T * 8;
-    const int heavy_grid = T < ctx->n_cu ? T : ctx->n_cu;
+    // a few resident workgroups per sample drain whatever heavy tiles there are (any number of them does)
+    const int heavy_grid = T < 8 ? T : 8;
     if (ctx->profiling) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
-    PCA_CHECK(ctx, hipMemcpyAsync(ctx->bevm_dev, ctx->bevm_pin, (size_t)up_bytes, hipMemcpyHostToDevice, s));
+    for (int k0 = 0; k0 < n_jobs; k0 += PCA_BEV_MANY_MAX) {
+        const int nk = n_jobs - k0 < PCA_BEV_MANY_MAX ? n_jobs - k0 : PCA_BEV_MANY_MAX;
+        PCA_CHECK(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_bev_many), ha + k0, sizeof(BevArgs) * (size_t)nk, 0, hipMemcpyHostToDevice, s));
+        if (intensity64) {
+            hipLaunchKernelGGL(bev_tile_bin_many<true>, dim3(G, nk), dim3(AB_THREADS), lds, s);
+            hipLaunchKernelGGL(bev_tile_cells_many<true>, dim3(T, nk), dim3(C_THREADS), 0, s);
+            hipLaunchKernelGGL(bev_tile_cells_heavy_many<true>, dim3(heavy_grid, nk), dim3(H_THREADS), HEAVY_LDS_BYTES, s);
+        } else {
+            hipLaunchKernelGGL(bev_tile_bin_many<false>, dim3(G, nk), dim3(AB_THREADS), lds, s);
+            hipLaunchKernelGGL(bev_tile_cells_many<false>, dim3(T, nk), dim3(C_THREADS), 0, s);
+            hipLaunchKernelGGL(bev_tile_cells_heavy_many<false>, dim3(heavy_grid, nk), dim3(H_THREADS), HEAVY_LDS_BYTES, s);
+        }
+    }
     PCA_CHECK(ctx, hipEventRecord(ctx->bevm_ev, s));
     ctx->bevm_busy = true;
-    const BevArgs *da = reinterpret_cast<const BevArgs *>(ctx->bevm_dev);
-    if (intensity64) {
-        hipLaunchKernelGGL(bev_tile_bin_many<true>, dim3(G, n_jobs), dim3(AB_THREADS), lds, s, da);
-        hipLaunchKernelGGL(bev_tile_cells_many<true>, dim3(T, n_jobs), dim3(C_THREADS), 0, s, da);
-        hipLaunchKernelGGL(bev_tile_cells_heavy_many<true>, dim3(heavy_grid, n_jobs), dim3(H_THREADS), HEAVY_LDS_BYTES, s, da);
-    } else {
-        hipLaunchKernelGGL(bev_tile_bin_many<false>, dim3(G, n_jobs), dim3(AB_THREADS), lds, s, da);
-        hipLaunchKernelGGL(bev_tile_cells_many<false>, dim3(T, n_jobs), dim3(C_THREADS), 0, s, da);
-        hipLaunchKernelGGL(bev_tile_cells_heavy_many<false>, dim3(heavy_grid, n_jobs), dim3(H_THREADS), HEAVY_LDS_BYTES, s, da);
-    }
     if (ctx->profiling) pca_prof_end(ctx, s);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;

@@ -42,7 +42,7 @@ struct pca_ctx {
     int64_t k1n_pin_cap = 0;
     hipEvent_t k1n_ev = nullptr;
     bool k1n_busy = false;
-    void *bevm_pin = nullptr, *bevm_dev = nullptr;   // argument blocks of pca_bev_generate_many (pinned staging, device copy)
+    void *bevm_pin = nullptr;         // argument blocks of pca_bev_generate_many (pinned staging)
     int64_t bevm_cap = 0;
     hipEvent_t bevm_ev = nullptr;
     bool bevm_busy = false;

@@ -105,21 +105,25 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
         semsegs = [self.semseg_model.pred(rgb)[0, 0] for rgb in rgbs]
         dev_sems = [getattr(m, 'dev', m) for m in semsegs]          # utils.onnx_utils.DeviceMap: already in HBM
 
-        def up(a, np_dtype, t_dtype):
+        if getattr(self, '_uploader', None) is None:
+            from pca_amd.ingest import PinnedUploader
+            self._uploader = PinnedUploader(dev)      # host arrays leave through reused pinned blocks, asynchronously
+
+        def up(kind, a, np_dtype, t_dtype):
             if isinstance(a, torch.Tensor):
                 return a.to(device=dev, dtype=t_dtype).contiguous()
-            return torch.from_numpy(np.ascontiguousarray(a, dtype=np_dtype)).to(dev)
+            return self._uploader(kind, np.ascontiguousarray(a, dtype=np_dtype))
 
         stack = getattr(rgbs, 'dev', rgbs)                          # pca_amd.ingest.DeviceImages: the six images as one tensor
         if isinstance(stack, torch.Tensor):
-            imgs = up(stack, np.uint8, torch.uint8)
+            imgs = up('imgs', stack, np.uint8, torch.uint8)
         else:
-            imgs = up(np.stack([np.array(rgb) for rgb in rgbs]), np.uint8, torch.uint8)
+            imgs = self._uploader.upload_stack('imgs', [np.asarray(rgb, dtype=np.uint8) for rgb in rgbs])
         if isinstance(dev_sems[0], torch.Tensor):
             sems = torch.stack([s.to(device=dev, dtype=torch.uint8) for s in dev_sems]).contiguous()
         else:
-            sems = up(np.stack(semsegs), np.uint8, torch.uint8)
-        return up(pc, np.float64, torch.float64), up(pc_cam_idx, np.int64, torch.int64), imgs, sems, semsegs
+            sems = self._uploader.upload_stack('sems', [np.asarray(m, dtype=np.uint8) for m in semsegs])
+        return (up('pc', pc, np.float64, torch.float64), up('cam', pc_cam_idx, np.int64, torch.int64), imgs, sems, semsegs)
 
     def _append_frame(self, rgbs, pc, pc_cam_idx, T_ego_global, ego_pose_z):
         T_ego_world, pose = self._ego_world(T_ego_global, ego_pose_z)

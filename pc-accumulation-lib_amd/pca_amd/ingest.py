@@ -116,6 +116,40 @@ class PinnedUploader:
         return out
 
 
+def _upload_stack(self, kind, arrays):
+    """k equally shaped host arrays -> ONE device tensor [k, ...]: the arrays are copied side by side (staging pool) into
+    one reused pinned block, which leaves in a single asynchronous H2D copy (the six camera images of a NuScenes observation:
+    26 MB that np.stack + a pageable .to(device) moved twice on the consumer's thread, blocking)."""
+    import torch
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    k, shape, tdtype = len(arrays), arrays[0].shape, _torch_dtype(arrays[0].dtype)
+    assert all(a.shape == shape and a.dtype == arrays[0].dtype for a in arrays)
+    n = k * int(np.prod(shape))
+    ring = self._slots.setdefault(kind, [0, [None] * self.DEPTH])
+    i = ring[0] % self.DEPTH
+    ring[0] += 1
+    slot = ring[1][i]
+    if slot is None or slot[0].numel() < n or slot[0].dtype != tdtype:
+        slot = (torch.empty(max(n, 1), dtype=tdtype, pin_memory=True), None)
+    elif slot[1] is not None:
+        slot[1].synchronize()
+    pin = slot[0][:n].view(k, *shape)
+    pool = self._copy_pool()
+    jobs = [pool.submit(np.copyto, pin[j].numpy(), arrays[j]) for j in range(1, k)]
+    np.copyto(pin[0].numpy(), arrays[0])
+    for j in jobs:
+        j.result()
+    dev = torch.empty((k, ) + tuple(shape), dtype=tdtype, device=self.device)
+    dev.copy_(pin, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    ring[1][i] = (slot[0], ev)
+    return dev
+
+
+PinnedUploader.upload_stack = _upload_stack
+
+
 def check_ring_lifetime(tensors, n_batches):
     """Raises if `n_batches` batches of a prefetching loader are about to be used together although the loader reuses its
     device buffers sooner: tensors it yields carry `_pca_ring` = the number of batches its ring holds."""
