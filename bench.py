@@ -682,6 +682,8 @@ def config5_pass(rank, world, scale, barrier, allmax, coll_dev, dist):
         barrier()
         t0 = time.perf_counter()
         run()
+        torch.cuda.synchronize()
+        mine_s = time.perf_counter() - t0                  # this rank's own wall time (an imbalance shows here)
         barrier()
         elapsed = allmax(time.perf_counter() - t0)
     finally:
@@ -716,6 +718,16 @@ def config5_pass(rank, world, scale, barrier, allmax, coll_dev, dist):
             out['gather_check'] = {'error': repr(e)[:300]}
         assert ok is not False, 'gathered BEV tensors differ from what the ranks produced'
     out['frames_this_rank_incl_warmup'] = my_frames
+    # per-rank wall times of the compute (before the closing barrier): the plan's imbalance as it was measured
+    if world > 1:
+        try:
+            ts = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+            dist.all_gather(ts, torch.tensor([mine_s], dtype=torch.float64, device=coll_dev))
+            out['seconds_per_rank'] = [float(t.item()) for t in ts]
+        except RuntimeError as e:
+            out['seconds_per_rank'] = {'error': repr(e)[:200]}
+    else:
+        out['seconds_per_rank'] = [mine_s]
     return out
 
 
@@ -873,7 +885,14 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))   # RCCL on ROCm
+            try:
+                dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))   # RCCL on ROCm
+            except Exception as e:                            # (no retry, no re-exec: the GPU is initialised by now)
+                sys.stderr.write(f'bench.py: rank {rank}: init_process_group(nccl) on cuda:{dev_index} failed: {e!r}\n'
+                                 f'  MASTER_ADDR={os.environ.get("MASTER_ADDR")} MASTER_PORT={os.environ.get("MASTER_PORT")} '
+                                 f'WORLD_SIZE={world} HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}\n'
+                                 f'  (rehearse the control flow without RCCL: PCA_BENCH_BACKEND=gloo)\n')
+                sys.exit(3)
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'

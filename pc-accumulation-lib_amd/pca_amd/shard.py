@@ -40,12 +40,13 @@ class Chunk:
     end: int          # one past the last frame
 
 
-def plan_chunks(seq_lengths, n_ranks, warmup_frames, max_imbalance=1.05):
-    """Cuts sequences into chunks of at most ceil(total / n_ranks * max_imbalance / k) frames so that an LPT
-    assignment is balanced, then assigns them.  Cost of a chunk = its frames + its warm-up prefix.
+def plan_chunks(seq_lengths, n_ranks, warmup_frames, max_imbalance=1.05, pieces_per_rank=1):
+    """Cuts sequences into chunks of about total / (n_ranks * pieces_per_rank) frames and assigns them longest first.
+    Cost of a chunk = its frames + its warm-up prefix.  More pieces per rank balance better and warm up more often: the
+    caller (sharded_run.plan) tries a few values and keeps the plan with the smallest busiest rank.
     Returns (chunks per rank, load per rank)."""
     total = float(sum(seq_lengths))
-    target = max(total / n_ranks, 1.0)
+    target = max(total / (n_ranks * max(int(pieces_per_rank), 1)), 1.0)
     chunks = []
     for s, n in enumerate(seq_lengths):
         pieces = max(1, int(np.ceil(n / target)))

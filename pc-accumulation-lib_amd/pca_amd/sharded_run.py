@@ -68,13 +68,59 @@ def plan(seq_Ts, n_ranks, accum_horizon=200., bev_horizon=80., min_spacing=1., m
     or more outside any BEV view)."""
     lengths = [int(np.asarray(T).reshape(-1, 16).shape[0]) for T in seq_Ts]
     rep = [replay(T, accum_horizon, bev_horizon, min_spacing) for T in seq_Ts]
-    per_rank, _ = shard.plan_chunks(lengths, n_ranks, warmup_frames=0, max_imbalance=max_imbalance)
-    jobs = []
-    for c in (c for r in per_rank for c in r):
-        oldest, samples = rep[c.seq]
-        warm = 0 if c.start == 0 else max(0, oldest[c.start] - 1)
-        jobs.append(ChunkJob(c.seq, warm, c.start, c.end, [(f, p) for f, p in samples if c.start <= f < c.end]))
-    items, loads = shard.lpt_assign([j.cost for j in jobs], n_ranks)       # re-balance with the real warm-up cost
+    def job_of(seq, start, end):
+        oldest, samples = rep[seq]
+        warm = 0 if start == 0 else max(0, oldest[start] - 1)
+        return ChunkJob(seq, warm, start, end, [(f, p) for f, p in samples if start <= f < end])
+
+    best = None
+    # (a) LPT over equal pieces of every sequence, at a few granularities: few large chunks warm up rarely but balance badly
+    #     over the ranks (nine sequences of 730 .. 14 384 frames), many small ones balance well and pay a horizon of warm-up each
+    for pieces in (1, 2, 3, 4, 6, 8):
+        per_rank, _ = shard.plan_chunks(lengths, n_ranks, warmup_frames=0, max_imbalance=max_imbalance, pieces_per_rank=pieces)
+        jobs = [job_of(c.seq, c.start, c.end) for r in per_rank for c in r]
+        items, loads = shard.lpt_assign([j.cost for j in jobs], n_ranks)   # balance with the real warm-up cost
+        if best is None or max(loads) < max(best[2]):
+            best = (jobs, items, loads)
+        if n_ranks == 1:
+            break
+    # (b) contiguous lanes: the sequences laid end to end (longest first) and cut into n_ranks stretches of equal COST, a
+    #     cut inside a sequence costing the next rank that sequence's warm-up: every rank warms up at most once more than it
+    #     has sequence starts, and the cost per rank is found by bisection
+    order = sorted(range(len(lengths)), key=lambda q: -lengths[q])
+
+    def lanes(cap):
+        jobs, items, loads, rank = [], [[] for _ in range(n_ranks)], [0.0] * n_ranks, 0
+        for q in order:
+            pos = 0
+            while pos < lengths[q]:
+                if rank >= n_ranks:
+                    return None
+                warm = 0 if pos == 0 else pos - job_of(q, pos, pos + 1).warm_start
+                room = cap - loads[rank] - warm
+                if room < 1 or (room < 32 and lengths[q] - pos > room and rank + 1 < n_ranks):
+                    rank += 1                               # not worth a warm-up for a few frames: the next rank starts here
+                    continue
+                take = int(min(lengths[q] - pos, room))
+                j = job_of(q, pos, pos + take)
+                items[rank].append(len(jobs))
+                jobs.append(j)
+                loads[rank] += j.cost
+                pos += take
+        return jobs, items, loads
+    if n_ranks > 1 and sum(lengths) > 0:
+        lo, hi = float(sum(lengths)) / n_ranks, float(sum(lengths)) + 1.0
+        found = None
+        for _ in range(40):
+            mid = 0.5 * (lo + hi)
+            got = lanes(mid)
+            if got is None:
+                lo = mid
+            else:
+                hi, found = mid, got
+        if found is not None and max(found[2]) < max(best[2]):
+            best = found
+    jobs, items, loads = best
     out = [sorted((jobs[i] for i in it), key=lambda j: (j.seq, j.start)) for it in items]
     return out, loads, [r[1] for r in rep]
 

@@ -83,3 +83,21 @@ def test_bench_config5_as_headline_workload():
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     d = last_json(r.stdout)
     assert d['scaling'] == 'strong' and d['n_gpus'] == 1 and d['value'] > 10 and d['config5']['frames'] == d['steps']
+
+
+def test_bench_four_ranks_gloo_rehearsal_of_config5():
+    """The strong-scaling job (BASELINE configs[4]) with FOUR ranks sharing the one GPU over gloo -- the most this box allows
+    (eight ranks on one card are not): every rank runs chunks, the checksums of what was gathered match, per-rank wall times
+    and the plan's loads are reported.  (The 8-rank PLAN is checked on the CPU: tests/test_sharded_plan.py.)"""
+    env = dict(os.environ, PCA_BENCH_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--workload', 'config5',
+                        '--config5-scale', '0.02'], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = last_json(r.stdout)
+    c5 = d['config5']
+    assert d['n_gpus'] == 4 and d['scaling'] == 'strong' and c5['n_gpus'] == 4
+    assert len(c5['frames_incl_warmup_per_rank']) == 4 and min(c5['frames_incl_warmup_per_rank']) > 0
+    assert len(c5['seconds_per_rank']) == 4 and all(t > 0 for t in c5['seconds_per_rank'])
+    assert c5['gather_check']['checksums_match'] is True and c5['ideal_speedup_of_this_plan'] > 2.5

@@ -42,3 +42,48 @@ def test_plan_tiles_the_sequences_and_warms_up_one_horizon():
             path = np.linalg.norm(np.diff(pos[j.warm_start:j.start + 1], axis=0), axis=1).sum()
             assert sc.ACCUM_H <= path <= sc.ACCUM_H + 4.0                   # one memory horizon, not more
     assert max(loads) / (sum(loads) / 4) < 1.4                             # four short sequences: coarse pieces
+
+
+def test_plan_of_the_nine_kitti360_sequences_on_eight_ranks():
+    """BASELINE configs[4] as the driver will run it (8 ranks): the nine sequence lengths of run_kitti360_bev_gen.py:172-173
+    (here at 1/4 scale, same proportions) cut into warm-up-prefixed chunks -- every rank gets work, every sample job lands
+    in exactly one chunk, and the plan's ideal speed-up (total frames / busiest rank incl. warm-up) clears the 6x target."""
+    lengths = [max(int(round(n * 0.25)), 2) for n in [11270, 14384, 730, 11440, 6610, 9578, 2960, 13855, 3540]]
+    c, s = np.cos(-0.002), np.sin(-0.002)
+    T = np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.]]) @ np.array(
+        [[1, 0, 0, -1.0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.]])
+    seqs = [np.tile(T, (n, 1, 1)) for n in lengths]
+    jobs, loads, samples = sr.plan(seqs, 8, 200., 80., 1.0)
+    assert len(jobs) == 8 and all(len(r) > 0 for r in jobs) and len(loads) == 8
+    total = sum(lengths)
+    assert total / max(loads) >= 7.0, (total, loads)
+    flat = [j for r in jobs for j in r]
+    for q, n in enumerate(lengths):
+        got = sorted(x for j in flat if j.seq == q for x in j.samples)
+        assert got == samples[q]
+        edges = sorted((j.start, j.end) for j in flat if j.seq == q)
+        assert edges[0][0] == 0 and edges[-1][1] == n and all(a[1] == b[0] for a, b in zip(edges[:-1], edges[1:]))
+
+
+def test_frame_exactly_at_the_horizon_is_held_by_the_chunk_too():
+    """A frame whose path distance from the newest is EXACTLY one horizon (unit steps, horizon 50.0: the eviction test is a
+    strict '> 0' on sums that are exact here) is kept by the sequential run; a chunk's warm-up starts one frame before the
+    oldest frame the sequential run still holds at the chunk's first frame, so the chunk holds it as well: from its first
+    own frame on, the replayed window of the chunk equals the sequential one, frame for frame."""
+    n = 260
+    T = np.eye(4)
+    T[0, 3] = -1.0                                                          # exactly 1 m per frame, no rotation
+    Ts = np.tile(T, (n, 1, 1))
+    oldest, samples = sr.replay(Ts, 50.0, 20.0, 1.0)
+    assert oldest[120] == 120 - 50                                          # 51 frames held: the one at exactly 50.0 m stays
+    jobs, _, _ = sr.plan([Ts], 2, 50.0, 20.0, 1.0)
+    second = max((j for r in jobs for j in r), key=lambda j: j.start)
+    assert second.start > 0 and second.warm_start == oldest[second.start] - 1
+    # replay of the chunk on its own: same window as the sequential run from its first own frame on
+    from pca_amd import host_logic as hl
+    track, first = hl.PoseTrack(), second.warm_start
+    for f in range(second.warm_start, second.end):
+        removed, _ = track.step(Ts[f], 50.0)
+        first += removed
+        if f >= second.start:
+            assert first == oldest[f] and len(track) == f + 1 - oldest[f], f
