@@ -29,7 +29,11 @@
 #define AB_THREADS 1024           // workgroup size of the hist / scatter kernels
 #endif
 #define MAX_G 512                 // workgroups of the hist / scatter kernels
+#ifndef C_THREADS
 #define C_THREADS 256             // workgroup size of the tile kernel
+#endif
+#define C_WAVES (C_THREADS / 64)
+#define C_HIST_WAVES 4            // waves that own a per-wave histogram (cells with more than 64 values)
 #define RGB_CAP 4096              // colour records resident in LDS
 #define CONTIG_MIN 2560           // tiles above this many records are read thread-contiguously (runs form)
 #define HEAVY_MIN_DEFAULT 2560    // tiles above this many records go to bev_tile_cells_heavy (PCA_BEV_HEAVY_MIN; the
@@ -116,13 +120,16 @@ struct PendHi { int64_t v[PCA_BEV_MAX_CHAIN]; };           // first point index 
 __device__ __forceinline__ bool apply_owed(const BevArgs &a, const PendHi &pend_hi, int64_t p, double &X, double &Y, double &Z)
 {
     bool moved = false;
-#pragma unroll
-    for (int k = 0; k < PCA_BEV_MAX_CHAIN; ++k)
-        if (k < a.n_pend && p < pend_hi.v[k]) {
-            const double nx = row4(a.pend_T[k].m + 0, X, Y, Z), ny = row4(a.pend_T[k].m + 4, X, Y, Z), nz = row4(a.pend_T[k].m + 8, X, Y, Z);
+#pragma unroll 1                                            // (not unrolled: the coefficients are fetched when their turn
+    for (int k = 0; k < a.n_pend; ++k) {                    //  comes -- unrolled, all 48 are preloaded into scalar registers
+        const int64_t hi = k == 0 ? pend_hi.v[0] : k == 1 ? pend_hi.v[1] : k == 2 ? pend_hi.v[2] : pend_hi.v[3];   // and spill)
+        if (p < hi) {
+            const Mat34 &T = a.pend_T[k];
+            const double nx = row4(T.m + 0, X, Y, Z), ny = row4(T.m + 4, X, Y, Z), nz = row4(T.m + 8, X, Y, Z);
             X = nx; Y = ny; Z = nz;
             moved = true;
         }
+    }
     return moved;
 }
 // BEV-frame key of one point (stored coordinates X, Y, Z after the owed transforms): KEY_INVALID = not in the view
@@ -703,7 +710,7 @@ struct TileLds {
     uint32_t off[NFK + 1];
     union {
         unsigned long long bits[TCELLS][24];                // cells with <= 64 values: one 64-lane mask per colour bit
-        uint32_t whist[C_THREADS / 64][2][3][128];          // cells with more: per-wave packed histograms [set][channel]
+        uint32_t whist[C_HIST_WAVES][2][3][128];            // cells with more: per-wave packed histograms [set][channel]
     };
 };
 
@@ -716,8 +723,8 @@ struct TileLds {
 __device__ __forceinline__ void small_cells_bitplanes(TileLds &L, const uint32_t *s_rgb)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = 0; i < TCELLS / 4; ++i) {
-        const int cell = 4 * i + wave;
+    for (int i = 0; i < TCELLS / C_WAVES; ++i) {
+        const int cell = C_WAVES * i + wave;
         const uint32_t n = L.S.cnt[2 * cell] + L.S.cnt[2 * cell + 1];
         if (n == 0 || n > 64) continue;
         const uint32_t v = (uint32_t)lane < n ? s_rgb[L.off[2 * cell] + lane] : 0u;
@@ -731,11 +738,11 @@ __device__ __forceinline__ void small_cells_bitplanes(TileLds &L, const uint32_t
 __device__ __forceinline__ void small_cells_select(TileLds &L)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NT = (TCELLS / 4) * 18;                   // targets of one wave
+    constexpr int NT = (TCELLS / C_WAVES) * 18;             // targets of one wave
     for (int t0 = 0; t0 < NT; t0 += 64) {
         const int t = t0 + lane;
         const int i = t / 18, qq = t - 18 * i;
-        const int cell = 4 * i + wave;
+        const int cell = C_WAVES * i + wave;
         const int set = qq / 6, ch = (qq % 6) >> 1, upper = qq & 1;
         bool ok = t < NT;
         uint32_t n_p = 0, n_f = 0;
@@ -773,9 +780,10 @@ __device__ __forceinline__ void small_cells_select(TileLds &L)
 __device__ __forceinline__ void wave_cells_hist(TileLds &L, const uint32_t *s_rgb)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= C_HIST_WAVES) return;                       // (the histograms' LDS is sized for four waves)
     uint32_t *h = &L.whist[wave][0][0][0];
-    for (int i = 0; i < TCELLS / 4; ++i) {
-        const int cell = 4 * i + wave;
+    for (int i = 0; i < TCELLS / C_HIST_WAVES; ++i) {
+        const int cell = C_HIST_WAVES * i + wave;
         const uint32_t n_p = L.S.cnt[2 * cell], n_f = L.S.cnt[2 * cell + 1], n = n_p + n_f;
         if (n <= 64) continue;
         for (int k = lane; k < 2 * 3 * 128 / 4; k += 64) reinterpret_cast<uint4 *>(h)[k] = make_uint4(0, 0, 0, 0);
@@ -1174,8 +1182,13 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
 // three dependent launches of pure latency; S samples in one launch of each kernel take little longer than one) ----
 template <bool I64>
 __global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void bev_tile_bin(const BevArgs a) { bev_tile_bin_body<I64>(a); }
+#if C_THREADS == 512
+#define C_OCC __attribute__((amdgpu_waves_per_eu(6, 6)))
+#else
+#define C_OCC
+#endif
 template <bool I64>
-__global__ __launch_bounds__(C_THREADS) void bev_tile_cells(const BevArgs a) { bev_tile_cells_body<I64>(a); }
+__global__ __launch_bounds__(C_THREADS) C_OCC void bev_tile_cells(const BevArgs a) { bev_tile_cells_body<I64>(a); }
 template <bool I64>
 __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs a) { bev_tile_cells_heavy_body<I64>(a); }
 // (the samples' argument blocks live in CONSTANT memory: the kernels read them through the scalar cache exactly as they read
@@ -1190,7 +1203,7 @@ __global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     if ((int)blockIdx.x < a.G) bev_tile_bin_body<I64>(a);
 }
 template <bool I64>
-__global__ __launch_bounds__(C_THREADS) void bev_tile_cells_many()
+__global__ __launch_bounds__(C_THREADS) C_OCC void bev_tile_cells_many()
 {
     bev_tile_cells_body<I64>(g_bev_many[blockIdx.y]);
 }
