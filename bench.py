@@ -49,7 +49,7 @@ MIN_TIMED_S = 0.25                        # ... and as many as it takes to have 
 MAX_REPEATS = 2000
 GATHER_CHUNK = 16                         # multi-GPU: BEV samples per asynchronous gather to rank 0
 HBM_PEAK_GBS = 8000.0                     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_TAG = 'r02'                       # profiles/<tag>_pmc_traffic.json: rocprofv3 PMC passes of THESE kernels
+PROFILE_TAG = 'r03'                       # profiles/<tag>_pmc_traffic*.json: rocprofv3 PMC passes of THESE kernels
 KITTI360_LENGTHS = [11270, 14384, 730, 11440, 6610, 9578, 2960, 13855, 3540]   # run_kitti360_bev_gen.py:172-173, end - start
 
 CAM_TO_VELO = np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418],
@@ -140,6 +140,22 @@ class ResidentSemSeg:
 
     def pred(self, rgb):
         return self.by_ptr[rgb.data_ptr()][None, None]
+
+
+def pmc_traffic(suffix='', prefixes=('bev_tile', )):
+    """HBM bytes per launch of the named kernels from the committed rocprofv3 PMC passes of THESE kernels
+    (profiles/<tag>_pmc_traffic<suffix>.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes with
+    --kernel-trace only; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the profiler
+    itself: (bytes, source) or (None, None) when the file is not there."""
+    path = os.path.join(ROOT, 'profiles', PROFILE_TAG + '_pmc_traffic' + suffix + '.json')
+    if not os.path.exists(path):
+        return None, None
+    pmc = json.load(open(path))['kernels']
+    names = [k for k in pmc if k.startswith(tuple(prefixes))]
+    if not names:
+        return None, None
+    total = sum(2.0 * pmc[k].get('FETCH_SIZE_KB', 0.0) + pmc[k].get('WRITE_SIZE_KB', 0.0) for k in names) * 1024.0
+    return total, 'profiles/%s_pmc_traffic%s.json (2*FETCH_SIZE + WRITE_SIZE, summed over %s)' % (PROFILE_TAG, suffix, ', '.join(sorted(names)))
 
 
 def present_index(acc):
@@ -256,6 +272,9 @@ def k1_batched_pass(pool_frames, n_distinct, batch=64, reps=20):
     def call():
         tmp.clear()
         tmp.append_kitti(frames, P_VELO_FRAME, IMG_H, IMG_W, FILTERS, descs=descs)
+    tmp.clear()
+    tmp.append_kitti(frames, P_VELO_FRAME, IMG_H, IMG_W, [], descs=descs)      # no class filter: the in-frustum count M_proj
+    m_proj = int(tmp.offsets()[-1])
     for _ in range(3):
         call()
     kept = int(tmp.offsets()[-1])
@@ -279,8 +298,9 @@ def k1_batched_pass(pool_frames, n_distinct, batch=64, reps=20):
     torch.cuda.synchronize()
     us = 1e6 * (time.perf_counter() - t0) / reps
     tmp.check_status()
-    alg = 16.0 * N_PTS * batch + 4.0 * (kept * 19.0 / 14.0 / 0.99) + 40.0 * kept
+    alg = 16.0 * N_PTS * batch + 4.0 * m_proj + 40.0 * kept
     return {'frames_per_call': batch, 'distinct_frames': n_distinct, 'points_per_call': N_PTS * batch, 'kept': kept,
+            'in_frustum': m_proj,
             'us_per_call_wall_back_to_back': us, 'us_per_call_hip_events': 1e3 * ev[0] / ev[1],
             'alg_bytes': alg, 'GBps': alg / us / 1e3, 'frac': alg / us / 1e3 / HBM_PEAK_GBS,
             'Mpoints_per_s': N_PTS * batch / us,
@@ -1051,6 +1071,11 @@ def main():
         big = device_pool(synth_frame, 7, 64)
         side['k1_batched_distinct'] = k1_batched_pass(big, 64)
         del big
+        ringpool = device_pool(ring_frame, 7, 64)          # 64 distinct ring-model frames: a real sweep's point ORDER
+        side['k1_batched_ring'] = k1_batched_pass(ringpool, 64)
+        side['k1_batched_ring']['note'] = ('ring-model frames (SURVEY 8d): consecutive points are neighbours in azimuth, so the '
+                                           'lanes of a gather share image lines; the uniform K-shape frame scatters them')
+        del ringpool
         side['nuscenes'] = nuscenes_pass()
         side['nuscenes']['scene'] = nuscenes_scene_pass()
         side['config4'] = config4_pass()
@@ -1083,14 +1108,7 @@ def main():
     achieved = alg[dominant] / (units[dominant] * 1e-6) / 1e9
     # HBM traffic per launch from the committed rocprofv3 PMC passes of THESE kernels (FETCH_SIZE / WRITE_SIZE in
     # separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); bench.py cannot run the profiler
-    traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, 'profiles', PROFILE_TAG + '_pmc_traffic.json')
-    if os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path))['kernels']
-        names = [k for k in pmc if k.startswith('bev_tile')]
-        if dominant == 'bev' and names:
-            traffic = sum(2.0 * pmc[k]['FETCH_SIZE_KB'] + pmc[k]['WRITE_SIZE_KB'] for k in names) * 1024.0
-            traffic_src = 'profiles/%s_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, summed over the unit\'s kernels)' % PROFILE_TAG
+    traffic, traffic_src = pmc_traffic('') if dominant == 'bev' else (None, None)
     roofline = {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_bytes_per_launch': alg[dominant], 'avg_launch_us': units[dominant],
@@ -1099,9 +1117,24 @@ def main():
                             'GBps': alg[k] / (units[k] * 1e-6) / 1e9,
                             'frac': alg[k] / (units[k] * 1e-6) / 1e9 / HBM_PEAK_GBS} for k in units},
                 'kernels': kern}
-    for k in ('k1_batched', 'k1_batched_distinct'):
+    if traffic:
+        roofline['frac_physical'] = traffic / (units[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS
+    k1_pmc_path = os.path.join(ROOT, 'profiles', PROFILE_TAG + '_k1_batched_summary.json')
+    k1_pmc = json.load(open(k1_pmc_path)) if os.path.exists(k1_pmc_path) else {}
+    for k, pool in (('k1_batched', 'pool8'), ('k1_batched_distinct', 'pool64'), ('k1_batched_ring', None)):
         if k in side:
             roofline[k] = side.pop(k)
+            phys = k1_pmc.get(pool, {}).get('physical_MB') if pool else None
+            if phys:                                       # PMC bytes of the two kernels / the wall time of the call
+                roofline[k]['traffic'] = phys * 1e6
+                roofline[k]['frac_physical'] = phys * 1e6 / (roofline[k]['us_per_call_wall_back_to_back'] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                roofline[k]['traffic_source'] = 'profiles/%s_k1_batched_summary.json' % PROFILE_TAG
+    for blk, suffix, prefixes in (('ring_model', '_ring', ('bev_tile', )), ('config4', '_config4', ('bev_tile', )),
+                                  ('nuscenes', '_nusc', ('bev_tile', 'k1n_'))):
+        if blk in side:
+            t, src = pmc_traffic(suffix, prefixes)
+            side[blk]['traffic'] = t
+            side[blk]['traffic_source'] = src
 
     out = {
         'metric': 'Mpoints/s projected+accumulated and BEV frames/s @256x256; 1/2/4/8 GPU',
