@@ -29,6 +29,12 @@
 #define AB_THREADS 1024           // workgroup size of the hist / scatter kernels
 #endif
 #define MAX_G 512                 // workgroups of the hist / scatter kernels
+#ifndef BIN_UNR
+#define BIN_UNR 4
+#endif
+#ifndef BIN_REG_P
+#define BIN_REG_P 12              // points per thread of level 1 that stay in registers between its passes (a multiple of 4)
+#endif
 #ifndef C_THREADS
 #define C_THREADS 256             // workgroup size of the tile kernel
 #endif
@@ -255,8 +261,8 @@ __device__ unsigned long long g_dbg_stamps[1024][8];   // PCA_BEV_DBG=8|16|32: p
 template <bool I64>
 __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
 {
-    constexpr int REG_P = I64 ? 0 : 12;
-    constexpr int UNR = 4;          // independent points per thread and iteration (memory-level parallelism)
+    constexpr int REG_P = I64 ? 0 : BIN_REG_P;
+    constexpr int UNR = BIN_UNR;    // independent points per thread and iteration (memory-level parallelism)
     extern __shared__ uint32_t s_lds[];                     // [T] histogram, [T] cursors
     __shared__ uint32_t s_wsum[AB_THREADS / 64];
     uint32_t *s_h = s_lds, *s_cur = s_lds + a.T;
@@ -322,14 +328,27 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
                 n_moved = n_owe > n_moved ? n_owe : n_moved;
                 const double t0 = Tk.m[0], t1 = Tk.m[1], t2 = Tk.m[2], t3 = Tk.m[3], t4 = Tk.m[4], t5 = Tk.m[5], t6 = Tk.m[6],
                              t7 = Tk.m[7], t8 = Tk.m[8], t9 = Tk.m[9], t10 = Tk.m[10], t11 = Tk.m[11];
+                // (uniform) every point of this batch owes it -- all but the batches that reach into the newest frames: no selects
+                const uint32_t batch_end = (uint32_t)(j0 + UNR) * AB_THREADS < n_reg ? (uint32_t)(j0 + UNR) * AB_THREADS : n_reg;
+                const bool all_owe = n_owe >= batch_end;
+                if (all_owe) {
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const uint32_t i = (uint32_t)(j0 + u) * AB_THREADS + threadIdx.x;
-                    const bool owed = i < n_owe;
-                    const double nx = fma(t2, Z[u], fma(t1, Y[u], t0 * X[u])) + t3;
-                    const double ny = fma(t6, Z[u], fma(t5, Y[u], t4 * X[u])) + t7;
-                    const double nz = fma(t10, Z[u], fma(t9, Y[u], t8 * X[u])) + t11;
-                    X[u] = owed ? nx : X[u]; Y[u] = owed ? ny : Y[u]; Z[u] = owed ? nz : Z[u];
+                    for (int u = 0; u < UNR; ++u) {
+                        const double nx = fma(t2, Z[u], fma(t1, Y[u], t0 * X[u])) + t3;
+                        const double ny = fma(t6, Z[u], fma(t5, Y[u], t4 * X[u])) + t7;
+                        const double nz = fma(t10, Z[u], fma(t9, Y[u], t8 * X[u])) + t11;
+                        X[u] = nx; Y[u] = ny; Z[u] = nz;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const uint32_t i = (uint32_t)(j0 + u) * AB_THREADS + threadIdx.x;
+                        const bool owed = i < n_owe;
+                        const double nx = fma(t2, Z[u], fma(t1, Y[u], t0 * X[u])) + t3;
+                        const double ny = fma(t6, Z[u], fma(t5, Y[u], t4 * X[u])) + t7;
+                        const double nz = fma(t10, Z[u], fma(t9, Y[u], t8 * X[u])) + t11;
+                        X[u] = owed ? nx : X[u]; Y[u] = owed ? ny : Y[u]; Z[u] = owed ? nz : Z[u];
+                    }
                 }
             }
             if (a.write_back && n_moved > 0) {
