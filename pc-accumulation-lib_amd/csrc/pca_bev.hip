@@ -29,6 +29,9 @@
 #define AB_THREADS 1024           // workgroup size of the hist / scatter kernels
 #endif
 #define MAX_G 512                 // workgroups of the hist / scatter kernels
+#ifndef BIN_RUNR
+#define BIN_RUNR 4                // ... of the register path
+#endif
 #ifndef BIN_UNR
 #define BIN_UNR 4
 #endif
@@ -67,7 +70,7 @@ struct BevArgs {
     int pend_slot_end[PCA_BEV_MAX_CHAIN];   // ascending
     Mat34 pend_T[PCA_BEV_MAX_CHAIN];
     int tx, T, G;
-    int tile_mult;        // bev_tile_cells: workgroup -> tile permutation (coprime to T)
+    int tile_mult;        // bev_tile_cells: workgroup -> tile permutation (coprime to its period: T / 4 or T)
     int heavy_min;        // tiles with more records than this are bev_tile_cells_heavy's (<= RGB_CAP)
     uint32_t *key;        // [max_points]
     uint32_t *bh;         // [T][G] kept records per (tile, workgroup)
@@ -262,7 +265,7 @@ template <bool I64>
 __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
 {
     constexpr int REG_P = I64 ? 0 : BIN_REG_P;
-    constexpr int UNR = BIN_UNR;    // independent points per thread and iteration (memory-level parallelism)
+    constexpr int UNR = BIN_RUNR;   // independent points per thread and iteration of the register path
     extern __shared__ uint32_t s_lds[];                     // [T] histogram, [T] cursors
     __shared__ uint32_t s_wsum[AB_THREADS / 64];
     uint32_t *s_h = s_lds, *s_cur = s_lds + a.T;
@@ -299,8 +302,9 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
         const double *xb = a.st.x + w.c_lo, *yb = a.st.y + w.c_lo, *zb = a.st.z + w.c_lo;
         const uint8_t *db = a.st.dyn + w.c_lo;
         const ViewConst vc = view_const(a);
-        // (Issuing the loads of batch b + 1 before batch b is worked on -- two register sets -- was tried: 128 VGPRs with
-        // spills, 6 us slower.  So was dealing the window to the workgroups in round-robin blocks of 1024 points instead of
+        // (Issuing the loads of batch b + 1 before batch b is worked on -- two register sets -- was tried twice: with batches
+        // of four 128 VGPRs and spills, 6 us slower; with batches of 2 / 3 / 4 and no spills 62.1 / 62.0 / 63.1 against 60.6 us:
+        // the pass does not wait for its point loads.  So was dealing the window to the workgroups in round-robin blocks of 1024 points instead of
         // contiguous chunks, to even out their run times: every workgroup then pays the kept-point work, +4 us.)
         double XA[UNR], YA[UNR], ZA[UNR];
         uint32_t DA[UNR];
@@ -378,11 +382,12 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     }
     BIN_STAMP(1);
     // ---- pass A, memory part (what the chunk holds beyond the registers) ----
-    for (int64_t base = reg_hi + threadIdx.x; base < w.c_hi; base += UNR * AB_THREADS) {
-        double X[UNR], Y[UNR], Z[UNR];
-        uint8_t D[UNR];
+    constexpr int MUNR = BIN_UNR;
+    for (int64_t base = reg_hi + threadIdx.x; base < w.c_hi; base += MUNR * AB_THREADS) {
+        double X[MUNR], Y[MUNR], Z[MUNR];
+        uint8_t D[MUNR];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
+        for (int u = 0; u < MUNR; ++u) {
             const int64_t p = base + u * AB_THREADS;
             const bool in = p < w.c_hi;
             X[u] = in ? a.st.x[p] : 0.0;
@@ -391,7 +396,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
             D[u] = in ? a.st.dyn[p] : (uint8_t)1;
         }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
+        for (int u = 0; u < MUNR; ++u) {
             const int64_t p = base + u * AB_THREADS;
             if (p >= w.c_hi) continue;
             const BinPoint b = bin_point(a, w, pend_hi, p, X[u], Y[u], Z[u], D[u]);
@@ -450,16 +455,16 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     }
     BIN_STAMP(4);
     const bool stale = a.n_pend > 0 && !a.write_back;
-    for (int64_t base = reg_hi + threadIdx.x; base < w.c_hi; base += UNR * AB_THREADS) {
-        uint32_t key[UNR], pos[UNR], rgbs[UNR];
-        double zz[UNR], iv[UNR];
+    for (int64_t base = reg_hi + threadIdx.x; base < w.c_hi; base += MUNR * AB_THREADS) {
+        uint32_t key[MUNR], pos[MUNR], rgbs[MUNR];
+        double zz[MUNR], iv[MUNR];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
+        for (int u = 0; u < MUNR; ++u) {
             const int64_t p = base + u * AB_THREADS;
             key[u] = p < w.c_hi ? a.key[p - w.lo] : KEY_INVALID;
         }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
+        for (int u = 0; u < MUNR; ++u) {
             const int64_t p = base + u * AB_THREADS;
             const bool ok = key[u] != KEY_INVALID;
             rgbs[u] = ok ? a.st.rgbs[p] : 0u;
@@ -473,7 +478,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
             pos[u] = ok ? seg + atomicAdd(&s_cur[key[u] >> 7], 1u) : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u)
+        for (int u = 0; u < MUNR; ++u)
             if (key[u] != KEY_INVALID) bin_store<I64>(a, pos[u], key[u], rgbs[u], zz[u], iv[u]);
     }
     BIN_STAMP(5);
@@ -532,6 +537,27 @@ __device__ __forceinline__ uint32_t recmap_at(const RecMap &M, int G, uint32_t i
     }
     return M.base[lo] + (i - M.pre[lo]);
 }
+// The light tile kernel's lookup: owner[i] = the piece record i lies in, written once per tile by the threads that own the
+// pieces (a piece holds ~3 records of a tile), so that a record costs three LDS reads instead of the ten-step search
+// (50 of the ~200 vector instructions a record cost).  `owner` holds the tile's count of entries (<= RGB_CAP).  Ends with
+// a barrier.
+__device__ __forceinline__ void recmap_expand(const RecMap &M, uint16_t *owner, int G, int nthreads)
+{
+    const int per = (G + nthreads - 1) / nthreads;
+    const int g0 = threadIdx.x * per;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < per && g0 + k < G) {
+            const uint32_t lo = M.pre[g0 + k], hi = M.pre[g0 + k + 1];
+            for (uint32_t r = lo; r < hi; ++r) owner[r] = (uint16_t)(g0 + k);
+        }
+    __syncthreads();
+}
+__device__ __forceinline__ uint32_t recmap_at(const RecMap &M, const uint16_t *owner, uint32_t i)
+{
+    const uint32_t g = owner[i];
+    return M.base[g] + (i - M.pre[g]);
+}
 // the tile joins the queue of bev_tile_cells_heavy, larger size classes first (classes of 1024 records): its workgroups
 // draw items one at a time and the kernel ends with the last item to finish
 __device__ __forceinline__ void heavy_push(const BevArgs &a, int tile, uint32_t count)
@@ -576,24 +602,64 @@ __device__ __forceinline__ void run_reset(Run &r, uint32_t key)
 {
     r.key = key; r.cnt = 0; r.road = 0; r.dyn = 0; r.zmin = ~0ull; r.zmax = 0; r.ihi = 0; r.ilo = 0; r.zhi = 0; r.zlo = 0;
 }
+// v = hi * 2^-20 + lo * 2^-60 exactly (hi = floor(v 2^20), lo = rint(frac 2^40)): the two terms of the fixed-point sums.
+// The conversions double -> int64 go through the 1.5 * 2^52 trick (one add and a 64-bit subtract instead of the ~8
+// instructions of the emulated cast; the add rounds to nearest-even like rint) while |v 2^20| < 2^51.
+__device__ __forceinline__ void fx_split(double v, long long &hi, long long &lo)
+{
+    const double sc = v * FX_HI, fl = floor(sc);
+    constexpr double MAGIC = 6755399441055744.0;            // 1.5 * 2^52 = 0x4338000000000000
+    if (fabs(sc) < 2251799813685248.0) {                    // 2^51
+        hi = __double_as_longlong(fl + MAGIC) - 0x4338000000000000ll;
+        lo = __double_as_longlong((sc - fl) * FX_LO + MAGIC) - 0x4338000000000000ll;
+    } else {
+        hi = (long long)fl;
+        lo = (long long)rint((sc - fl) * FX_LO);
+    }
+}
 __device__ __forceinline__ void run_add(Run &r, bool extra, uint32_t c, double z, double iv)
 {
     const unsigned long long zkey = f64_order_key(z);
     r.cnt++;
     r.zmin = zkey < r.zmin ? zkey : r.zmin;
     if (extra) {
-        const double sc = z * FX_HI, fl = floor(sc);
+        long long hi, lo;
+        fx_split(z, hi, lo);
         r.zmax = zkey > r.zmax ? zkey : r.zmax;
-        r.zhi += (long long)fl;
-        r.zlo += (long long)rint((sc - fl) * FX_LO);
+        r.zhi += hi;
+        r.zlo += lo;
     }
     if (c & FLAG_DYNOBJ) r.dyn++;
     if (c & FLAG_ROAD) {
-        const double sc = iv * FX_HI, fl = floor(sc);
+        long long hi, lo;
+        fx_split(iv, hi, lo);
         r.road++;
-        r.ihi += (long long)fl;
-        r.ilo += (long long)rint((sc - fl) * FX_LO);
+        r.ihi += hi;
+        r.ilo += lo;
     }
+}
+// one record on its own (a run of length one without the bookkeeping): returns its rank inside its (cell,set)
+__device__ __forceinline__ uint32_t rec_add(TileStats &S, bool extra, uint32_t key, uint32_t c, double z, double iv)
+{
+    const unsigned long long zkey = f64_order_key(z);
+    const uint32_t rank = atomicAdd(&S.cnt[key], 1u);
+    atomicMin(&S.zk[key], zkey);
+    if (extra) {
+        long long hi, lo;
+        fx_split(z, hi, lo);
+        atomicMax(&S.zmaxk[key], zkey);
+        atomicAdd(&S.zhi[key], (unsigned long long)hi);
+        atomicAdd(&S.zlo[key], (unsigned long long)lo);
+    }
+    if (c & FLAG_DYNOBJ) atomicAdd(&S.dyn[key], 1u);
+    if (c & FLAG_ROAD) {
+        long long hi, lo;
+        fx_split(iv, hi, lo);
+        atomicAdd(&S.road[key], 1u);
+        atomicAdd(&S.ihi[key], (unsigned long long)hi);
+        atomicAdd(&S.ilo[key], (unsigned long long)lo);
+    }
+    return rank;
 }
 // returns the rank of the run's first record inside its (cell,set)
 __device__ __forceinline__ uint32_t run_flush(TileStats &S, bool extra, const Run &r)
@@ -684,6 +750,20 @@ __device__ __forceinline__ void tile_finalize_write(const BevArgs &a, const Tile
     const int row0 = (tile / a.tx) * TS, col0 = (tile % a.tx) * TS;
     const int64_t ncell = (int64_t)q.px * q.px;
     const int n_planes = extra ? 21 + PCA_BEV_EXTRA_PLANES * 3 : 21;
+    // fp16 planes only, whole tile inside the grid: one 16-byte store per (plane, row of the tile) instead of eight 2-byte ones
+    static_assert(TS == 8, "a tile row of fp16 cells is one uint4");
+    if (!a.planes && a.planes_f16 && !extra && cell_lo == 0 && cell_hi == TCELLS && (q.px % TS) == 0 &&
+        (reinterpret_cast<uintptr_t>(a.planes_f16) & 15) == 0) {
+        if (threadIdx.x < 21 * TS) {
+            const int plane = threadIdx.x / TS, r = threadIdx.x % TS;
+            const double *src = &s_out[plane][r * TS];
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = (uint32_t)f64_to_f16_bits(src[2 * k]) | ((uint32_t)f64_to_f16_bits(src[2 * k + 1]) << 16);
+            *reinterpret_cast<uint4 *>(a.planes_f16 + (int64_t)plane * ncell + (int64_t)(row0 + r) * q.px + col0) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < n_planes * TCELLS; idx += nthreads) {
         const int plane = idx / TCELLS, lc = idx % TCELLS;
         const int row = row0 + lc / TS, col = col0 + lc % TS;
@@ -727,9 +807,11 @@ __device__ __forceinline__ void hist16_medians(TileStats &S, const uint32_t *row
 struct TileLds {
     TileStats S;
     uint32_t off[NFK + 1];
+    uint32_t n_big;                                         // cells of the tile with more than 64 values
     union {
         unsigned long long bits[TCELLS][24];                // cells with <= 64 values: one 64-lane mask per colour bit
         uint32_t whist[C_HIST_WAVES][2][3][128];            // cells with more: per-wave packed histograms [set][channel]
+        uint16_t owner[RGB_CAP];                            // pass 1: record -> piece (recmap_expand)
     };
 };
 
@@ -742,16 +824,59 @@ struct TileLds {
 __device__ __forceinline__ void small_cells_bitplanes(TileLds &L, const uint32_t *s_rgb)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = 0; i < TCELLS / C_WAVES; ++i) {
+    constexpr int PER_WAVE = TCELLS / C_WAVES;              // this wave's cells: C_WAVES * i + wave
+    static_assert(PER_WAVE <= 64, "one lane per cell of the wave");
+    uint32_t n_mine = 0;
+    if (lane < PER_WAVE) n_mine = L.S.cnt[2 * (C_WAVES * lane + wave)] + L.S.cnt[2 * (C_WAVES * lane + wave) + 1];
+    // The transpose works on the two halves of the wave independently: two cells of at most 32 values share one (the
+    // uniform 200-frame window averages 25 values per cell), lanes 0..31 holding the first cell's values, 32..63 the second's.
+    unsigned long long half = __ballot(n_mine >= 1 && n_mine <= 32), full = __ballot(n_mine > 32 && n_mine <= 64);
+    while (half) {
+        const int ia = __ffsll(half) - 1;
+        half &= half - 1;
+        const int ib = half ? __ffsll(half) - 1 : -1;
+        half &= half - 1;                                   // (0 & anything stays 0)
+        const int i = lane < 32 ? ia : ib;
+        const int l = lane & 31;
+        uint32_t v = 0;
+        int cell = 0;
+        if (i >= 0) {
+            cell = C_WAVES * i + wave;
+            const uint32_t n = L.S.cnt[2 * cell] + L.S.cnt[2 * cell + 1];
+            if ((uint32_t)l < n) v = s_rgb[L.off[2 * cell] + l];
+        }
+        const uint32_t t = wave_bit_transpose32(v);
+        if (i >= 0 && l < 24) L.bits[cell][l] = (unsigned long long)t;
+    }
+    while (full) {
+        const int i = __ffsll(full) - 1;
+        full &= full - 1;
         const int cell = C_WAVES * i + wave;
         const uint32_t n = L.S.cnt[2 * cell] + L.S.cnt[2 * cell + 1];
-        if (n == 0 || n > 64) continue;
         const uint32_t v = (uint32_t)lane < n ? s_rgb[L.off[2 * cell] + lane] : 0u;
         // 64 values x 24 bits -> 24 masks of 64 lanes: a bit-matrix transpose across lanes (30 VALU; 24 ballots with
         // their select chains were 130)
         const uint32_t t = wave_bit_transpose32(v);
         if ((lane & 31) < 24) reinterpret_cast<uint32_t *>(&L.bits[cell][lane & 31])[lane >> 5] = t;
     }
+}
+
+// the walk down the eight bit planes of one target; W = uint32_t when no cell of the wave's batch holds more than 32 values
+template <typename W>
+__device__ __forceinline__ uint32_t bitplane_select(const unsigned long long *planes, W cand, uint32_t k)
+{
+    uint32_t val = 0;
+#pragma unroll
+    for (int b = 7; b >= 0; --b) {
+        const W B = (W)planes[b];
+        const W zeros = cand & ~B;
+        const uint32_t cz = sizeof(W) == 8 ? (uint32_t)__popcll((unsigned long long)zeros) : (uint32_t)__popc((uint32_t)zeros);
+        const bool take0 = k < cz;
+        cand = take0 ? zeros : (W)(cand & B);
+        k = take0 ? k : k - cz;
+        val |= take0 ? 0u : (1u << b);
+    }
+    return val;
 }
 
 __device__ __forceinline__ void small_cells_select(TileLds &L)
@@ -770,23 +895,16 @@ __device__ __forceinline__ void small_cells_select(TileLds &L)
         ok = ok && n > 0 && n <= 64;
         const unsigned long long m_p = n_p >= 64 ? ~0ull : ((1ull << n_p) - 1ull);
         const unsigned long long m_all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-        unsigned long long cand = set == 0 ? m_p : (set == 1 ? (m_all & ~m_p) : m_all);
+        const unsigned long long cand = set == 0 ? m_p : (set == 1 ? (m_all & ~m_p) : m_all);
         const uint32_t n_s = (uint32_t)__popcll(cand);
         ok = ok && n_s > 0;
-        uint32_t k = upper ? (n_s >> 1) : ((n_s - 1) >> 1);
+        const uint32_t k = upper ? (n_s >> 1) : ((n_s - 1) >> 1);
         uint32_t val = 0;
-        if (ok) {
-            const unsigned long long *planes = &L.bits[cell][8 * ch];
-#pragma unroll
-            for (int b = 7; b >= 0; --b) {
-                const unsigned long long B = planes[b];
-                const unsigned long long zeros = cand & ~B;
-                const uint32_t cz = (uint32_t)__popcll(zeros);
-                const bool take0 = k < cz;
-                cand = take0 ? zeros : (cand & B);
-                k = take0 ? k : k - cz;
-                val |= take0 ? 0u : (1u << b);
-            }
+        const unsigned long long *planes = &L.bits[ok ? cell : 0][8 * ch];
+        if (__any(ok && n > 32)) {
+            if (ok) val = bitplane_select<unsigned long long>(planes, cand, k);
+        } else {
+            if (ok) val = bitplane_select<uint32_t>(planes, (uint32_t)cand, k);
         }
         // the partner target (lower <-> upper middle) is the adjacent lane: quad_perm [1,0,3,2]
         const uint32_t other = dpp_or<0xb1>(0u, val);
@@ -931,9 +1049,23 @@ __device__ __forceinline__ void bev_tile_cells_body(const BevArgs &a)
     uint32_t *s_rgb = reinterpret_cast<uint32_t *>(s_buf);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool extra = a.extra != nullptr;
-    // Dense tiles are neighbours in the grid (they follow the driven path).  Workgroup b takes tile b * tile_mult mod T
-    // (tile_mult coprime to T), which interleaves them with the empty ones in dispatch order.
-    const int tile = (int)(((int64_t)blockIdx.x * a.tile_mult) % a.T);
+    // Dense tiles are neighbours in the grid (they follow the driven path), and all tiles are resident at once (four per CU at
+    // 256 x 256): the kernel lasts as long as the CU with the most records.  Workgroups b, b + T/4, b + T/2, b + 3T/4 share a CU
+    // (round-robin dispatch); they take tiles a quarter of the grid apart in BOTH directions -- a band of rows each, the
+    // columns rotated by a quarter per band -- so that a CU samples the density at four spread-out places instead of four
+    // tiles of one column (the CU totals then ranged 3 800..8 400 records, the kernel's span 30 us against a mean tile life of
+    // 23).  Inside a band, workgroup i takes place i * tile_mult mod T/4 (tile_mult coprime to T/4), which interleaves dense
+    // and empty tiles in dispatch order.  Grids whose tile count per side is not a multiple of four: one permutation of all.
+    int tile;
+    if ((a.tx & 3) == 0) {
+        const int Tq = a.T >> 2, bw = a.tx >> 2;
+        const int q = (int)blockIdx.x / Tq, i = (int)blockIdx.x - q * Tq;
+        const int i2 = (int)(((int64_t)i * a.tile_mult) % Tq);
+        const int row = q * bw + i2 / a.tx, col = (i2 % a.tx + q * bw) % a.tx;
+        tile = row * a.tx + col;
+    } else {
+        tile = (int)(((int64_t)blockIdx.x * a.tile_mult) % a.T);
+    }
     const unsigned long long t_begin = wall_clock64();
     RecMap &M = *reinterpret_cast<RecMap *>(s_buf);         // lives in the colour buffer until pass 2 fills that
     static_assert(sizeof(RecMap) <= sizeof(s_buf), "RecMap aliases the colour buffer");
@@ -952,35 +1084,55 @@ __device__ __forceinline__ void bev_tile_cells_body(const BevArgs &a)
     constexpr int RPT = RGB_CAP / C_THREADS;
     constexpr int HALF = RPT / 2;                           // two rounds of loads: bounds the registers in flight
     const bool contig = (r_hi - r_lo) > CONTIG_MIN;
-    uint32_t kr[RPT], cc[RPT], end_base[RPT];
-    uint32_t is_end = 0;
-    Run run;
-    run_reset(run, RUN_NONE);
+    uint32_t kr[RPT], cc[RPT];
+    recmap_expand(M, L.owner, a.G, C_THREADS);
+    if (!contig) {
+        // records a workgroup-width apart share a cell only by chance: every record is counted on its own
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        uint32_t k[HALF], c[HALF];
-        double z[HALF], iv[HALF];
+        for (int h = 0; h < 2; ++h) {
+            uint32_t k[HALF], c[HALF];
+            double z[HALF], iv[HALF];
 #pragma unroll
-        for (int u = 0; u < HALF; ++u) {
-            const int uu = h * HALF + u;
-            const uint32_t r = r_lo + (contig ? threadIdx.x * RPT + uu : uu * C_THREADS + threadIdx.x);
-            k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
-            if (r < r_hi) load_rec<I64>(a, recmap_at(M, a.G, r), k[u], c[u], z[u], iv[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < HALF; ++u) {
-            const int uu = h * HALF + u;
-            kr[uu] = RUN_NONE; cc[uu] = c[u] & 0xffffffu; end_base[uu] = 0;
-            if (k[u] == RUN_NONE) continue;
-            if (k[u] != run.key) {
-                if (run.key != RUN_NONE && uu > 0) { end_base[uu - 1] = run_flush(L.S, extra, run); is_end |= 1u << (uu - 1); }
-                run_reset(run, k[u]);
+            for (int u = 0; u < HALF; ++u) {
+                const uint32_t r = r_lo + (uint32_t)(h * HALF + u) * C_THREADS + threadIdx.x;
+                k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
+                if (r < r_hi) load_rec<I64>(a, recmap_at(M, L.owner, r), k[u], c[u], z[u], iv[u]);
             }
-            kr[uu] = k[u] | (run.cnt << 8);                 // position in the run, for now
-            run_add(run, extra, c[u], z[u], iv[u]);
+#pragma unroll
+            for (int u = 0; u < HALF; ++u) {
+                const int uu = h * HALF + u;
+                kr[uu] = RUN_NONE; cc[uu] = c[u] & 0xffffffu;
+                if (k[u] != RUN_NONE) kr[uu] = k[u] | (rec_add(L.S, extra, k[u], c[u], z[u], iv[u]) << 8);
+            }
         }
-    }
-    {
+    } else {
+        uint32_t end_base[RPT];
+        uint32_t is_end = 0;
+        Run run;
+        run_reset(run, RUN_NONE);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t k[HALF], c[HALF];
+            double z[HALF], iv[HALF];
+#pragma unroll
+            for (int u = 0; u < HALF; ++u) {
+                const uint32_t r = r_lo + threadIdx.x * RPT + (uint32_t)(h * HALF + u);
+                k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
+                if (r < r_hi) load_rec<I64>(a, recmap_at(M, L.owner, r), k[u], c[u], z[u], iv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < HALF; ++u) {
+                const int uu = h * HALF + u;
+                kr[uu] = RUN_NONE; cc[uu] = c[u] & 0xffffffu; end_base[uu] = 0;
+                if (k[u] == RUN_NONE) continue;
+                if (k[u] != run.key) {
+                    if (run.key != RUN_NONE && uu > 0) { end_base[uu - 1] = run_flush(L.S, extra, run); is_end |= 1u << (uu - 1); }
+                    run_reset(run, k[u]);
+                }
+                kr[uu] = k[u] | (run.cnt << 8);             // position in the run, for now
+                run_add(run, extra, c[u], z[u], iv[u]);
+            }
+        }
         uint32_t b = run.key != RUN_NONE ? run_flush(L.S, extra, run) : 0u;
 #pragma unroll
         for (int uu = RPT - 1; uu >= 0; --uu) {
@@ -998,6 +1150,8 @@ __device__ __forceinline__ void bev_tile_cells_body(const BevArgs &a)
         L.off[2 * lane] = excl;
         L.off[2 * lane + 1] = excl + c0;
         if (lane == 63) L.off[NFK] = inc;
+        const unsigned long long big = __ballot(c0 + c1 > 64);  // (lane = cell)
+        if (lane == 0) L.n_big = (uint32_t)__popcll(big);
     }
     __syncthreads();
     // ---- pass 2: colours sorted by (cell,set) in LDS, then the medians ----
@@ -1011,8 +1165,10 @@ __device__ __forceinline__ void bev_tile_cells_body(const BevArgs &a)
     small_cells_select(L);
     __syncthreads();                                        // the bit planes' LDS becomes the per-wave histograms
     DBG_STAMP(16, 5);
-    wave_cells_hist(L, s_rgb);
-    __syncthreads();
+    if (L.n_big) {                                          // (uniform; no cell above 64 values: nothing to do, no barrier)
+        wave_cells_hist(L, s_rgb);
+        __syncthreads();
+    }
     DBG_STAMP(16, 6);
     tile_finalize_write(a, L.S, reinterpret_cast<double(*)[TCELLS]>(s_buf), tile, C_THREADS);
     cells_drain<I64>(a, L, s_buf, false);
@@ -1334,8 +1490,9 @@ static int bev_prepare(pca_ctx *ctx, const pca_store *store, const double *inten
     a.status = ctx->ticket + 1;
     {
         auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
-        int m = (int)(a.T * 0.6180339887) | 1;
-        while (m > 1 && gcd(m, a.T) != 1) m -= 2;
+        const int Tp = (a.tx & 3) == 0 ? a.T / 4 : a.T;     // the permutation's period (bev_tile_cells_body)
+        int m = (int)(Tp * 0.6180339887) | 1;
+        while (m > 1 && gcd(m, Tp) != 1) m -= 2;
         a.tile_mult = m < 1 ? 1 : m;
     }
     a.heavy_hint = nullptr; a.heavy_hint_known = 0; a.heavy_launched = 1;
