@@ -314,6 +314,18 @@ int pca_host_ego_to_grid(const double *full, int F, const double R[9], double dx
                          double *rows, int32_t *start);
 
 /* ------------------------------------------------------------------------------------------------
+ * Host arrays -> device for callers that hold their observations in pageable host memory -- what the reference's drivers
+ * pass to integrate() (run_kitti360_bev_gen.py:173-190: numpy arrays straight from the loader).  src[k] (pageable, bytes[k]
+ * long) is copied into pinned[k] (page-locked, caller-owned, at least bytes[k]) on a small pool of host threads, then
+ * pinned[k] -> dev[k] is enqueued on `stream` (asynchronous).  The pinned blocks may be reused once the stream has passed
+ * the copies (record an event after the call).  PCA_STAGING_THREADS (default 3; 0 = the calling thread alone) and
+ * PCA_STAGING_SPIN_US (default 2000: how long the pool's threads poll after a job before they sleep) tune the pool.
+ * Returns 0, -1 for bad arguments, -2 if a copy could not be enqueued.
+ * ------------------------------------------------------------------------------------------------ */
+int pca_host_stage_h2d(int n, const void *const *src, void *const *pinned, void *const *dev, const int64_t *bytes,
+                       void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Host helper (no device work): the accumulator's pose track -- the per-frame bookkeeping integrate() does on Python
  * lists in the reference.  Replaces sem_pc_accum.py:156-165 (update_poses), :185-209 (remove_observations), :211-228
  * (comp_incr_path_dist), :404-415 (dist) and, for runners that replay it, the sample trigger of

@@ -94,7 +94,16 @@ struct BevArgs {
 
 struct Window { int64_t lo, hi, sp, c_lo, c_hi; };
 
-__device__ __forceinline__ Window chunk_of(const BevArgs &a)
+// Workgroup b of level 1 takes chunk b.  (Other orders were measured, the result does not depend on it -- segments, counters
+// and offsets are indexed by the chunk: the chunks around the present frame first -- the ones with points inside the view,
+// the expensive ones -- and outwards from there: 62.9 us against 61.0; a golden-ratio permutation that mixes expensive and
+// cheap chunks: 67.3 us.  Neighbouring chunks running at the same time is worth more than an even tail.)
+__device__ __forceinline__ int chunk_index(const BevArgs &a, int64_t lo, int64_t sp, int64_t chunk)
+{
+    (void)a; (void)lo; (void)sp; (void)chunk;
+    return (int)blockIdx.x;
+}
+__device__ __forceinline__ Window chunk_of(const BevArgs &a, int &g)
 {
     Window w;
     w.lo = a.frame_off[a.slot_begin];
@@ -102,7 +111,8 @@ __device__ __forceinline__ Window chunk_of(const BevArgs &a)
     w.sp = a.frame_off[a.slot_split];
     w.hi = (hi0 - w.lo > a.max_points) ? w.lo + a.max_points : hi0;
     const int64_t chunk = (w.hi - w.lo + a.G - 1) / a.G;
-    w.c_lo = w.lo + (int64_t)blockIdx.x * chunk;
+    g = chunk_index(a, w.lo, w.sp, chunk);
+    w.c_lo = w.lo + (int64_t)g * chunk;
     w.c_hi = w.c_lo + chunk < w.hi ? w.c_lo + chunk : w.hi;
     if (w.c_lo > w.hi) w.c_lo = w.c_hi = w.hi;
     return w;
@@ -270,7 +280,8 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     __shared__ uint32_t s_wsum[AB_THREADS / 64];
     uint32_t *s_h = s_lds, *s_cur = s_lds + a.T;
     BIN_STAMP(0);
-    const Window w = chunk_of(a);
+    int g;                                                  // this workgroup's chunk
+    const Window w = chunk_of(a, g);
     const int64_t chunk = seg_stride(w.hi - w.lo, a.G);
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0 && a.frame_off[a.slot_end] - w.lo > a.max_points) atomicOr(a.status, PCA_STATUS_STORE_OVERFLOW);
@@ -425,15 +436,15 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
             const uint32_t c = s_h[t];
             s_cur[t] = run;
             // tile-major tables [tile][workgroup]: a tile's workgroup of level 2 reads its G counters as one range
-            a.bh[(int64_t)t * a.G + blockIdx.x] = c;
-            a.boff[(int64_t)t * a.G + blockIdx.x] = run;
+            a.bh[(int64_t)t * a.G + g] = c;
+            a.boff[(int64_t)t * a.G + g] = run;
             run += c;
         }
     }
     __syncthreads();
     BIN_STAMP(3);
     // ---- pass B: the chunk's records into its segment, tile by tile ----
-    const uint32_t seg = (uint32_t)((int64_t)blockIdx.x * chunk);
+    const uint32_t seg = (uint32_t)((int64_t)g * chunk);
     if (REG_P > 0 && n_reg > 0) {
         // colour and intensity of the kept points: all of a lane's gathers issued back to back, before the first is used
         // (a point outside the view re-reads the chunk's first point: no branch around a load).  Issuing them before the
@@ -494,20 +505,23 @@ struct RecMap {
 };
 // builds the map of `tile` (all `nthreads` threads of the workgroup, G <= 1024); returns the tile's record count.
 // Ends with a barrier.
-__device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, int tile, int nthreads)
+__device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, int tile, int nthreads, uint16_t *owner = nullptr)
 {
-    const int64_t lo = a.frame_off[a.slot_begin], hi0 = a.frame_off[a.slot_end];
-    const int64_t n = hi0 - lo > a.max_points ? a.max_points : hi0 - lo;
-    const uint32_t chunk = (uint32_t)seg_stride(n, a.G);
     const int per = (a.G + nthreads - 1) / nthreads;
     const int g0 = threadIdx.x * per;
     const uint32_t *cnt = a.bh + (int64_t)tile * a.G, *off = a.boff + (int64_t)tile * a.G;
-    uint32_t c[4] = {0, 0, 0, 0}, sum = 0;                  // per <= 4: G <= 1024, nthreads >= 256
+    uint32_t c[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0}, sum = 0;  // per <= 4: G <= 1024, nthreads >= 256
+    // (the counters' loads are issued before the window's size is waited for: two memory round trips side by side)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < per && g0 + k < a.G) { c[k] = cnt[g0 + k]; o[k] = off[g0 + k]; }
+    const int64_t lo = a.frame_off[a.slot_begin], hi0 = a.frame_off[a.slot_end];
+    const int64_t n = hi0 - lo > a.max_points ? a.max_points : hi0 - lo;
+    const uint32_t chunk = (uint32_t)seg_stride(n, a.G);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (k < per && g0 + k < a.G) {
-            c[k] = cnt[g0 + k];
-            M.base[g0 + k] = (uint32_t)(g0 + k) * chunk + off[g0 + k];
+            M.base[g0 + k] = (uint32_t)(g0 + k) * chunk + o[k];
             sum += c[k];
         }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -518,7 +532,15 @@ __device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, in
     for (int k = 0; k < wave; ++k) run += M.wsum[k];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (k < per && g0 + k < a.G) { M.pre[g0 + k] = run; run += c[k]; }
+        if (k < per && g0 + k < a.G) {
+            M.pre[g0 + k] = run;
+            // the light tile kernel's lookup table: owner[i] = the piece record i lies in (a piece holds ~3 records of a
+            // tile), so that a record costs three LDS reads instead of the ten-step search (50 of the ~200 vector
+            // instructions a record cost).  Only for tiles that fit the table (RGB_CAP records): the caller checks.
+            if (owner && run + c[k] <= RGB_CAP)
+                for (uint32_t j = 0; j < c[k]; ++j) owner[run + j] = (uint16_t)(g0 + k);
+            run += c[k];
+        }
     if ((int)threadIdx.x == nthreads - 1) M.pre[a.G] = run;
     __syncthreads();
     return M.pre[a.G];
@@ -537,22 +559,7 @@ __device__ __forceinline__ uint32_t recmap_at(const RecMap &M, int G, uint32_t i
     }
     return M.base[lo] + (i - M.pre[lo]);
 }
-// The light tile kernel's lookup: owner[i] = the piece record i lies in, written once per tile by the threads that own the
-// pieces (a piece holds ~3 records of a tile), so that a record costs three LDS reads instead of the ten-step search
-// (50 of the ~200 vector instructions a record cost).  `owner` holds the tile's count of entries (<= RGB_CAP).  Ends with
-// a barrier.
-__device__ __forceinline__ void recmap_expand(const RecMap &M, uint16_t *owner, int G, int nthreads)
-{
-    const int per = (G + nthreads - 1) / nthreads;
-    const int g0 = threadIdx.x * per;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (k < per && g0 + k < G) {
-            const uint32_t lo = M.pre[g0 + k], hi = M.pre[g0 + k + 1];
-            for (uint32_t r = lo; r < hi; ++r) owner[r] = (uint16_t)(g0 + k);
-        }
-    __syncthreads();
-}
+// the light tile kernel's lookup (owner[] filled by recmap_build)
 __device__ __forceinline__ uint32_t recmap_at(const RecMap &M, const uint16_t *owner, uint32_t i)
 {
     const uint32_t g = owner[i];
@@ -1070,7 +1077,7 @@ __device__ __forceinline__ void bev_tile_cells_body(const BevArgs &a)
     RecMap &M = *reinterpret_cast<RecMap *>(s_buf);         // lives in the colour buffer until pass 2 fills that
     static_assert(sizeof(RecMap) <= sizeof(s_buf), "RecMap aliases the colour buffer");
     stats_init(L.S, C_THREADS);
-    const uint32_t r_lo = 0, r_hi = recmap_build(M, a, tile, C_THREADS);
+    const uint32_t r_lo = 0, r_hi = recmap_build(M, a, tile, C_THREADS, L.owner);
     if (r_hi > (uint32_t)a.heavy_min) {                     // bev_tile_cells_heavy's
         if (threadIdx.x == 0) heavy_push(a, tile, r_hi);
         cells_drain<I64>(a, L, s_buf, true);
@@ -1085,7 +1092,6 @@ __device__ __forceinline__ void bev_tile_cells_body(const BevArgs &a)
     constexpr int HALF = RPT / 2;                           // two rounds of loads: bounds the registers in flight
     const bool contig = (r_hi - r_lo) > CONTIG_MIN;
     uint32_t kr[RPT], cc[RPT];
-    recmap_expand(M, L.owner, a.G, C_THREADS);
     if (!contig) {
         // records a workgroup-width apart share a cell only by chance: every record is counted on its own
 #pragma unroll

@@ -45,9 +45,15 @@ class DeviceImage:
         return self.host if dtype is None else self.host.astype(dtype)
 
 
+_TORCH_DTYPES = {}
+
+
 def _torch_dtype(np_dtype):
-    import torch
-    return torch.from_numpy(np.empty(0, dtype=np_dtype)).dtype
+    t = _TORCH_DTYPES.get(np_dtype)
+    if t is None:
+        import torch
+        t = _TORCH_DTYPES[np_dtype] = torch.from_numpy(np.empty(0, dtype=np_dtype)).dtype
+    return t
 
 
 class PinnedUploader:
@@ -64,53 +70,38 @@ class PinnedUploader:
     def __call__(self, kind, a):
         return self.upload_many([(kind, a)])[0]
 
-    _pool = None
-
-    @classmethod
-    def _copy_pool(cls):
-        if cls._pool is None:
-            cls._pool = ThreadPoolExecutor(max_workers=int(os.environ.get('PCA_STAGING_THREADS', '3')),
-                                           thread_name_prefix='pca-staging')
-        return cls._pool
-
     def upload_many(self, items):
-        """items: [(kind, host array)].  The host-side copies into the pinned blocks run side by side on a small pool
-        (numpy releases the GIL for them; three arrays of one KITTI observation: 0.15 ms one after the other on the
-        consumer's thread), then the H2D copies are enqueued -- by THIS thread, the only one that talks to HIP -- with one
-        event for all of them.  Returns the device tensors in order."""
+        """items: [(kind, host array)].  ONE call into the library copies the arrays into their pinned blocks -- side by side
+        on its small pool of host threads (pca_host_stage_h2d; ctypes releases the GIL for it) -- and enqueues the H2D
+        copies on the current stream; one event marks the blocks as reusable.  (The same in Python -- three np.copyto and
+        three tensor.copy_ for one KITTI observation -- was 0.15 ms of the unchanged driver's 0.34 ms step; a Python thread
+        pool for the copies cost more in wake-ups than it saved.)  Returns the device tensors in order."""
+        import ctypes as C
         import torch
+        from . import _lib
         arrays = [np.ascontiguousarray(a) for _, a in items]
-        pins, slots = [], []
+        n = len(arrays)
+        pins, slots, out = [], [], []
         for (kind, _), a in zip(items, arrays):
             ring = self._slots.setdefault(kind, [0, [None] * self.DEPTH])
             i = ring[0] % self.DEPTH
             ring[0] += 1
             slot = ring[1][i]
-            tdtype = _torch_dtype(a.dtype)
-            if slot is None or slot[0].numel() < a.size or slot[0].dtype != tdtype:
-                slot = (torch.empty(max(a.size, 1), dtype=tdtype, pin_memory=True), None)
+            if slot is None or slot[0].numel() < a.nbytes:
+                slot = (torch.empty(max(a.nbytes, 1), dtype=torch.uint8, pin_memory=True), None)
             elif slot[1] is not None:
                 slot[1].synchronize()            # the copy out of this block, DEPTH uploads ago: long done
-            pins.append(slot[0][:a.size].view(*a.shape))
+            pins.append(slot[0])
             slots.append((ring, i, slot[0]))
-        # (a hand-off to a pool thread costs ~30-50 us of wake-up: it pays for 4 MB camera images, not for the 0.5-2 MB
-        # arrays of a KITTI observation -- measured: 0.39 -> 0.43 ms per step with those on the pool)
-        big = [k for k, a in enumerate(arrays) if a.nbytes >= (1 << 22)]
-        jobs = []
-        if len(big) > 1:                         # the largest stays on this thread, the others go to the pool
-            big.sort(key=lambda k: -arrays[k].nbytes)
-            pool = self._copy_pool()
-            jobs = [pool.submit(np.copyto, pins[k].numpy(), arrays[k]) for k in big[1:]]
-        mine = [k for k in range(len(arrays)) if k not in big[1:]] if jobs else range(len(arrays))
-        for k in mine:
-            np.copyto(pins[k].numpy(), arrays[k])
-        for j in jobs:
-            j.result()
-        out = []
-        for pin, a in zip(pins, arrays):
-            dev = torch.empty(a.shape, dtype=pin.dtype, device=self.device)
-            dev.copy_(pin, non_blocking=True)
-            out.append(dev)
+            out.append(torch.empty(a.shape, dtype=_torch_dtype(a.dtype), device=self.device))
+        vp = C.c_void_p * n
+        src = vp(*[a.ctypes.data for a in arrays])
+        pin = vp(*[p.data_ptr() for p in pins])
+        dev = vp(*[d.data_ptr() for d in out])
+        nbytes = (C.c_int64 * n)(*[a.nbytes for a in arrays])
+        rc = _lib.load().pca_host_stage_h2d(n, src, pin, dev, nbytes, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f'pca_host_stage_h2d failed ({rc})')
         ev = torch.cuda.Event()
         ev.record()
         for ring, i, block in slots:
@@ -135,14 +126,16 @@ def _upload_stack(self, kind, arrays):
         slot = (torch.empty(max(n, 1), dtype=tdtype, pin_memory=True), None)
     elif slot[1] is not None:
         slot[1].synchronize()
-    pin = slot[0][:n].view(k, *shape)
-    pool = self._copy_pool()
-    jobs = [pool.submit(np.copyto, pin[j].numpy(), arrays[j]) for j in range(1, k)]
-    np.copyto(pin[0].numpy(), arrays[0])
-    for j in jobs:
-        j.result()
+    import ctypes as C
+    from . import _lib
     dev = torch.empty((k, ) + tuple(shape), dtype=tdtype, device=self.device)
-    dev.copy_(pin, non_blocking=True)
+    each = arrays[0].nbytes
+    vp = C.c_void_p * k
+    rc = _lib.load().pca_host_stage_h2d(k, vp(*[a.ctypes.data for a in arrays]), vp(*[slot[0].data_ptr() + j * each for j in range(k)]),
+                                        vp(*[dev.data_ptr() + j * each for j in range(k)]), (C.c_int64 * k)(*([each] * k)),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f'pca_host_stage_h2d failed ({rc})')
     ev = torch.cuda.Event()
     ev.record()
     ring[1][i] = (slot[0], ev)
@@ -391,20 +384,22 @@ class NuScenesPrefetchingLoader:
         pc = np.ascontiguousarray(geom['pc'], dtype=np.float64)
         n, ncam = pc.shape[0], len(geom['cams_K'])
         pin_pc, dev_pc = self._buffers(slot, 'pc', pc.shape, torch.float64)
-        jobs = []
         images = obs['images']
         real = all(isinstance(im, np.ndarray) and im.ndim == 3 for im in imgs) and len({im.shape for im in imgs}) == 1
+        src, pin, dev, nbytes = [pc.ctypes.data], [pin_pc.data_ptr()], [dev_pc.data_ptr()], [pc.nbytes]
         if real:
             pin_im, dev_im = self._buffers(slot, 'img', (len(imgs), ) + imgs[0].shape, torch.uint8)
-            pool = PinnedUploader._copy_pool()
-            jobs = [pool.submit(np.copyto, pin_im[k].numpy(), imgs[k]) for k in range(1, len(imgs))]
-            np.copyto(pin_im[0].numpy(), imgs[0])
-        np.copyto(pin_pc.numpy(), pc)
-        for j in jobs:
-            j.result()
-        dev_pc.copy_(pin_pc, non_blocking=True)
+            imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in imgs]
+            each = imgs[0].nbytes
+            for k, im in enumerate(imgs):
+                src.append(im.ctypes.data); pin.append(pin_im.data_ptr() + k * each)
+                dev.append(dev_im.data_ptr() + k * each); nbytes.append(each)
+        import ctypes as C                                   # pinned copies on the library's staging threads, H2D enqueued
+        vp = C.c_void_p * len(src)
+        if lib.pca_host_stage_h2d(len(src), vp(*src), vp(*pin), vp(*dev), (C.c_int64 * len(src))(*nbytes),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0:
+            raise RuntimeError('pca_host_stage_h2d failed')
         if real:
-            dev_im.copy_(pin_im, non_blocking=True)
             images = DeviceImages(obs['images'], dev_im)
         ev = torch.cuda.Event()
         ev.record()

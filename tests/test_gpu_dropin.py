@@ -1192,3 +1192,50 @@ def test_nuscenes_prefetching_loader_equals_plain_loader_and_feeds_the_accumulat
     monkeypatch.setenv('PCA_PREFETCH_RING', '4')
     with pytest.raises(ValueError, match='reuses its device buffers'):
         run(True, True)
+
+
+def test_staged_upload_ragged_sizes_and_threads():
+    """pca_host_stage_h2d behind PinnedUploader: arrays of 0 bytes, 1 byte, a non-multiple of the 128 KB slice and several MB,
+    of different dtypes, arrive intact; the pinned blocks are reused over more calls than the ring is deep; several calling
+    threads take turns."""
+    import threading
+
+    import torch
+    from pca_amd.ingest import PinnedUploader
+    up = PinnedUploader(torch.device('cuda', 0))
+    rng = np.random.default_rng(5)
+    shapes = [((0, 4), np.float32), ((1, ), np.uint8), ((131073, ), np.uint8), ((376, 1408, 3), np.uint8), ((120000, 4), np.float32),
+              ((33, 7), np.float64), ((5, ), np.int64)]
+    for rep in range(7):
+        items = []
+        for k, (shape, dt) in enumerate(shapes):
+            a = (rng.random(shape) * 200).astype(dt)
+            items.append((f'k{k}', a if rep % 2 else np.asfortranarray(a) if a.ndim > 1 else a))
+        out = up.upload_many(items)
+        torch.cuda.synchronize()
+        for (_, a), d in zip(items, out):
+            assert tuple(d.shape) == a.shape and np.array_equal(d.cpu().numpy(), a)
+    stack = [rng.integers(0, 255, (90, 160, 3), dtype=np.uint8) for _ in range(6)]
+    assert np.array_equal(up.upload_stack('imgs', stack).cpu().numpy(), np.stack(stack))
+
+    errors = []
+
+    def worker(seed):
+        try:
+            mine = PinnedUploader(torch.device('cuda', 0))
+            r = np.random.default_rng(seed)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(20):
+                    a = r.random((50000 + seed, 3)).astype(np.float32)
+                    d = mine('pts', a)
+                    torch.cuda.current_stream().synchronize()
+                    if not np.array_equal(d.cpu().numpy(), a):
+                        errors.append(seed)
+        except Exception as e:                           # noqa: BLE001
+            errors.append(repr(e))
+    threads = [threading.Thread(target=worker, args=(s, )) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
