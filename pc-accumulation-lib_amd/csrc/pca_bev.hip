@@ -182,14 +182,16 @@ __device__ __forceinline__ uint32_t view_key(const BevArgs &a, const Window &w, 
     return key;
 }
 // One point of pass A (memory path): owed re-transform (returns the stored coordinates), BEV-frame key.
-__device__ __forceinline__ BinPoint bin_point(const BevArgs &a, const Window &w, const PendHi &pend_hi, int64_t p, double X, double Y,
-                                              double Z, uint8_t D)
+struct ViewConst;
+__device__ __forceinline__ uint32_t view_key_lean(const ViewConst &c, double X, double Y, double Z, bool live, uint32_t set);
+__device__ __forceinline__ BinPoint bin_point(const BevArgs &a, const ViewConst &vc, const Window &w, const PendHi &pend_hi, int64_t p,
+                                              double X, double Y, double Z, uint8_t D)
 {
     BinPoint r;
     const bool moved = apply_owed(a, pend_hi, p, X, Y, Z);
     if (moved && a.write_back) { a.st.x[p] = X; a.st.y[p] = Y; a.st.z[p] = Z; }
     r.x = X; r.y = Y; r.z = Z;
-    r.key = view_key(a, w, p, X, Y, Z, D);
+    r.key = view_key_lean(vc, X, Y, Z, D != 1, p >= w.sp ? 1u : 0u);
     return r;
 }
 // packs and stores one kept record (pass B)
@@ -394,6 +396,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     BIN_STAMP(1);
     // ---- pass A, memory part (what the chunk holds beyond the registers) ----
     constexpr int MUNR = BIN_UNR;
+    const ViewConst vcm = view_const(a);
     for (int64_t base = reg_hi + threadIdx.x; base < w.c_hi; base += MUNR * AB_THREADS) {
         double X[MUNR], Y[MUNR], Z[MUNR];
         uint8_t D[MUNR];
@@ -410,7 +413,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
         for (int u = 0; u < MUNR; ++u) {
             const int64_t p = base + u * AB_THREADS;
             if (p >= w.c_hi) continue;
-            const BinPoint b = bin_point(a, w, pend_hi, p, X[u], Y[u], Z[u], D[u]);
+            const BinPoint b = bin_point(a, vcm, w, pend_hi, p, X[u], Y[u], Z[u], D[u]);
             if (b.key != KEY_INVALID) atomicAdd(&s_h[b.key >> 7], 1u);
             a.key[p - w.lo] = b.key;
         }
@@ -558,6 +561,30 @@ __device__ __forceinline__ uint32_t recmap_at(const RecMap &M, int G, uint32_t i
         lo = pm <= i ? m : lo;
     }
     return M.base[lo] + (i - M.pre[lo]);
+}
+// A thread that reads CONSECUTIVE records of a tile (the heavy kernel: a contiguous chunk per thread) searches once and
+// walks from there: a piece of a dense tile holds tens of records, so the ten-step search per record (50 vector
+// instructions, a quarter of the kernel's) becomes an increment and a compare.
+struct RecWalk { uint32_t i, end, at; };                   // record i lies at `at`; its piece ends before record `end`
+__device__ __forceinline__ void recwalk_seek(RecWalk &w, const RecMap &M, int G, uint32_t i)
+{
+    int lo = 0;
+#pragma unroll
+    for (int step = 512; step >= 1; step >>= 1) {
+        const int m = lo + step;
+        const uint32_t pm = M.pre[m < G ? m : G];
+        lo = pm <= i ? m : lo;
+    }
+    w.i = i; w.end = M.pre[lo + 1]; w.at = M.base[lo] + (i - M.pre[lo]);
+}
+// place of the current record; moves on to the next one (a new search at the end of a piece: it skips the empty pieces --
+// a dense tile of a real accumulation is fed by a few dozen of the 512).  Not to be called past the tile's last record.
+__device__ __forceinline__ uint32_t recwalk_next(RecWalk &w, const RecMap &M, int G, uint32_t n_records)
+{
+    const uint32_t at = w.at;
+    ++w.i; ++w.at;
+    if (w.i == w.end && w.i < n_records) recwalk_seek(w, M, G, w.i);
+    return at;
 }
 // the light tile kernel's lookup (owner[] filled by recmap_build)
 __device__ __forceinline__ uint32_t recmap_at(const RecMap &M, const uint16_t *owner, uint32_t i)
@@ -1301,20 +1328,21 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
     {
         for (int k = threadIdx.x; k < H_HIST_DWORDS / 4; k += H_THREADS) reinterpret_cast<uint4 *>(hist)[k] = make_uint4(0, 0, 0, 0);
         __syncthreads();
-        // every thread walks a contiguous chunk of the tile's records (runs form: see Run)
+        // Every thread takes UNR consecutive records at a time, the wave 64 * UNR consecutive ones: a wave's loads cover whole
+        // cache lines (one contiguous chunk per THREAD made every load instruction touch 64 lines of which the L1 kept none
+        // until the thread's next visit); runs of up to UNR records still form (see Run).
         constexpr int UNR = 4;
-        const uint32_t per_thread = (r_hi - r_lo + H_THREADS - 1) / H_THREADS;
-        const uint32_t t_lo = r_lo + threadIdx.x * per_thread;
-        const uint32_t t_hi = t_lo + per_thread < r_hi ? t_lo + per_thread : r_hi;
         Run run;
         run_reset(run, RUN_NONE);
-        for (uint32_t r0 = t_lo; r0 < t_hi; r0 += UNR) {
+        for (uint32_t r0 = r_lo + threadIdx.x * UNR; r0 < r_hi; r0 += H_THREADS * UNR) {
             uint32_t k[UNR], c[UNR];
             double z[UNR], iv[UNR];
+            RecWalk walk;
+            recwalk_seek(walk, L.M, a.G, r0);
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
-                if (r0 + u < t_hi) load_rec<I64>(a, recmap_at(L.M, a.G, r0 + u), k[u], c[u], z[u], iv[u]);
+                if (r0 + u < r_hi) load_rec<I64>(a, recwalk_next(walk, L.M, a.G, r_hi), k[u], c[u], z[u], iv[u]);
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
