@@ -460,6 +460,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
             rrgb[j] = cb[ic];
             rinten[j] = ib[ic];
         }
+        // (all cursor atomics first, then all stores: no gain, 62.2 against 61.5 us)
 #pragma unroll
         for (int j = 0; j < REG_P; ++j) {
             if (rkey[j] == KEY_INVALID) continue;
