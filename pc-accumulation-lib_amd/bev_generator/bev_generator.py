@@ -209,7 +209,8 @@ class BEVGenerator(ABC):
         rot_mat = hl.rotation_matrix_3d(rot_ang)
 
         def to_grid(traj_list):
-            return [hl.transform_traj(t, rot_mat, trans_dx, trans_dy, aug_view_size, self.pixel_size)
+            # (the lists are this call's own copies: nobody reads the in-place rotation the reference leaves behind)
+            return [hl.transform_traj(t, rot_mat, trans_dx, trans_dy, aug_view_size, self.pixel_size, mutate=False)
                     for t in traj_list]
 
         split = trajs.get('_ego_split')          # set by the accumulators: the ego polylines are slices of one array

@@ -120,10 +120,25 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
         else:
             imgs = self._uploader.upload_stack('imgs', [np.asarray(rgb, dtype=np.uint8) for rgb in rgbs])
         if isinstance(dev_sems[0], torch.Tensor):
-            sems = torch.stack([s.to(device=dev, dtype=torch.uint8) for s in dev_sems]).contiguous()
+            sems = self._as_one_stack(dev_sems)              # a model that ran the six cameras as one batch: no copy
+            if sems is None or sems.device != dev or sems.dtype != torch.uint8:
+                sems = torch.stack([s.to(device=dev, dtype=torch.uint8) for s in dev_sems]).contiguous()
         else:
             sems = self._uploader.upload_stack('sems', [np.asarray(m, dtype=np.uint8) for m in semsegs])
         return (up('pc', pc, np.float64, torch.float64), up('cam', pc_cam_idx, np.int64, torch.int64), imgs, sems, semsegs)
+
+    @staticmethod
+    def _as_one_stack(maps):
+        """The tensor [k, H, W] the k maps are consecutive slices of, if there is one (else None)."""
+        base = maps[0]._base
+        if base is None or base.dim() != maps[0].dim() + 1 or base.shape[0] != len(maps) or not base.is_contiguous():
+            return None
+        step = maps[0].numel() * maps[0].element_size()
+        p0 = base.data_ptr()
+        for j, m in enumerate(maps):
+            if m._base is not base or tuple(m.shape) != tuple(base.shape[1:]) or not m.is_contiguous() or m.data_ptr() != p0 + j * step:
+                return None
+        return base
 
     def _append_frame(self, rgbs, pc, pc_cam_idx, T_ego_global, ego_pose_z):
         T_ego_world, pose = self._ego_world(T_ego_global, ego_pose_z)

@@ -520,9 +520,23 @@ def transform_ego_split(full, split, rot_mat, dx, dy, view, px):
     return present, future, rows
 
 
-def transform_traj(traj, rot_mat, dx, dy, view, px):
+def transform_traj(traj, rot_mat, dx, dy, view, px, mutate=True):
     """rotate -> translate -> clip -> grid coordinates, for one (k,3) trajectory.  Mutates `traj` like the
-    reference (bev_generator.py:226-231)."""
+    reference (bev_generator.py:226-231) unless the caller does not need that (mutate=False: the same arithmetic in one C
+    call, pca_host_ego_to_grid, as transform_ego_split uses it -- a NuScenes sample has three polylines per agent)."""
+    if not mutate:
+        lib = _c_library()
+        if lib is not None and isinstance(traj, np.ndarray) and traj.ndim == 2 and traj.shape[1] == 3:
+            t = np.ascontiguousarray(traj, dtype=np.float64)
+            n = t.shape[0]
+            if n < 2:
+                return np.zeros((0, 3))
+            R = np.ascontiguousarray(rot_mat, dtype=np.float64)
+            rows = np.empty((2 * (n - 1), 3))
+            start = np.empty(n, dtype=np.int32)
+            m = lib.pca_host_ego_to_grid(t.ctypes.data, n, R.ctypes.data, float(dx), float(dy), float(view), int(px),
+                                         rows.ctypes.data, start.ctypes.data)
+            return rows[:m]
     traj[:, :3] = np.matmul(rot_mat, traj[:, :3].T).T
     traj[:, 0] += dx
     traj[:, 1] += dy

@@ -184,6 +184,22 @@ def test_ego_split_transform_equals_three_separate_transforms():
             assert got.shape == w.shape and np.array_equal(got, w), (trial, n, split)
 
 
+def test_transform_traj_c_call_equals_numpy_form():
+    """transform_traj(mutate=False) -- the one C call generate() uses for the other agents' polylines -- returns what the
+    reference's in-place numpy form returns, on random polylines incl. ones that leave and re-enter the view."""
+    rng = np.random.default_rng(21)
+    for trial in range(300):
+        n = int(rng.integers(0, 40))
+        pts = np.cumsum(rng.normal(0, 2.5, (n, 3)), axis=0) + rng.normal(0, 8, 3) if n else np.zeros((0, 3))
+        R = hl.rotation_matrix_3d(rng.uniform(0, 6.28))
+        dx, dy, view, px = rng.uniform(-2, 2), rng.uniform(-2, 2), float(rng.choice([10., 20., 51.2])), int(rng.choice([32, 256]))
+        keep = pts.copy()
+        got = hl.transform_traj(pts, R, dx, dy, view, px, mutate=False)
+        assert np.array_equal(pts, keep)                                   # left alone
+        want = hl.transform_traj(keep.copy(), R, dx, dy, view, px)
+        assert got.shape == want.shape and np.array_equal(got, want), (trial, n)
+
+
 def test_pts_feat_from_img_nearest_and_optin_bilinear(golden):
     """datasets/nuscenes_utils.py:181-214: 'nearest' is what every caller uses (and what K1n fuses); 'bilinear' is
     the reference's unused branch (2-D maps only), kept as an opt-in and pinned on its own output: here the oracle's
