@@ -13,5 +13,5 @@ pr.disable()
 builtins.print = rp
 print({k: v for k, v in r.items() if not isinstance(v, dict)})
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(70)
+pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(45)
 print(s.getvalue())
