@@ -32,6 +32,9 @@
 #ifndef BIN_RUNR
 #define BIN_RUNR 4                // ... of the register path
 #endif
+#ifndef BIN_WPE
+#define BIN_WPE 4                 // waves per SIMD level 1 is compiled for (4: 128 VGPRs, one 1024-thread workgroup per CU)
+#endif
 #ifndef BIN_UNR
 #define BIN_UNR 4
 #endif
@@ -1391,7 +1394,7 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
 // blockIdx.y = sample, its arguments read from a device array -- a NuScenes-size window is 108 level-1 workgroups and
 // three dependent launches of pure latency; S samples in one launch of each kernel take little longer than one) ----
 template <bool I64>
-__global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void bev_tile_bin(const BevArgs a) { bev_tile_bin_body<I64>(a); }
+__global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(BIN_WPE, BIN_WPE))) void bev_tile_bin(const BevArgs a) { bev_tile_bin_body<I64>(a); }
 #if C_THREADS == 512
 #define C_OCC __attribute__((amdgpu_waves_per_eu(6, 6)))
 #else
@@ -1407,7 +1410,7 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs 
 #define PCA_BEV_MANY_MAX 48
 __constant__ BevArgs g_bev_many[PCA_BEV_MANY_MAX];
 template <bool I64>
-__global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void bev_tile_bin_many()
+__global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(BIN_WPE, BIN_WPE))) void bev_tile_bin_many()
 {
     const BevArgs &a = g_bev_many[blockIdx.y];
     if ((int)blockIdx.x < a.G) bev_tile_bin_body<I64>(a);

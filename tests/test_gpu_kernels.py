@@ -1,6 +1,8 @@
 """GPU parity, kernel level: every HIP kernel (through the C ABI) against the CPU oracle on the same seeded
 inputs and against the committed golden vectors.  Integers / masks / coordinates: bit-exact.
 Floating-point planes: 1e-12 absolute against the oracle (contract: 1e-5 against the reference)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -946,3 +948,16 @@ def test_k1_one_pixel_image(T, orc):
         ost = orc.Store(n)
         orc.kitti_project_sample_filter(ost, pc, P, im, se, None, 1, 1, KITTI_FILTERS)
         assert ost.n > 10 and np.array_equal(rows, ost.rows())
+
+
+def test_light_tile_kernel_thread_contiguous_mode_in_a_subprocess():
+    """PCA_BEV_HEAVY_MIN is read once per process.  Raised to the LDS colour capacity (4096), tiles of 2561..4096 records
+    stay with the light tile kernel and take its thread-contiguous mode (per-thread runs); the skewed and the dense-tile
+    parity cases are repeated that way in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PCA_BEV_HEAVY_MIN='4096')
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_kernels.py'), '-x', '-q', '-m', 'gpu', '-k',
+                        'ring_like_skew or dense_tile_goes or randomised_configs'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

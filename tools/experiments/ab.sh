@@ -12,5 +12,5 @@ k = d['roofline']['kernels']
 print(sys.argv[1].split('/')[-1], 'value %.0f  ms/step %.4f' % (d['value'], d['ms_per_step']), {n: round(v['avg_us'], 1) for n, v in k.items()}, 'unit %.1f' % d['roofline']['avg_launch_us'])
 PY
 }
-for rep in 1 2 3; do for v in old new; do run tools/experiments/libpca_$v.bin; done; done
+for rep in 1 2; do for v in ${VARIANTS:-old new}; do run tools/experiments/libpca_$v.bin; done; done
 cp /tmp/std.so pc-accumulation-lib_amd/pca_amd/libpca_hip.so
