@@ -326,6 +326,15 @@ int pca_host_stage_h2d(int n, const void *const *src, void *const *pinned, void 
                        void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * A device result on its way to the host (the BEV planes of a sample: sem_bev.py hands them back as host float16
+ * arrays, bev_generator/sem_bev.py:164-205 of the reference) without the caller's stream waiting for the copy: it runs on
+ * a side stream of the context behind everything enqueued on `stream` so far.  `pinned`: page-locked, caller-owned, to be
+ * left alone until pca_host_d2h_wait(ticket) has returned.  Returns the ticket (0..63) or -1.
+ * ------------------------------------------------------------------------------------------------ */
+int pca_host_d2h_async(pca_ctx *ctx, const void *dev, void *pinned, int64_t bytes, void *stream);
+int pca_host_d2h_wait(pca_ctx *ctx, int ticket);
+
+/* ------------------------------------------------------------------------------------------------
  * Host helper (no device work): the accumulator's pose track -- the per-frame bookkeeping integrate() does on Python
  * lists in the reference.  Replaces sem_pc_accum.py:156-165 (update_poses), :185-209 (remove_observations), :211-228
  * (comp_incr_path_dist), :404-415 (dist) and, for runners that replay it, the sample trigger of

@@ -10,6 +10,28 @@ import numpy as np
 from .bev_generator import PLANES, SETS, BEVGenerator, WindowPart
 
 
+class _PendingCopy:
+    """A device -> host copy in flight (pca_host_d2h_async).  Holds the device tensor until the copy has been waited for, so
+    that its memory is not handed to another tensor while the side stream may still read it."""
+
+    __slots__ = ('ctx', 'ticket', 'keep')
+
+    def __init__(self, ctx, ticket, keep):
+        self.ctx, self.ticket, self.keep = ctx, ticket, keep
+
+    def synchronize(self):
+        if self.keep is not None:
+            self.ctx.check(self.ctx.lib.pca_host_d2h_wait(self.ctx.h, self.ticket))
+            self.keep = None
+
+    def __del__(self):                       # a sample nobody looked at: its blocks go back only after the copy has landed
+        try:
+            if self.keep is not None:
+                self.ctx.lib.pca_host_d2h_wait(self.ctx.h, self.ticket)
+        except Exception:                    # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 class LazyBev(dict):
     """The reference's BEV dict whose plane arrays are still on their way from the device: the fp16 D2H copy was
     enqueued on a side stream into pinned memory; the first access waits for THAT copy only and fills the dict in.
@@ -144,18 +166,19 @@ class SemBEVGenerator(BEVGenerator):
         out=planes[i])).  ONE device->host copy of all k samples is enqueued on a side stream into pinned memory; returns
         k LazyBev dicts at once (bev_num > 1: the k augmented rasters run back to back, no host round trip between)."""
         import torch
-        if getattr(self, '_d2h_stream', None) is None:
-            self._d2h_stream = torch.cuda.Stream(planes.device)
-        # a fresh pinned block per call: torch's caching host allocator hands back a block whose arrays have all died
-        # (and whose copies have completed), so in steady state this allocates nothing
+        from pca_amd import _lib
+        ctx = _lib.Context.get(planes.device)
+        # a fresh pinned block per call: torch's caching host allocator hands back a block whose arrays have all died, so in
+        # steady state this allocates nothing.  The copy itself is ONE library call (pca_host_d2h_async: a side stream of
+        # the context behind the current stream's work, a completion event named by a ticket) -- the same in torch (stream
+        # context, wait_stream, copy_, Event, record_stream) was 0.04 ms per sample.
         host = torch.empty(tuple(planes.shape), dtype=torch.float16, pin_memory=True)
-        side = self._d2h_stream
-        side.wait_stream(torch.cuda.current_stream(planes.device))
-        with torch.cuda.stream(side):
-            host.copy_(planes, non_blocking=True)
-            event = torch.cuda.Event()
-            event.record(side)
-        planes.record_stream(side)
+        ticket = ctx.lib.pca_host_d2h_async(ctx.h, planes.data_ptr(), host.data_ptr(), planes.numel() * planes.element_size(),
+                                            ctx.stream())
+        if ticket < 0:
+            ctx.check(ticket)
+        assert planes.is_contiguous()
+        event = _PendingCopy(ctx, ticket, (planes, host))
         return [LazyBev(host, i, event, (r['trajs_present'], r['trajs_future'], r['trajs_full']), r.get('gt_lanes'))
                 for i, r in enumerate(results)]
 

@@ -161,6 +161,9 @@ void pca_ctx_destroy(pca_ctx *ctx)
     if (ctx->k1_tiny) (void)hipFree(ctx->k1_tiny);
     if (ctx->bevm_pin) (void)hipHostFree(ctx->bevm_pin);
     if (ctx->bevm_ev) (void)hipEventDestroy(ctx->bevm_ev);
+    for (auto &e : ctx->d2h_done) if (e) (void)hipEventDestroy(e);
+    if (ctx->d2h_go) (void)hipEventDestroy(ctx->d2h_go);
+    if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
     if (ctx->k1n_ws) (void)hipFree(ctx->k1n_ws);
     if (ctx->k1n_desc_dev) (void)hipFree(ctx->k1n_desc_dev);
     if (ctx->k1n_pin) (void)hipHostFree(ctx->k1n_pin);

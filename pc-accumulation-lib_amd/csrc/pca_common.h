@@ -46,6 +46,12 @@ struct pca_ctx {
     int64_t bevm_cap = 0;
     hipEvent_t bevm_ev = nullptr;
     bool bevm_busy = false;
+    // pca_host_d2h_async: a side stream for results on their way to the host, the event that lets it start and a ring of
+    // completion events (a ticket = a place in the ring)
+    hipStream_t d2h_stream = nullptr;
+    hipEvent_t d2h_go = nullptr;
+    hipEvent_t d2h_done[64] = {};
+    uint32_t d2h_next = 0;
     void *k1_tiny = nullptr;          // dev: 4-byte copies of images smaller than the 4-byte colour gather
     int64_t k1_tiny_cap = 0;
     void *k1_ws[2] = {nullptr, nullptr};   // dev: counts / kept records of K1's split form, one per sub-batch in flight

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/pca.h"
+#include "pca_common.h"
 
 typedef void (*cblas_dgemv64_fn)(int order, int trans, int64_t m, int64_t n, double alpha, const double *A, int64_t lda,
                                  const double *x, int64_t incx, double beta, double *y, int64_t incy);
@@ -469,5 +470,38 @@ extern "C" int pca_host_stage_h2d(int n, const void *const *src, void *const *pi
     for (int k = 0; k < n; ++k)
         if (bytes[k] > 0 && hipMemcpyAsync(dev[k], pinned[k], (size_t)bytes[k], hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
             return -2;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A device result on its way to the host without the caller's stream waiting for it: the copy runs on a side stream of
+// the context, behind everything enqueued on `stream` so far; the ticket names the event that marks its end.
+// (In Python this was a stream context, wait_stream, copy_, an Event and record_stream per sample: 0.04 ms of the
+// unchanged driver's 0.24 ms step.)
+// ---------------------------------------------------------------------------------------------
+extern "C" int pca_host_d2h_async(pca_ctx *ctx, const void *dev, void *pinned, int64_t bytes, void *stream)
+{
+    if (!ctx) return -1;
+    if (!dev || !pinned || bytes < 0) { ctx->err = "d2h_async: bad arguments"; return -1; }
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d2h_stream) {
+        PCA_CHECK(ctx, hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+        PCA_CHECK(ctx, hipEventCreateWithFlags(&ctx->d2h_go, hipEventDisableTiming));
+    }
+    const uint32_t k = ctx->d2h_next++ & 63u;
+    if (!ctx->d2h_done[k]) PCA_CHECK(ctx, hipEventCreateWithFlags(&ctx->d2h_done[k], hipEventDisableTiming));
+    PCA_CHECK(ctx, hipEventRecord(ctx->d2h_go, (hipStream_t)stream));
+    PCA_CHECK(ctx, hipStreamWaitEvent(ctx->d2h_stream, ctx->d2h_go, 0));
+    if (bytes > 0) PCA_CHECK(ctx, hipMemcpyAsync(pinned, dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
+    PCA_CHECK(ctx, hipEventRecord(ctx->d2h_done[k], ctx->d2h_stream));
+    return (int)k;
+}
+
+// Waits for the copy of `ticket` (a ticket older than 64 copies waits for a later copy of the same stream: still after its own).
+extern "C" int pca_host_d2h_wait(pca_ctx *ctx, int ticket)
+{
+    if (!ctx) return -1;
+    if (ticket < 0 || ticket > 63 || !ctx->d2h_done[ticket]) { ctx->err = "d2h_wait: bad ticket"; return -1; }
+    PCA_CHECK(ctx, hipEventSynchronize(ctx->d2h_done[ticket]));
     return 0;
 }

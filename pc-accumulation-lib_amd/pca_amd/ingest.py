@@ -99,7 +99,10 @@ class PinnedUploader:
         pin = vp(*[p.data_ptr() for p in pins])
         dev = vp(*[d.data_ptr() for d in out])
         nbytes = (C.c_int64 * n)(*[a.nbytes for a in arrays])
-        rc = _lib.load().pca_host_stage_h2d(n, src, pin, dev, nbytes, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        dix = torch.device(self.device).index
+        raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)      # ~10x cheaper than current_stream()
+        stream = raw(dix if dix is not None else torch.cuda.current_device()) if raw is not None else torch.cuda.current_stream().cuda_stream
+        rc = _lib.load().pca_host_stage_h2d(n, src, pin, dev, nbytes, C.c_void_p(stream))
         if rc != 0:
             raise RuntimeError(f'pca_host_stage_h2d failed ({rc})')
         ev = torch.cuda.Event()
