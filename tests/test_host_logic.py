@@ -94,3 +94,40 @@ def test_c_pose_track_full_product_fallbacks_agree():
     finally:
         lib.pca_host_gemv4_mode(mode)
         lib.pca_host_incr_blocks(blocks)
+
+
+def test_staging_pool_copies_without_a_gpu():
+    """pca_host_stage_h2d's host side: the pool of threads copies ragged arrays (0 bytes .. several slices) into the staging
+    blocks, also with several threads calling at once; without a GPU the H2D enqueue that follows fails (-2), which is the
+    point where this test stops."""
+    import ctypes as C
+    import threading
+    from pca_amd import _lib
+    lib = _lib.load()
+    errors = []
+
+    def one(seed, reps):
+        r = np.random.default_rng(seed)
+        for _ in range(reps):
+            n = int(r.integers(1, 5))
+            srcs = [r.integers(0, 255, int(r.integers(0, 600000)), dtype=np.uint8) for _ in range(n)]
+            pins = [np.zeros(max(len(s), 1), dtype=np.uint8) for s in srcs]
+            vp = C.c_void_p * n
+            rc = lib.pca_host_stage_h2d(n, vp(*[s.ctypes.data for s in srcs]), vp(*[p.ctypes.data for p in pins]),
+                                        vp(*[p.ctypes.data for p in pins]), (C.c_int64 * n)(*[len(s) for s in srcs]), None)
+            if any(len(s) for s in srcs) and rc == 0:
+                import torch
+                if not torch.cuda.is_available():
+                    errors.append('H2D succeeded without a GPU')
+            for s, p in zip(srcs, pins):
+                if not np.array_equal(p[:len(s)], s):
+                    errors.append(('copy', seed))
+    one(1, 30)
+    threads = [threading.Thread(target=one, args=(k, 25)) for k in range(2, 6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    assert lib.pca_host_stage_h2d(0, None, None, None, None, None) == 0
+    assert lib.pca_host_stage_h2d(-1, None, None, None, None, None) == -1
