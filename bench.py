@@ -725,7 +725,8 @@ def config5_pass(rank, world, scale, barrier, allmax, coll_dev, dist):
     # content check: the last chunk of every rank -> rank 0, checksums compared.  A failure of the check's own collectives
     # is reported in the block, it does not take the measurement above down with it.
     mine = ring.view(torch.int16).to(torch.int64).sum().reshape(1)
-    if world > 1:
+    use_dist = world > 1 or dist.is_initialized()
+    if use_dist:
         ok = None
         try:
             sums = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
@@ -738,13 +739,14 @@ def config5_pass(rank, world, scale, barrier, allmax, coll_dev, dist):
                 ok = all(int(g.view(torch.int16).to(torch.int64).sum().item()) == int(s.item()) for g, s in zip(got, sums))
                 mb = (world - 1) * GATHER_CHUNK * 21 * PX * PX * 2 / 1e6
                 out['gather_check'] = {'samples_per_rank': GATHER_CHUNK, 'MB_into_rank0': mb, 'ms': 1e3 * tg,
-                                       'GBps': mb / 1e3 / tg, 'checksums_match': bool(ok)}
+                                       'GBps': mb / 1e3 / tg, 'checksums_match': bool(ok), 'backend': dist.get_backend(),
+                                       'on_device_tensors': coll_dev == 'cuda'}
         except RuntimeError as e:                                   # torch.distributed / RCCL errors
             out['gather_check'] = {'error': repr(e)[:300]}
         assert ok is not False, 'gathered BEV tensors differ from what the ranks produced'
     out['frames_this_rank_incl_warmup'] = my_frames
     # per-rank wall times of the compute (before the closing barrier): the plan's imbalance as it was measured
-    if world > 1:
+    if use_dist:
         try:
             ts = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
             dist.all_gather(ts, torch.tensor([mine_s], dtype=torch.float64, device=coll_dev))
@@ -753,6 +755,17 @@ def config5_pass(rank, world, scale, barrier, allmax, coll_dev, dist):
             out['seconds_per_rank'] = {'error': repr(e)[:200]}
     else:
         out['seconds_per_rank'] = [mine_s]
+    return out
+
+
+def config5_headline(c5):
+    """What a reader of SCALE_rNN.json wants from the strong-scaling block without opening it: how well the plan COULD
+    scale, and how uneven the ranks' own wall times were."""
+    out = {'config5_ideal_speedup_of_this_plan': c5.get('ideal_speedup_of_this_plan')}
+    spr = c5.get('seconds_per_rank')
+    if isinstance(spr, list) and spr:
+        out['config5_seconds_per_rank_min'] = float(min(spr))
+        out['config5_seconds_per_rank_max'] = float(max(spr))
     return out
 
 
@@ -907,8 +920,13 @@ def main():
     backend = os.environ.get('PCA_BENCH_BACKEND', 'nccl')
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    # under a launcher (RANK set) the process group is initialised even for ONE rank: `torchrun --nproc-per-node 1 bench.py`
+    # takes RCCL, the gathers of device tensors and the checksum check through the real transport on a one-GPU box (the
+    # driver's own N = 1 run starts bench.py without a launcher: no process group, nothing changes there)
+    use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('PCA_BENCH_DIST_AT_1', '1') != '0')
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':
             try:
                 dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))   # RCCL on ROCm
@@ -924,12 +942,12 @@ def main():
     coll_dev = 'cuda' if backend == 'nccl' else 'cpu'
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def allmax(x):
-        if world == 1:
+        if not use_dist:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -950,8 +968,9 @@ def main():
                    'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                    'config': {'workload': c5['workload'], 'points_per_frame': N_PTS, 'image': [IMG_H, IMG_W], 'bev_px': PX},
                    'config5': c5, 'roofline': None, 'cpu_baseline': None}
+            out.update(config5_headline(c5))
             print(json.dumps(out))
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -978,7 +997,7 @@ def main():
 
     def chunk_of(lo, hi):
         return bev_buf[lo:hi] if backend == 'nccl' else bev_buf[lo:hi].cpu()
-    gathered = [recv_bufs(lo, hi) for lo, hi in chunks] if (world > 1 and args.gather) else None
+    gathered = [recv_bufs(lo, hi) for lo, hi in chunks] if (use_dist and args.gather) else None
 
     # ---- timed region: exactly K steps (barrier + synchronize on both sides, max over ranks).  The region is REPEATED:
     #      at least REPEATS times and until MIN_TIMED_S seconds have been timed in all, whatever --steps says (a 20-step
@@ -1006,7 +1025,7 @@ def main():
     first_repeat_s, times = times[0], times[1:]
     elapsed = float(np.median(times))
     gather_check = None
-    if world > 1:
+    if use_dist:
         # the last chunk of every rank -> rank 0 (untimed unless --gather already did it): checksums + link rate.  A failure
         # of the check's own collectives is reported in the block, it does not take the measurement above down with it.
         ok = None
@@ -1025,7 +1044,7 @@ def main():
                 ok = all(int(g.view(torch.int16).to(torch.int64).sum().item()) == int(s.item()) for g, s in zip(last, sums))
                 mb = (world - 1) * (hi - lo) * 21 * PX * PX * 2 / 1e6
                 gather_check = {'in_timed_region': gathered is not None, 'samples_per_rank': hi - lo, 'MB_into_rank0': mb,
-                                'ms': 1e3 * tg, 'GBps': mb / 1e3 / tg, 'checksums_match': bool(ok)}
+                                'ms': 1e3 * tg, 'GBps': mb / 1e3 / tg, 'checksums_match': bool(ok), 'backend': backend}
         except RuntimeError as e:                                   # torch.distributed / RCCL errors
             gather_check = {'error': repr(e)[:300]}
         assert ok is not False, 'gathered BEV tensors differ from what the ranks produced'
@@ -1064,7 +1083,7 @@ def main():
         c5 = config5_pass(rank, world, args.config5_scale, barrier, allmax, coll_dev, dist)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -1170,13 +1189,14 @@ def main():
     }
     if c5 is not None:
         out['config5'] = c5
+        out.update(config5_headline(c5))
     if gather_check is not None:
         out['gather_check'] = gather_check
     out.update(side)
     if not args.no_cpu_baseline and world == 1:           # reported at N = 1 only
         out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -59,6 +59,14 @@ void pca_ctx_destroy(pca_ctx *ctx);
 const char *pca_last_error(pca_ctx *ctx);
 /* Synchronises `stream`, returns the OR of PCA_STATUS_* bits raised since the last call and clears them. */
 int pca_status(pca_ctx *ctx, void *stream, uint32_t *status_out);
+/* The same bits as the host can see them now, WITHOUT touching the stream (every raise also stores into a mapped host
+ * word): a kernel's raise shows here at the latest once that kernel has finished.  Does not clear; pca_status does.
+ * The drop-in classes peek on every integrate() / generate_bev() and where they wait for a result anyway, so that a
+ * dropped point or an invalid compaction surfaces as the exception the reference would have raised synchronously
+ * (IndexError of bev_generator/sem_bev.py:543-551, AssertionError of datasets/nuscenes_utils.py:191-195). */
+int pca_status_peek(pca_ctx *ctx, uint32_t *status_out);
+/* the mirror itself: host address of 8 words, word b != 0 <=> bit b raised (for bindings that want a zero-cost read) */
+const uint32_t *pca_status_mirror(pca_ctx *ctx);
 
 /* ------------------------------------------------------------------------------------------------
  * K1  KITTI-360 fused  project -> frustum mask -> nearest sample (rgb + semseg) -> class filter ->

@@ -23,6 +23,10 @@ class _PendingCopy:
         if self.keep is not None:
             self.ctx.check(self.ctx.lib.pca_host_d2h_wait(self.ctx.h, self.ticket))
             self.keep = None
+            # every kernel behind this copy has finished: what they raised is visible in the status mirror.  A sample made
+            # from dropped points or an invalid compaction must not reach its consumer silently (the reference fails
+            # synchronously: sem_bev.py:543-551, nuscenes_utils.py:191-195)
+            self.ctx.poll_status()
 
     def __del__(self):                       # a sample nobody looked at: its blocks go back only after the copy has landed
         try:

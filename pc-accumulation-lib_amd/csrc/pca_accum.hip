@@ -179,7 +179,7 @@ __global__ __launch_bounds__(K1N_BLK) void k1n_nusc(const K1nArgs a)
         keep[k] = valid[k] && !in_mask(a.filt, cls[k]);
         packed[k] |= cls[k] << 24;
     }
-    if (bad_uv) atomicOr(a.ticket + 1, PCA_STATUS_UV_OUT_OF_IMAGE);
+    if (bad_uv) pca_raise(a.ticket + 1, PCA_STATUS_UV_OUT_OF_IMAGE);
 
     const TileScanT<K1N_PPT> sc = tile_compact<K1N_BLK, K1N_PPT>(keep, a.state, tile, a.epoch, a.ticket + 1);
     const int64_t tile_base = a.frame_off[a.slot] + (int64_t)sc.excl;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(K1N_BLK) void k1n_nusc(const K1nArgs a)
         a.st.inst[o] = (int32_t)row[k][6];
         a.st.dyn[o] = 0;
     }
-    if (overflow) atomicOr(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
+    if (overflow) pca_raise(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
     if (threadIdx.x == 0 && tile == a.total_tiles - 1) a.frame_off[a.slot + 1] = tile_base + sc.total;
 }
 
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(K1N_BLK) void k1n_front_batch(const K1nBatchArgs a)
     }
 #pragma unroll
     for (int k = 0; k < K1N_PPT; ++k) packed[k] |= cls[k] << 24;
-    if (bad_uv) atomicOr(a.status, PCA_STATUS_UV_OUT_OF_IMAGE);
+    if (bad_uv) pca_raise(a.status, PCA_STATUS_UV_OUT_OF_IMAGE);
     // stable ranks inside the tile (point order = k-major, then thread)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t local[K1N_PPT];
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void k1n_append_batch(const K1nBatchArgs a)
         a.st.inst[o] = ldg(a.sn + sbase + j);
         a.st.dyn[o] = 0;
     }
-    if (overflow) atomicOr(a.status, PCA_STATUS_STORE_OVERFLOW);
+    if (overflow) pca_raise(a.status, PCA_STATUS_STORE_OVERFLOW);
 }
 
 // pts_feat_from_img(pts_uv, img, 'bilinear') of the reference (datasets/nuscenes_utils.py:181-210) for a 2-D map:
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(SBLK) void sample_bilinear(const BilinArgs a)
     const int p = blockIdx.x * SBLK + threadIdx.x;
     if (p >= a.n) return;
     const double u = a.uv[2 * p], v = a.uv[2 * p + 1];
-    if (!(u > 1.0 && u < (double)a.W - 1.0 && v > 1.0 && v < (double)a.H - 1.0)) { atomicOr(a.status, PCA_STATUS_UV_OUT_OF_IMAGE); a.out[p] = 0.0; return; }
+    if (!(u > 1.0 && u < (double)a.W - 1.0 && v > 1.0 && v < (double)a.H - 1.0)) { pca_raise(a.status, PCA_STATUS_UV_OUT_OF_IMAGE); a.out[p] = 0.0; return; }
     const Bilin b = bilin_weights<true>(u, v);
     const int u0 = (int)b.u0, u1 = (int)b.u1, v0 = (int)b.v0, v1 = (int)b.v1;
     a.out[p] = bilin_value(b, a.map[(int64_t)v0 * a.W + u0], a.map[(int64_t)v1 * a.W + u1], a.map[(int64_t)v1 * a.W + u0],
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(SBLK) void dedup_insert(const DedupArgs a)
     int64_t lo, hi;
     dedup_window(a, lo, hi);
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.frame_off[a.slot_end] - lo > a.max_points)
-        atomicOr(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
+        pca_raise(a.ticket + 1, PCA_STATUS_STORE_OVERFLOW);
     for (int64_t p = lo + (int64_t)blockIdx.x * SBLK + threadIdx.x; p < hi; p += (int64_t)gridDim.x * SBLK) {
         const unsigned long long key = voxel_key(a.st.x[p], a.st.y[p], a.st.z[p], a.size);
         uint64_t h = voxel_hash(key) & a.cap_mask;

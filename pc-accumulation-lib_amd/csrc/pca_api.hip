@@ -128,9 +128,10 @@ int pca_ctx_create(int device, pca_ctx **out)
     *out = nullptr;
     pca_ctx *ctx = new pca_ctx();
     ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->ticket, 2 * sizeof(uint32_t)) != hipSuccess ||
-        hipMemset(ctx->ticket, 0, 2 * sizeof(uint32_t)) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->ticket, 4 * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(ctx->ticket, 0, 4 * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc(&ctx->status_host, sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc(&ctx->status_mirror, PCA_STATUS_BITS * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
         hipHostMalloc(&ctx->heavy_hint, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) {
         delete ctx;
         return -1;
@@ -138,7 +139,10 @@ int pca_ctx_create(int device, pca_ctx **out)
     int n_cu = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) ctx->n_cu = n_cu;
     *ctx->heavy_hint = 1;            // first call: assume heavy tiles exist
-    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->heavy_hint_dev), ctx->heavy_hint, 0) != hipSuccess) {
+    for (int b = 0; b < PCA_STATUS_BITS; ++b) ctx->status_mirror[b] = 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->heavy_hint_dev), ctx->heavy_hint, 0) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->status_mirror_dev), ctx->status_mirror, 0) != hipSuccess ||
+        hipMemcpy(ctx->ticket + 2, &ctx->status_mirror_dev, sizeof(void *), hipMemcpyHostToDevice) != hipSuccess) {
         delete ctx;
         return -1;
     }
@@ -169,6 +173,7 @@ void pca_ctx_destroy(pca_ctx *ctx)
     if (ctx->k1n_pin) (void)hipHostFree(ctx->k1n_pin);
     if (ctx->k1n_ev) (void)hipEventDestroy(ctx->k1n_ev);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
+    if (ctx->status_mirror) (void)hipHostFree(ctx->status_mirror);
     if (ctx->heavy_hint) (void)hipHostFree(ctx->heavy_hint);
     prof_fold(ctx);
     for (auto &e : ctx->free_evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -186,7 +191,26 @@ int pca_status(pca_ctx *ctx, void *stream, uint32_t *status_out)
     PCA_CHECK(ctx, hipMemsetAsync(ctx->ticket + 1, 0, sizeof(uint32_t), s));
     PCA_CHECK(ctx, hipStreamSynchronize(s));
     *status_out = *ctx->status_host;
+    for (int b = 0; b < PCA_STATUS_BITS; ++b) {             // the mirror may have run ahead of a status word cleared earlier
+        if (__atomic_load_n(&ctx->status_mirror[b], __ATOMIC_RELAXED)) *status_out |= 1u << b;
+        __atomic_store_n(&ctx->status_mirror[b], 0u, __ATOMIC_RELAXED);
+    }
     return 0;
 }
+
+// The bits raised so far as the host sees them NOW: no stream operation, no wait.  A kernel's raise is visible here at the
+// latest when that kernel has finished (any wait on its stream, an event behind it, a finished copy).  Does not clear:
+// pca_status does.
+int pca_status_peek(pca_ctx *ctx, uint32_t *status_out)
+{
+    if (!ctx || !status_out) return -1;
+    uint32_t st = 0;
+    for (int b = 0; b < PCA_STATUS_BITS; ++b)
+        if (__atomic_load_n(&ctx->status_mirror[b], __ATOMIC_RELAXED)) st |= 1u << b;
+    *status_out = st;
+    return 0;
+}
+
+const uint32_t *pca_status_mirror(pca_ctx *ctx) { return ctx ? ctx->status_mirror : nullptr; }
 
 }  // extern "C"

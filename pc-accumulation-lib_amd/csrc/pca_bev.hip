@@ -73,6 +73,7 @@ struct BevArgs {
     int pend_slot_end[PCA_BEV_MAX_CHAIN];   // ascending
     Mat34 pend_T[PCA_BEV_MAX_CHAIN];
     int tx, T, G;
+    int Gr, Gp;           // counter tables: row length (>= G) and workgroups per XCD column block (table_pos)
     int tile_mult;        // bev_tile_cells: workgroup -> tile permutation (coprime to its period: T / 4 or T)
     int heavy_min;        // tiles with more records than this are bev_tile_cells_heavy's (<= RGB_CAP)
     uint32_t *key;        // [max_points]
@@ -121,6 +122,18 @@ __device__ __forceinline__ Window chunk_of(const BevArgs &a, int &g)
     return w;
 }
 __host__ __device__ __forceinline__ int64_t seg_stride(int64_t n, int G) { return (n + G - 1) / G; }
+// The per-(tile, workgroup) counter tables bh / boff are [tile][Gr] with workgroup g at position (g mod 8) Gp + g / 8:
+// workgroups are dealt to the eight XCDs round-robin, so the entries that share a cache line are written by workgroups of
+// ONE XCD -- the 32 of a round fill a whole 128-byte line in that XCD's L2, which then leaves it as one full-line write.
+// In plain [tile][g] order a line held the 4-byte stores of eight different L2s: 1 M partial-line writes per call, 100 MB
+// of write traffic for 75 MB of payload.  Level 2 reads a tile's row as one range either way.  Gp = 0: plain order.
+__device__ __forceinline__ int table_pos(const BevArgs &a, int g) { return a.Gp ? (g & 7) * a.Gp + (g >> 3) : g; }
+__device__ __forceinline__ int table_group(const BevArgs &a, int p)
+{
+    if (!a.Gp) return p;
+    const int x = p / a.Gp;
+    return (p - x * a.Gp) * 8 + x;                          // may be >= G: an unused place of the row
+}
 
 // ---------------------------------------------------------------------------------------------
 // level 1: bev_tile_bin -- every workgroup bins its contiguous chunk of the window into the T tiles and leaves the
@@ -212,7 +225,7 @@ __device__ __forceinline__ void bin_store(const BevArgs &a, uint32_t pos, uint32
         reinterpret_cast<RecD *>(a.recs)[pos] = r;
     } else {
         const float fi = (float)iv;
-        if (fi < 0.0f) atomicOr(a.status, PCA_STATUS_NEGATIVE_INTENSITY);
+        if (fi < 0.0f) pca_raise(a.status, PCA_STATUS_NEGATIVE_INTENSITY);
         RecF r; r.z = z;
         r.iw = (__float_as_uint(fi) & 0x7fffffffu) | ((key & 1u) << 31);
         r.cw = c | (((key & 127u) >> 1) << 26);
@@ -289,7 +302,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     const Window w = chunk_of(a, g);
     const int64_t chunk = seg_stride(w.hi - w.lo, a.G);
     if (blockIdx.x == 0) {
-        if (threadIdx.x == 0 && a.frame_off[a.slot_end] - w.lo > a.max_points) atomicOr(a.status, PCA_STATUS_STORE_OVERFLOW);
+        if (threadIdx.x == 0 && a.frame_off[a.slot_end] - w.lo > a.max_points) pca_raise(a.status, PCA_STATUS_STORE_OVERFLOW);
         if (threadIdx.x < HQ_IDS) a.heavy[threadIdx.x] = 0;  // the heavy queue of this call starts empty
     }
     for (int t = threadIdx.x; t < a.T; t += AB_THREADS) s_h[t] = 0;
@@ -427,6 +440,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     {
         const int per = (a.T + AB_THREADS - 1) / AB_THREADS;
         const int t0 = threadIdx.x * per;
+        const int gp = table_pos(a, g);
         uint32_t sum = 0;
         for (int k = 0; k < per; ++k) sum += t0 + k < a.T ? s_h[t0 + k] : 0u;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -442,8 +456,8 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
             const uint32_t c = s_h[t];
             s_cur[t] = run;
             // tile-major tables [tile][workgroup]: a tile's workgroup of level 2 reads its G counters as one range
-            a.bh[(int64_t)t * a.G + g] = c;
-            a.boff[(int64_t)t * a.G + g] = run;
+            a.bh[(int64_t)t * a.Gr + gp] = c;
+            a.boff[(int64_t)t * a.Gr + gp] = run;
             run += c;
         }
     }
@@ -514,21 +528,26 @@ struct RecMap {
 // Ends with a barrier.
 __device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, int tile, int nthreads, uint16_t *owner = nullptr)
 {
-    const int per = (a.G + nthreads - 1) / nthreads;
+    // (places of the row, not workgroups: see table_pos; a place beyond the last workgroup counts as an empty piece)
+    const int per = (a.Gr + nthreads - 1) / nthreads;
     const int g0 = threadIdx.x * per;
-    const uint32_t *cnt = a.bh + (int64_t)tile * a.G, *off = a.boff + (int64_t)tile * a.G;
-    uint32_t c[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0}, sum = 0;  // per <= 4: G <= 1024, nthreads >= 256
+    const uint32_t *cnt = a.bh + (int64_t)tile * a.Gr, *off = a.boff + (int64_t)tile * a.Gr;
+    uint32_t c[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0}, sum = 0;  // per <= 4: Gr <= 1024, nthreads >= 256
+    int grp[4] = {0, 0, 0, 0};
     // (the counters' loads are issued before the window's size is waited for: two memory round trips side by side)
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (k < per && g0 + k < a.G) { c[k] = cnt[g0 + k]; o[k] = off[g0 + k]; }
+        if (k < per && g0 + k < a.Gr) {
+            grp[k] = table_group(a, g0 + k);
+            if (grp[k] < a.G) { c[k] = cnt[g0 + k]; o[k] = off[g0 + k]; }
+        }
     const int64_t lo = a.frame_off[a.slot_begin], hi0 = a.frame_off[a.slot_end];
     const int64_t n = hi0 - lo > a.max_points ? a.max_points : hi0 - lo;
     const uint32_t chunk = (uint32_t)seg_stride(n, a.G);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (k < per && g0 + k < a.G) {
-            M.base[g0 + k] = (uint32_t)(g0 + k) * chunk + o[k];
+        if (k < per && g0 + k < a.Gr) {
+            M.base[g0 + k] = (uint32_t)grp[k] * chunk + o[k];
             sum += c[k];
         }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -539,7 +558,7 @@ __device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, in
     for (int k = 0; k < wave; ++k) run += M.wsum[k];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (k < per && g0 + k < a.G) {
+        if (k < per && g0 + k < a.Gr) {
             M.pre[g0 + k] = run;
             // the light tile kernel's lookup table: owner[i] = the piece record i lies in (a piece holds ~3 records of a
             // tile), so that a record costs three LDS reads instead of the ten-step search (50 of the ~200 vector
@@ -548,9 +567,9 @@ __device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, in
                 for (uint32_t j = 0; j < c[k]; ++j) owner[run + j] = (uint16_t)(g0 + k);
             run += c[k];
         }
-    if ((int)threadIdx.x == nthreads - 1) M.pre[a.G] = run;
+    if ((int)threadIdx.x == nthreads - 1) M.pre[a.Gr] = run;
     __syncthreads();
-    return M.pre[a.G];
+    return M.pre[a.Gr];
 }
 // place of the tile's record number i (< the tile's count): the last piece g with pre[g] <= i.  Ten fixed steps, no
 // branches: the lookups of a thread's 16 records are independent chains of LDS reads that the compiler interleaves (a
@@ -1033,7 +1052,7 @@ __device__ __forceinline__ void cells_drain(const BevArgs &a, TileLds &L, unsign
             for (uint32_t r = t_lo; r < t_hi; ++r) {
                 uint32_t kk, c;
                 double z, iv;
-                load_rec<I64>(a, recmap_at(M, a.G, r), kk, c, z, iv);
+                load_rec<I64>(a, recmap_at(M, a.Gr, r), kk, c, z, iv);
                 if (kk != run.key) {
                     if (run.key != RUN_NONE) run_flush(S, extra, run);
                     run_reset(run, kk);
@@ -1053,7 +1072,7 @@ __device__ __forceinline__ void cells_drain(const BevArgs &a, TileLds &L, unsign
                 __syncthreads();
                 for (uint32_t r = threadIdx.x; r < r_hi; r += C_THREADS) {
                     uint32_t kk, v;
-                    load_rec_key_colour<I64>(a, recmap_at(M, a.G, r), kk, v);
+                    load_rec_key_colour<I64>(a, recmap_at(M, a.Gr, r), kk, v);
                     const uint32_t rel = kk - 2u * (uint32_t)c0;
                     if (rel >= 8u) continue;
 #pragma unroll
@@ -1242,7 +1261,7 @@ __device__ __forceinline__ void tile_hist32(uint32_t (*hist)[256], const RecMap 
         uint32_t v = 0;
         if (act) {
             uint32_t k;
-            load_rec_key_colour<I64>(a, recmap_at(M, a.G, r), k, v);
+            load_rec_key_colour<I64>(a, recmap_at(M, a.Gr, r), k, v);
             act = k == fk;
         }
         const uint32_t tag = act ? v : 0xffffffffu;
@@ -1342,11 +1361,11 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
             uint32_t k[UNR], c[UNR];
             double z[UNR], iv[UNR];
             RecWalk walk;
-            recwalk_seek(walk, L.M, a.G, r0);
+            recwalk_seek(walk, L.M, a.Gr, r0);
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
-                if (r0 + u < r_hi) load_rec<I64>(a, recwalk_next(walk, L.M, a.G, r_hi), k[u], c[u], z[u], iv[u]);
+                if (r0 + u < r_hi) load_rec<I64>(a, recwalk_next(walk, L.M, a.Gr, r_hi), k[u], c[u], z[u], iv[u]);
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -1449,7 +1468,7 @@ int64_t pca_bev_workspace_bytes(int64_t max_points, int px)
 {
     if (max_points < 1) max_points = 1;
     const int64_t T = (int64_t)tiles_x(px) * tiles_x(px), G = n_groups(max_points);
-    return align256(max_points * 4) + 2 * align256(G * T * 4) + align256((HQ_IDS + HQ_CLASSES * T) * 4) +
+    return align256(max_points * 4) + 2 * align256((G + 8) * T * 4) + align256((HQ_IDS + HQ_CLASSES * T) * 4) +
            align256((max_points + G) * 24) + 512;
 }
 
@@ -1514,10 +1533,16 @@ static int bev_prepare(pca_ctx *ctx, const pca_store *store, const double *inten
     a.tx = tiles_x(prm->px);
     a.T = a.tx * a.tx;
     a.G = n_groups(max_points);
+    {   // PCA_BEV_XCD_TABLES=0: the counter tables in plain [tile][workgroup] order (A/B)
+        static int xt = -1;
+        if (xt < 0) { const char *e = getenv("PCA_BEV_XCD_TABLES"); xt = e ? atoi(e) : 1; }
+        a.Gp = (xt && a.G >= 16 && a.G <= 1016) ? (a.G + 7) / 8 : 0;   // (RecMap holds 1024 places)
+        a.Gr = a.Gp ? 8 * a.Gp : a.G;
+    }
     char *w = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     a.key = reinterpret_cast<uint32_t *>(w); w += align256(max_points * 4);
-    a.bh = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)a.G * a.T * 4);
-    a.boff = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)a.G * a.T * 4);
+    a.bh = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.G + 8) * a.T * 4);
+    a.boff = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.G + 8) * a.T * 4);
     a.heavy = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(HQ_IDS + HQ_CLASSES * (int64_t)a.T) * 4);
     a.recs = w;
     a.planes = planes;

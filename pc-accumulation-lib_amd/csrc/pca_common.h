@@ -30,7 +30,9 @@ struct pca_ctx {
     // decoupled look-back workspace (stable compaction / scans)
     uint64_t *tile_state = nullptr;   // dev [tile_cap]
     int64_t tile_cap = 0;
-    uint32_t *ticket = nullptr;       // dev [2]: [0] ticket counter, [1] status bits
+    uint32_t *ticket = nullptr;       // dev [4]: [0] ticket counter, [1] status bits, [2..3] device address of the mirror
+    uint32_t *status_mirror = nullptr;     // pinned, device-visible [PCA_STATUS_BITS]: word b != 0 <=> bit b was raised
+    uint32_t *status_mirror_dev = nullptr;
     uint32_t epoch = 0;               // 22-bit launch tag of tile_state entries
     void *k1_frames_dev = nullptr;    // dev: K1's frame descriptors of a batched launch
     int64_t k1_frames_cap = 0;        // bytes
@@ -192,6 +194,17 @@ __device__ __forceinline__ uint16_t f64_to_f16_bits_reference(double d)
     return (uint16_t)(sign | h);
 }
 
+// Raises a PCA_STATUS_* bit: the device word (read and cleared by pca_status, which synchronises) and its host-visible
+// mirror -- a plain store into mapped host memory, whose address sits next to the status word -- that pca_status_peek
+// reads without touching the stream.  Only ever executed on the error paths.
+#define PCA_STATUS_BITS 8
+__device__ __forceinline__ void pca_raise(uint32_t *status, uint32_t bit)
+{
+    atomicOr(status, bit);
+    uint32_t *mirror = *reinterpret_cast<uint32_t *const *>(status + 1);
+    if (mirror) __hip_atomic_store(mirror + (__ffs((int)bit) - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Decoupled look-back (single-pass chained scan).  Tiles are handed out by an atomic ticket so a
 // tile only ever waits on tiles whose workgroups are already running (no dispatch-order assumption).
@@ -244,7 +257,7 @@ __device__ __forceinline__ uint64_t lb_walk(uint64_t *state, int tile, uint64_t 
     uint32_t polls = 0;
     while (!done) {
         if (++polls > LB_MAX_POLLS) {
-            if (status && lane == 0) atomicOr(status, PCA_STATUS_LOOKBACK_TIMEOUT);
+            if (status && lane == 0) pca_raise(status, PCA_STATUS_LOOKBACK_TIMEOUT);
             break;
         }
         uint64_t w[LB_W];

@@ -468,7 +468,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a)
             db[o] = 0;
         }
     }
-    if (overflow) atomicOr(a.status, PCA_STATUS_STORE_OVERFLOW);
+    if (overflow) pca_raise(a.status, PCA_STATUS_STORE_OVERFLOW);
     if (threadIdx.x == 0 && tin == ftiles - 1)             // the last tile of a frame closes its segment
         a.frame_off[a.first_slot + fr.f + 1] = tile_base + total;
     K1_STAMP(6);
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(K1_APPEND_BLK) void k1_append(const K1AppendArgs a)
         a.st.inst[o] = 0;
         a.st.dyn[o] = 0;
     }
-    if (overflow) atomicOr(a.status, PCA_STATUS_STORE_OVERFLOW);
+    if (overflow) pca_raise(a.status, PCA_STATUS_STORE_OVERFLOW);
 }
 
 // =============================================================================================

@@ -173,6 +173,10 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         return out
 
     def _integrate_batch(self, batch):
+        # a prefetching loader reuses its buffers every few batches: refuse BEFORE anything of the accumulator has changed
+        # (poses, images, the pose provider's position), so that a refused call leaves it as it was
+        from pca_amd.ingest import check_ring_lifetime
+        check_ring_lifetime([item for observations in batch for item in observations[0]], len(batch))
         frames, Ts, shape = [], [], None
         for observations in batch:
             rgb, pc, sem_gt = observations[0]
@@ -188,8 +192,6 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
             Ts.append(T_new_prev)
             self.rgbs.append(rgb)
             self.semsegs.append(semseg)
-        from pca_amd.ingest import check_ring_lifetime     # a prefetching loader reuses its buffers every few batches
-        check_ring_lifetime([t for f in frames for t in f.values()], len(frames))
         self.store.flush_pending()
         self.store.append_kitti(frames, self.P_velo_frame, shape[0], shape[1], self.semseg_filters,
                                 sample_mode=self.sample_mode)
@@ -198,10 +200,11 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         for T_new_prev in Ts:                           # host bookkeeping, frame by frame as integrate() does
             idx, path_length = self._track.step(T_new_prev, self.horizon_dist)
             if path_length is not None:
-                print(f'    #pc {len(self._track) + idx} |', f'path length {path_length:.2f}')
+                print(f'    #pc {len(self._track)} |', f'path length {path_length:.2f}')
             removed.append(idx)
             total += idx
             self._integrated += 1
+        self.store.poll_status()
         if total:
             self.store.evict(total)
             self.rgbs = self.rgbs[total:]

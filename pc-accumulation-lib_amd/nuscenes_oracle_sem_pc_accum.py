@@ -156,6 +156,11 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
             for observations in batch:
                 self.integrate(observations)
             return
+        # a prefetching loader reuses its buffers every RING batches: refuse BEFORE anything of the accumulator has changed
+        # (poses, tracker, images, ts), so that a refused call leaves it as it was
+        from pca_amd.ingest import check_ring_lifetime
+        check_ring_lifetime([observations[0].get(k) for observations in batch for k in ('pc', 'pc_cam_idx', 'images')],
+                            len(batch))
         frames, marks = [], []
         for observations in batch:
             obs = observations[0]
@@ -178,8 +183,6 @@ class NuScenesOracleSemanticPointCloudAccumulator(SemanticPointCloudAccumulator)
             print(f'    ts {self.ts} | #pc {self.store.n_frames + len(frames)} |', f'path length {path_length:.2f}')
             self.ts += 1
             self._integrated += 1
-        from pca_amd.ingest import check_ring_lifetime     # a prefetching loader reuses its buffers every RING batches
-        check_ring_lifetime([t for f in frames for t in (f['pc'], f['cam_idx'], f['imgs'])], len(frames))
         self.store.append_nusc_many(frames, self.semseg_filters, sample_mode=self.sample_mode)
         self.store.mark_dynamic(marks)                 # flags only ever go from 0 to 1: the order of the marks is immaterial
 

@@ -16,7 +16,7 @@ STATUS_NEGATIVE_INTENSITY = 4
 STATUS_LOOKBACK_TIMEOUT = 8
 SAMPLE_MODES = {'nearest': 0, 'bilinear': 1}
 
-EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error', 'pca_status',
+EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error', 'pca_status', 'pca_status_peek', 'pca_status_mirror',
            'pca_kitti_project_sample_filter', 'pca_kitti_project_sample_filter_ex',
            'pca_nusc_sample_filter_transform', 'pca_nusc_sample_filter_transform_ex', 'pca_nusc_sample_filter_transform_batch', 'pca_sample_bilinear', 'pca_nusc_project_cams', 'pca_retransform', 'pca_retransform_batch_tail',
            'pca_mark_dynamic',
@@ -96,6 +96,9 @@ def load():
     lib.pca_last_error.argtypes = [vp]
     lib.pca_last_error.restype = C.c_char_p
     lib.pca_status.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
+    lib.pca_status_peek.argtypes = [vp, C.POINTER(C.c_uint32)]
+    lib.pca_status_mirror.argtypes = [vp]
+    lib.pca_status_mirror.restype = vp
     lib.pca_kitti_project_sample_filter.argtypes = [
         vp, C.POINTER(PcaKittiFrame), i32, C.POINTER(C.c_double), i32, i32, C.POINTER(C.c_uint64),
         C.POINTER(PcaStore), vp, i32, vp
@@ -197,6 +200,8 @@ class Context:
         if self.lib.pca_ctx_create(self.device_index, C.byref(h)) != 0:
             raise RuntimeError('pca_ctx_create failed')
         self.h = h
+        # the device status bits as the host sees them without a stream operation (pca_status_peek): mapped once
+        self._mirror = (C.c_uint32 * 8).from_address(self.lib.pca_status_mirror(h))
 
     @classmethod
     def get(cls, device=None):
@@ -233,6 +238,33 @@ class Context:
             self.check(self.lib.pca_profile_read(self.h, k, C.byref(ms), C.byref(n)))
             out[name] = (ms.value, n.value)
         return out
+
+    def peek_status(self):
+        """The status bits raised by kernels that have FINISHED, read from mapped host memory: no stream operation, no
+        wait (a fraction of a microsecond).  Does not clear; `status()` does."""
+        m = self._mirror
+        if not (m[0] | m[1] | m[2] | m[3] | m[4] | m[5] | m[6] | m[7]):
+            return 0
+        return sum(1 << b for b in range(8) if m[b])
+
+    def check_status(self):
+        """Synchronises, reads and clears the device status word and raises what the reference would have raised on the
+        spot (AssertionError of datasets/nuscenes_utils.py:191-195) or a RuntimeError naming what went wrong."""
+        st = self.status()
+        if st & STATUS_UV_OUT_OF_IMAGE:
+            raise AssertionError('pts_uv must be all inside image')
+        if st & STATUS_STORE_OVERFLOW:
+            raise RuntimeError('pca: device point store overflow (points were dropped)')
+        if st & STATUS_LOOKBACK_TIMEOUT:
+            raise RuntimeError('pca: a compaction workgroup timed out waiting for its predecessor (output invalid)')
+        if st & STATUS_NEGATIVE_INTENSITY:
+            raise ValueError('pca: negative lidar intensity on the f32 path (pass intensity64 to bev())')
+
+    def poll_status(self):
+        """check_status() without the wait: only when the host-visible mirror shows a raised bit (a kernel that has
+        finished raised it) does it synchronise and raise.  Cheap enough for every call."""
+        if self.peek_status():
+            self.check_status()
 
     def status(self):
         """Synchronises the stream and returns (and clears) the device status bits."""

@@ -84,16 +84,12 @@ class DeviceStore:
     def sizes(self):
         return np.diff(self.offsets())
 
+    def poll_status(self):
+        """check_status() without the wait (the host-visible mirror of the status word); for every call."""
+        self.ctx.poll_status()
+
     def check_status(self):
-        st = self.ctx.status()
-        if st & _lib.STATUS_UV_OUT_OF_IMAGE:
-            raise AssertionError('pts_uv must be all inside image')
-        if st & _lib.STATUS_STORE_OVERFLOW:
-            raise RuntimeError('pca: device point store overflow (points were dropped)')
-        if st & _lib.STATUS_LOOKBACK_TIMEOUT:
-            raise RuntimeError('pca: a compaction workgroup timed out waiting for its predecessor (output invalid)')
-        if st & _lib.STATUS_NEGATIVE_INTENSITY:
-            raise ValueError('pca: negative lidar intensity on the f32 path (pass intensity64 to bev())')
+        self.ctx.check_status()
 
     def reserve(self, n_new, n_slots=1):
         """Make room for n_slots more frames holding at most n_new points in total."""

@@ -151,7 +151,12 @@ PinnedUploader.upload_stack = _upload_stack
 def check_ring_lifetime(tensors, n_batches):
     """Raises if `n_batches` batches of a prefetching loader are about to be used together although the loader reuses its
     device buffers sooner: tensors it yields carry `_pca_ring` = the number of batches its ring holds."""
-    ring = min((getattr(t, '_pca_ring', 1 << 30) for t in tensors), default=1 << 30)
+    def ring_of(t):
+        # the tensor itself, or a wrapper's device copy IF it exists already (DeviceImage._dev, DeviceImages.dev): never
+        # triggers a lazy upload
+        d = getattr(t, '__dict__', {})
+        return min(getattr(c, '_pca_ring', 1 << 30) for c in (t, d.get('_dev'), d.get('dev')))
+    ring = min((ring_of(t) for t in tensors if t is not None), default=1 << 30)
     if n_batches > ring - 1:
         raise ValueError(f'these observations come from a prefetching loader that reuses its device buffers every {ring} '
                          f'batches: at most {ring - 1} of them can be integrated in one call (the earlier ones have been '

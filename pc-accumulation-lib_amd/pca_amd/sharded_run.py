@@ -140,6 +140,7 @@ def run_chunk(acc, get_obs, job, on_sample, warm_batch=64):
             oldest_here = f + 1 - len(acc.poses)          # number of the oldest frame this accumulator holds
             on_sample(f, todo[f] - oldest_here)
             taken += 1
+    acc.store.check_status()          # end of the chunk: one synchronisation, every kernel of the chunk has been heard
     return taken
 
 

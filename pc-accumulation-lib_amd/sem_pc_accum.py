@@ -101,6 +101,9 @@ class SemanticPointCloudAccumulator:
 
     def _after_integrate(self):
         self._integrated += 1
+        # errors of kernels that have finished (an overflowing store, a timed-out compaction, ...) surface on the next call
+        # at the latest; the read is a few words of mapped host memory, no stream operation
+        self.store.poll_status()
         if self.voxel_dedup and self._integrated % max(self.voxel_dedup_every, 1) == 0:
             self.store.voxel_dedup(self.voxel_dedup)
 
@@ -299,6 +302,8 @@ class SemanticPointCloudAccumulator:
         import torch
         from bev_generator.bev_generator import WindowPart
         gen = self.sem_bev_generator
+        if self._store is not None:
+            self._store.poll_status()
         if not isinstance(pcs['pc_present'], WindowPart) or os.environ.get('PCA_SYNC_BEV'):
             return [gen.generate_multiproc((pcs, self._copy_trajs(trajs)), worker=self._aug_worker0 + k)
                     for k in range(bev_num)]
@@ -323,6 +328,7 @@ class SemanticPointCloudAccumulator:
         present_idxs = list(present_idxs)
         if not present_idxs:
             return []
+        self.store.poll_status()
         px = gen.pixel_size
         planes = torch.empty((len(present_idxs), 21, px, px), dtype=torch.float16, device=self.store.device)
         with gen.raster_batch():

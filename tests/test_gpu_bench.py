@@ -101,3 +101,27 @@ def test_bench_four_ranks_gloo_rehearsal_of_config5():
     assert len(c5['frames_incl_warmup_per_rank']) == 4 and min(c5['frames_incl_warmup_per_rank']) > 0
     assert len(c5['seconds_per_rank']) == 4 and all(t > 0 for t in c5['seconds_per_rank'])
     assert c5['gather_check']['checksums_match'] is True and c5['ideal_speedup_of_this_plan'] > 2.5
+
+
+def test_bench_one_rank_over_rccl():
+    """The real transport on the one-GPU box: `torchrun --nproc-per-node 1 bench.py` initialises the `nccl` backend (RCCL on
+    ROCm), every barrier / all-reduce of the timed region goes through it, the headline's chunk and config 5's last chunk
+    are gathered as DEVICE tensors (shard.gather_to_rank0) and the checksums of what was sent and what arrived are compared.
+    A multi-GPU node only adds peers to the same calls."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('PCA_BENCH_BACKEND', None)
+    base = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+            '--master-port', '29547', os.path.join(ROOT, 'bench.py'), '--gpus', '1']
+    r = subprocess.run(base + ['--workload', 'config5', '--config5-scale', '0.01'], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = last_json(r.stdout)
+    gc = d['config5']['gather_check']
+    assert gc['backend'] == 'nccl' and gc['on_device_tensors'] is True and gc['checksums_match'] is True
+    assert d['config5_ideal_speedup_of_this_plan'] == pytest.approx(1.0) and d['config5_seconds_per_rank_max'] > 0
+    r = subprocess.run(base + ['--steps', '20', '--warmup', '1', '--no-extras', '--no-cpu-baseline', '--gather'],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = last_json(r.stdout)
+    gc = d['gather_check']
+    assert d['n_gpus'] == 1 and gc['backend'] == 'nccl' and gc['in_timed_region'] is True and gc['checksums_match'] is True

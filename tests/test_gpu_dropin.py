@@ -1239,3 +1239,68 @@ def test_staged_upload_ragged_sizes_and_threads():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def _kitti_gt_accumulator(capacity=None):
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    P = np.array([[40., 0, 48, 0], [0, 40., 32, 0], [0, 0, 1, 0]])
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': P}
+    acc = Kitti360SemanticPointCloudAccumulator(50., calib, 1e3, None, KITTI_FILTERS, SEM_IDXS, True, dict(BEV_KITTI))
+    acc.pose_provider = lambda pc: np.eye(4)
+    if capacity is not None:
+        acc._store_args = dict(capacity=capacity, max_frames=8)
+    return acc
+
+
+def _gt_obs(rng, n, intensity_sign=1.0):
+    from PIL import Image
+    pc = np.stack([rng.uniform(-9, 9, n), rng.uniform(-9, 9, n), rng.uniform(-1, 2, n),
+                   intensity_sign * rng.uniform(0.1, 1, n)], 1).astype(np.float32)
+    sem = np.zeros((n, 1), np.int64)                       # road: the intensity plane takes every point
+    return [(Image.fromarray(np.zeros((64, 96, 3), np.uint8)), pc, sem)]
+
+
+def test_device_errors_surface_through_the_kitti_dropin_without_check_status(tmp_path):
+    """The reference fails synchronously (IndexError in sem_bev.py:543-551, AssertionError in nuscenes_utils.py:191-195).
+    Here a kernel raises a status bit; the drop-in must turn it into an exception on its own -- when a sample is looked at,
+    when it is handed to the writer, on the next integrate() -- without anybody calling check_status()."""
+    import torch
+    from pca_amd import writer
+    rng = np.random.default_rng(5)
+    # (1) an overflowing store: points were dropped -> no sample made from the rest may be handed out.  The raise is seen as
+    # soon as the kernel has stored it: by the integrate() that caused it if the kernel is quick, else by the next call or the
+    # first look at the sample -- whichever comes first, without anybody asking
+    acc = _kitti_gt_accumulator(capacity=64)
+    acc.store.ub_tail = -10**9                             # defeat the host-side planner on purpose (as the K1 test does)
+    with pytest.raises(RuntimeError, match='overflow'):
+        acc.integrate(_gt_obs(rng, 5000))
+        bevs = acc.generate_bev(None, 1, gen_future=True)
+        bevs[0]['road_present']                            # first access waits for the copy and looks at the status mirror
+    assert acc.store.ctx.peek_status() == 0                # raised once, cleared
+    # (2) ... and on the next integrate() at the latest, for a driver that never looks at its samples
+    acc = _kitti_gt_accumulator(capacity=64)
+    acc.store.ub_tail = -10**9
+    with pytest.raises(RuntimeError, match='overflow'):
+        acc.integrate(_gt_obs(rng, 5000))
+        torch.cuda.synchronize()
+        acc.store.ub_tail = 0
+        acc.integrate(_gt_obs(rng, 10))
+    # (3) an error raised by the RASTER (a negative lidar intensity on the f32 path: the exact integer sums assume >= 0):
+    # integrate() and generate_bev() only enqueue, the sample's first access waits for its copy and raises
+    acc = _kitti_gt_accumulator()
+    acc.integrate(_gt_obs(rng, 2000, intensity_sign=-1.0))
+    bev = acc.generate_bev(None, 1, gen_future=True)[0]
+    with pytest.raises(ValueError, match='negative lidar intensity'):
+        bev['intensity_full']
+    # (4) the same through the background writer: the error comes back on the thread that talks to the driver
+    acc = _kitti_gt_accumulator()
+    acc.integrate(_gt_obs(rng, 2000, intensity_sign=-1.0))
+    acc.write_compressed_pickle(acc.generate_bev(None, 1, gen_future=True)[0], 'bev_bad.pkl', str(tmp_path))
+    with pytest.raises(ValueError, match='negative lidar intensity'):
+        writer.flush_shared()
+    assert not os.path.exists(os.path.join(str(tmp_path), 'bev_bad.pkl.gz'))
+    # (5) a clean run stays silent and costs no synchronisation: the mirror reads zero
+    acc = _kitti_gt_accumulator()
+    acc.integrate(_gt_obs(rng, 2000))
+    assert acc.generate_bev(None, 1, gen_future=True)[0]['road_full'].shape == (32, 32)
+    assert acc.store.ctx.peek_status() == 0
