@@ -322,6 +322,41 @@ int pca_host_ego_to_grid(const double *full, int F, const double R[9], double dx
                          double *rows, int32_t *start);
 
 /* ------------------------------------------------------------------------------------------------
+ * One library call per driver call (KITTI-360 flow).  The reference's driver calls integrate(observations) per frame and
+ * generate_bev(present_idx, bev_num, gen_future) when its trigger fires (run_kitti360_bev_gen.py:186-273); each of the two
+ * below does everything the library contributes to one such call.
+ *
+ * pca_kitti_integrate  replaces kitti360_sem_pc_accum.py:41-88: K1 on the observation (see pca_kitti_project_sample_filter)
+ *     + the pose bookkeeping of the frame (pca_host_track_step; track may be NULL: the caller keeps its own).  Inputs named
+ *     in host_mask are HOST arrays (what the reference's loader yields: kitti360_obs_dataloader.py:87-106); they are copied
+ *     into a pinned block of the context on the staging pool and leave in ONE asynchronous H2D copy; the others are device
+ *     pointers.  frame_off[slot] must hold the append position; *evicted / *path_length as pca_host_track_step.
+ * pca_kitti_generate_bev  replaces kitti360_sem_pc_accum.py:166-243 + bev_generator.py:63-125 for one un-augmented sample:
+ *     ego polylines (pca_host_ego_to_grid on poses - prm->origin; rows / start / *n_rows as there, F = poses of the track
+ *     = slot_end - slot_begin), raster (pca_bev_generate_chain, same arguments), and -- host_planes != NULL: page-locked,
+ *     21 px px 2 bytes -- the planes' copy to the host (pca_host_d2h_async).  Returns that copy's ticket (0 without), -1 on error.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct pca_host_track pca_host_track;
+typedef struct {
+    const void *pts;       /* [n,4] f32 x,y,z,intensity                                        */
+    const void *rgb;       /* [H,W,3] u8, or NULL with sem_gt                                  */
+    const void *sem;       /* [H,W] u8 class map, or NULL with sem_gt                          */
+    const void *sem_gt;    /* [n] u8 per-point class, or NULL                                  */
+    int32_t n;
+    uint32_t host_mask;    /* bit 0 pts, 1 rgb, 2 sem, 3 sem_gt: that pointer is a HOST array  */
+} pca_kitti_obs;
+int pca_kitti_integrate(pca_ctx *ctx, const pca_kitti_obs *obs, const double P[12], int H, int W,
+                        const uint64_t filter_mask[4], const pca_store *store, int64_t *frame_off /*dev*/, int slot,
+                        int sample_mode, pca_host_track *track, const double *T_new_prev, double horizon, int64_t *evicted,
+                        double *path_length, void *stream);
+int pca_kitti_generate_bev(pca_ctx *ctx, const pca_store *store, const int64_t *frame_off /*dev*/, int slot_begin,
+                           int slot_split, int slot_end, int64_t max_points, const pca_bev_params *prm,
+                           const double *pending_Ts, const int *pending_slot_ends, int n_pending, int write_back,
+                           void *workspace /*dev*/, int64_t workspace_bytes, uint16_t *planes_f16 /*dev*/,
+                           void *host_planes /*pinned or NULL*/, const pca_host_track *track, double *traj_rows,
+                           int32_t *traj_start, int32_t *n_rows, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Host arrays -> device for callers that hold their observations in pageable host memory -- what the reference's drivers
  * pass to integrate() (run_kitti360_bev_gen.py:173-190: numpy arrays straight from the loader).  src[k] (pageable, bytes[k]
  * long) is copied into pinned[k] (page-locked, caller-owned, at least bytes[k]) on a small pool of host threads, then
@@ -332,6 +367,12 @@ int pca_host_ego_to_grid(const double *full, int F, const double R[9], double dx
  * ------------------------------------------------------------------------------------------------ */
 int pca_host_stage_h2d(int n, const void *const *src, void *const *pinned, void *const *dev, const int64_t *bytes,
                        void *stream);
+/* The same as a PIPELINE for large transfers (the six camera images of a NuScenes observation,
+ * nuscenes_obs_dataloader.py:162-202: 26 MB per frame): 4 MB pieces, the pool fills piece c + 1 while piece c crosses PCIe,
+ * pieces alternate between two copy streams of the context; `stream` waits for both before the call returns its work to
+ * it.  Below PCA_H2D_PIPELINE_MIN bytes (default 8 MB) it is pca_host_stage_h2d. */
+int pca_host_stage_h2d_pipelined(pca_ctx *ctx, int n, const void *const *src, void *const *pinned, void *const *dev,
+                                 const int64_t *bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A device result on its way to the host (the BEV planes of a sample: sem_bev.py hands them back as host float16

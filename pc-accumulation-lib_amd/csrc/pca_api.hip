@@ -163,11 +163,21 @@ void pca_ctx_destroy(pca_ctx *ctx)
     }
     if (ctx->k1_frames_dev) (void)hipFree(ctx->k1_frames_dev);
     if (ctx->k1_tiny) (void)hipFree(ctx->k1_tiny);
+    for (auto &st : ctx->stage) {
+        if (st.done) { (void)hipEventSynchronize(st.done); (void)hipEventDestroy(st.done); }
+        if (st.pin) (void)hipHostFree(st.pin);
+        if (st.dev) (void)hipFree(st.dev);
+    }
     if (ctx->bevm_pin) (void)hipHostFree(ctx->bevm_pin);
     if (ctx->bevm_ev) (void)hipEventDestroy(ctx->bevm_ev);
     for (auto &e : ctx->d2h_done) if (e) (void)hipEventDestroy(e);
     if (ctx->d2h_go) (void)hipEventDestroy(ctx->d2h_go);
     if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
+    for (int j = 0; j < 2; ++j) {
+        if (ctx->h2d_done[j]) (void)hipEventDestroy(ctx->h2d_done[j]);
+        if (ctx->h2d_stream[j]) { (void)hipStreamSynchronize(ctx->h2d_stream[j]); (void)hipStreamDestroy(ctx->h2d_stream[j]); }
+    }
+    if (ctx->h2d_go) (void)hipEventDestroy(ctx->h2d_go);
     if (ctx->k1n_ws) (void)hipFree(ctx->k1n_ws);
     if (ctx->k1n_desc_dev) (void)hipFree(ctx->k1n_desc_dev);
     if (ctx->k1n_pin) (void)hipHostFree(ctx->k1n_pin);

@@ -54,6 +54,16 @@ struct pca_ctx {
     hipEvent_t d2h_go = nullptr;
     hipEvent_t d2h_done[64] = {};
     uint32_t d2h_next = 0;
+    // pca_host_stage_h2d_pipelined: two copy streams for large uploads, the event that lets them start, their ends
+    hipStream_t h2d_stream[2] = {nullptr, nullptr};
+    hipEvent_t h2d_go = nullptr;
+    hipEvent_t h2d_done[2] = {nullptr, nullptr};
+    // pca_kitti_integrate: host observations on their way to the device -- a ring of pinned + device blocks, each free
+    // again when the K1 launch that read it has finished
+    struct Stage { void *pin = nullptr; void *dev = nullptr; int64_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+#define PCA_STAGE_DEPTH 4
+    Stage stage[PCA_STAGE_DEPTH];
+    uint32_t stage_next = 0;
     void *k1_tiny = nullptr;          // dev: 4-byte copies of images smaller than the 4-byte colour gather
     int64_t k1_tiny_cap = 0;
     void *k1_ws[2] = {nullptr, nullptr};   // dev: counts / kept records of K1's split form, one per sub-batch in flight

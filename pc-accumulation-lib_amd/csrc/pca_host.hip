@@ -368,22 +368,30 @@ int64_t pca_host_track_trigger(pca_host_track *t, double bev_horizon, int64_t pr
 namespace {
 struct StageSlice { char *dst; const char *src; size_t n; };
 struct StagePool {
-    int T = 0;                                            // worker threads (the caller is participant T)
+    int T = 0;                                            // worker threads (the caller takes part too)
     long spin_us = 2000;
     std::vector<std::thread> th;
     std::atomic<uint64_t> job{0};
-    std::atomic<int> finished{0}, sleepers{0};
+    std::atomic<int> next{0}, done{0}, sleepers{0};
     std::atomic<bool> stop{false};
     std::mutex m;
     std::condition_variable cv;
     const StageSlice *slices = nullptr;
     int total = 0;
 
-    static void share(const StageSlice *s, int total, int who, int stride)
+    // Slices are CLAIMED from a shared counter, one at a time: a worker that is descheduled (more runnable threads than
+    // cores: eight ranks with their pools, a cgroup-limited container) simply claims nothing, and whoever is running --
+    // the caller included -- finishes the job; nobody waits for a share that was dealt to a sleeping thread.
+    void drain()
     {
-        for (int i = who; i < total; i += stride) memcpy(s[i].dst, s[i].src, s[i].n);
+        for (;;) {
+            const int i = next.fetch_add(1, std::memory_order_acq_rel);   // (pairs with run()'s release store: slices / total are visible)
+            if (i >= total) return;
+            memcpy(slices[i].dst, slices[i].src, slices[i].n);
+            done.fetch_add(1, std::memory_order_release);
+        }
     }
-    void worker(int w)
+    void worker()
     {
         uint64_t seen = 0;
         for (;;) {
@@ -402,24 +410,30 @@ struct StagePool {
             }
             if (stop.load()) return;
             seen = job.load(std::memory_order_acquire);
-            share(slices, total, w, T + 1);
-            finished.fetch_add(1, std::memory_order_release);
+            drain();
         }
     }
     void start(int threads)
     {
         T = threads;
         if (const char *e = getenv("PCA_STAGING_SPIN_US")) spin_us = atol(e);
-        for (int w = 0; w < T; ++w) th.emplace_back([this, w] { worker(w); });
+        for (int w = 0; w < T; ++w) th.emplace_back([this] { worker(); });
     }
     void run(const StageSlice *s, int n)
     {
         slices = s; total = n;
-        finished.store(0, std::memory_order_relaxed);
+        done.store(0, std::memory_order_relaxed);
+        next.store(0, std::memory_order_release);
         { std::lock_guard<std::mutex> lk(m); job.fetch_add(1, std::memory_order_release); }
         if (sleepers.load() > 0) cv.notify_all();
-        share(s, n, T, T + 1);
-        while (finished.load(std::memory_order_acquire) < T) __builtin_ia32_pause();
+        drain();
+        // every slice is claimed by now; the last few may still be in another thread's memcpy (<= 128 KB each): a short,
+        // bounded spin, then yield the core to whoever holds them
+        for (int spins = 0; done.load(std::memory_order_acquire) < n; ++spins) {
+            if (spins < 4096) __builtin_ia32_pause();
+            else std::this_thread::yield();
+        }
+        // (a worker that wakes up late finds next >= total and copies nothing; `slices` is not dereferenced then)
     }
     ~StagePool()
     {
@@ -437,7 +451,13 @@ static StagePool *stage_pool()
     if (pool && owner != getpid()) pool = nullptr;          // a forked child: the threads stayed with the parent (leaks the object)
     if (!pool) {
         owner = getpid();
+        // default: a third of this rank's share of the host's cores (sched_getaffinity-blind: cgroup limits are not seen,
+        // which is why slices are claimed and not dealt), at most 7 helpers, at least one
         int threads = 3;
+        long ranks = 1;
+        if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = atol(e) > 0 ? atol(e) : 1;
+        const long cores = sysconf(_SC_NPROCESSORS_ONLN);
+        if (cores > 0) { const long t = cores / ranks / 3; threads = (int)(t < 1 ? 1 : (t > 7 ? 7 : t)); }
         if (const char *e = getenv("PCA_STAGING_THREADS")) threads = atoi(e);
         if (threads < 0) threads = 0;
         if (threads > 15) threads = 15;
@@ -449,27 +469,89 @@ static StagePool *stage_pool()
 }
 }  // namespace
 
+// host copies of `n` ranges side by side on the staging pool (also used by pca_kitti_integrate)
+int pca_stage_copy(const void *const *src, void *const *dst, const int64_t *bytes, int n)
+{
+    constexpr size_t SLICE = 128 * 1024;
+    std::vector<StageSlice> slices;
+    for (int k = 0; k < n; ++k)
+        for (size_t o = 0; o < (size_t)bytes[k]; o += SLICE)
+            slices.push_back({(char *)dst[k] + o, (const char *)src[k] + o, (size_t)bytes[k] - o < SLICE ? (size_t)bytes[k] - o : SLICE});
+    static std::mutex serial;                               // one job at a time (callers on several threads take turns)
+    std::lock_guard<std::mutex> lk(serial);
+    StagePool *pool = stage_pool();
+    if (pool->T == 0 || slices.size() < 2) for (auto &sl : slices) memcpy(sl.dst, sl.src, sl.n);
+    else pool->run(slices.data(), (int)slices.size());
+    return 0;
+}
+
 extern "C" int pca_host_stage_h2d(int n, const void *const *src, void *const *pinned, void *const *dev, const int64_t *bytes,
                                   void *stream)
 {
     if (n < 0 || (n > 0 && (!src || !pinned || !dev || !bytes))) return -1;
-    constexpr size_t SLICE = 128 * 1024;
-    std::vector<StageSlice> slices;
-    for (int k = 0; k < n; ++k) {
+    for (int k = 0; k < n; ++k)
         if (bytes[k] < 0 || (bytes[k] > 0 && (!src[k] || !pinned[k] || !dev[k]))) return -1;
-        for (size_t o = 0; o < (size_t)bytes[k]; o += SLICE)
-            slices.push_back({(char *)pinned[k] + o, (const char *)src[k] + o, (size_t)bytes[k] - o < SLICE ? (size_t)bytes[k] - o : SLICE});
-    }
-    static std::mutex serial;                               // one job at a time (callers on several threads take turns)
-    {
-        std::lock_guard<std::mutex> lk(serial);
-        StagePool *pool = stage_pool();
-        if (pool->T == 0 || slices.size() < 2) StagePool::share(slices.data(), (int)slices.size(), 0, 1);
-        else pool->run(slices.data(), (int)slices.size());
-    }
+    pca_stage_copy(src, pinned, bytes, n);
     for (int k = 0; k < n; ++k)
         if (bytes[k] > 0 && hipMemcpyAsync(dev[k], pinned[k], (size_t)bytes[k], hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
             return -2;
+    return 0;
+}
+
+// The same for LARGE transfers (the six camera images of a NuScenes observation: 26 MB per frame, 1 GB per scene), as a
+// pipeline: the arrays are cut into 4 MB pieces; while piece c is on its way over PCIe the pool already fills the pinned
+// bytes of piece c + 1, and the pieces alternate between two copy streams of the context (two SDMA engines instead of one).
+// `stream` waits for both at the end, so for the caller the call looks like pca_host_stage_h2d: everything enqueued on
+// `stream` afterwards sees the data; the pinned blocks may be reused once `stream` has passed this point.
+// Below PCA_H2D_PIPELINE_MIN bytes (default 8 MB) it IS pca_host_stage_h2d (the two event hops cost more than they hide).
+extern "C" int pca_host_stage_h2d_pipelined(pca_ctx *ctx, int n, const void *const *src, void *const *pinned, void *const *dev,
+                                            const int64_t *bytes, void *stream)
+{
+    if (!ctx) return -1;
+    if (n < 0 || (n > 0 && (!src || !pinned || !dev || !bytes))) { ctx->err = "stage_h2d_pipelined: bad arguments"; return -1; }
+    int64_t total = 0;
+    for (int k = 0; k < n; ++k) {
+        if (bytes[k] < 0 || (bytes[k] > 0 && (!src[k] || !pinned[k] || !dev[k]))) { ctx->err = "stage_h2d_pipelined: bad arguments"; return -1; }
+        total += bytes[k];
+    }
+    static int64_t min_bytes = -1;
+    if (min_bytes < 0) { const char *e = getenv("PCA_H2D_PIPELINE_MIN"); min_bytes = e ? atoll(e) : (8ll << 20); }
+    if (total < min_bytes) {
+        const int rc = pca_host_stage_h2d(n, src, pinned, dev, bytes, stream);
+        if (rc != 0) ctx->err = "stage_h2d: a copy could not be enqueued";
+        return rc;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    static int n_streams = -1;                              // PCA_H2D_STREAMS: 0 = the caller's stream, 1 or 2 copy streams
+    if (n_streams < 0) { const char *e = getenv("PCA_H2D_STREAMS"); n_streams = e ? atoi(e) : 1; if (n_streams < 0 || n_streams > 2) n_streams = 1; }
+    hipStream_t cs[2] = {s, s};
+    for (int j = 0; j < n_streams; ++j) {
+        if (!ctx->h2d_stream[j]) PCA_CHECK(ctx, hipStreamCreateWithFlags(&ctx->h2d_stream[j], hipStreamNonBlocking));
+        if (!ctx->h2d_done[j]) PCA_CHECK(ctx, hipEventCreateWithFlags(&ctx->h2d_done[j], hipEventDisableTiming));
+        cs[j] = ctx->h2d_stream[j];
+    }
+    if (n_streams == 1) cs[1] = cs[0];
+    if (n_streams > 0) {
+        if (!ctx->h2d_go) PCA_CHECK(ctx, hipEventCreateWithFlags(&ctx->h2d_go, hipEventDisableTiming));
+        // the copies may start once everything enqueued on `stream` so far is done (whoever still reads the device buffers)
+        PCA_CHECK(ctx, hipEventRecord(ctx->h2d_go, s));
+        for (int j = 0; j < n_streams; ++j) PCA_CHECK(ctx, hipStreamWaitEvent(ctx->h2d_stream[j], ctx->h2d_go, 0));
+    }
+    constexpr int64_t PIECE = 4ll << 20;
+    int c = 0;
+    for (int k = 0; k < n; ++k)
+        for (int64_t o = 0; o < bytes[k]; o += PIECE, ++c) {
+            const int64_t len = bytes[k] - o < PIECE ? bytes[k] - o : PIECE;
+            const void *ps = (const char *)src[k] + o;
+            void *pp = (char *)pinned[k] + o;
+            pca_stage_copy(&ps, &pp, &len, 1);
+            PCA_CHECK(ctx, hipMemcpyAsync((char *)dev[k] + o, pp, (size_t)len, hipMemcpyHostToDevice, cs[c & 1]));
+        }
+    for (int j = 0; j < n_streams; ++j) {
+        PCA_CHECK(ctx, hipEventRecord(ctx->h2d_done[j], ctx->h2d_stream[j]));
+        PCA_CHECK(ctx, hipStreamWaitEvent(s, ctx->h2d_done[j], 0));
+    }
     return 0;
 }
 

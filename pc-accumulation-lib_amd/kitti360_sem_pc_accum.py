@@ -27,6 +27,9 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         self.P_velo_frame = calib_params['p_velo_frame']
         self._gpu_icp = None
         self._uploader = None            # pinned staging of host-array observations (pca_amd.ingest.PinnedUploader)
+        self._cobs = None                # the observation as the library takes it (reused)
+        import os
+        self._fast = os.environ.get('PCA_FAST_CALLS', '1') != '0'      # one library call per driver call (0: the general path)
         self._prev_sweep = None
         self.pose_provider = self._default_pose_provider()
 
@@ -133,20 +136,87 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         return self._uploader.upload_many(items)
 
     # ---- integrate -----------------------------------------------------------------------------
+    def _obs_pointers(self, rgb, pc, sem_gt):
+        """The observation as pca_kitti_integrate takes it: (PcaKittiObs, semseg, H, W, what must stay alive), host arrays
+        named in the struct's host_mask (the library stages them: one pinned block, ONE H2D copy), device tensors passed as
+        they are.  None if this observation needs the general path (a model that wants the image on the device first)."""
+        import torch
+        from pca_amd._lib import PcaKittiObs
+        dev = self.store.device
+        obs = self._cobs
+        if obs is None:
+            obs = self._cobs = PcaKittiObs()
+        keep, mask = [], 0
+
+        def put(a, np_dtype, t_dtype, bit):
+            nonlocal mask
+            if not isinstance(a, torch.Tensor):
+                d = getattr(a, '__dict__', {}).get('_dev')      # pca_amd.ingest.DeviceImage with its copy already there
+                if d is not None:
+                    a = d
+                elif hasattr(a, 'host') and hasattr(a, 'dev'):  # ... or not yet: its host array goes with the others
+                    a = a.host
+            if isinstance(a, torch.Tensor):
+                if a.device != dev or a.dtype != t_dtype or not a.is_contiguous():
+                    a = a.to(device=dev, dtype=t_dtype).contiguous()
+                keep.append(a)
+                return a.data_ptr(), tuple(a.shape)
+            a = np.ascontiguousarray(a, dtype=np_dtype)
+            keep.append(a)
+            mask |= bit
+            return a.ctypes.data, a.shape
+
+        obs.pts, shape = put(pc, np.float32, torch.float32, 1)
+        if len(shape) != 2 or shape[1] != 4:
+            raise ValueError('pc must be (N, 4): x, y, z, intensity')
+        obs.n = int(shape[0])
+        semseg = None
+        if sem_gt is None:
+            if getattr(self.semseg_model, 'accepts_device', False) and not isinstance(rgb, torch.Tensor) \
+                    and getattr(rgb, '__dict__', {}).get('_dev') is None:
+                return None
+            obs.rgb, ishape = put(rgb, np.uint8, torch.uint8, 2)
+            # a model that works on the device gets the device image (its class map goes to K1 without visiting the host)
+            src = keep[-1] if getattr(self.semseg_model, 'accepts_device', False) else rgb
+            semseg = self.semseg_model.pred(src)[0, 0]
+            obs.sem, sshape = put(semseg, np.uint8, torch.uint8, 4)
+            if len(ishape) != 3 or ishape[2] != 3 or tuple(ishape[:2]) != tuple(sshape):
+                raise ValueError(f'image {tuple(ishape)} and class map {tuple(sshape)} do not fit together')
+            obs.sem_gt = None
+            H, W = int(sshape[0]), int(sshape[1])
+        else:
+            sg = sem_gt if isinstance(sem_gt, torch.Tensor) else np.asarray(sem_gt)[:, -1]
+            obs.sem_gt, gshape = put(sg, np.uint8, torch.uint8, 8)         # trainIds 0..18 and 255
+            if tuple(gshape) != (obs.n, ):
+                raise ValueError('sem_gt must hold one label per point')
+            obs.rgb = obs.sem = None
+            H, W = 1, 1
+        obs.host_mask = mask
+        return obs, semseg, H, W, keep
+
     def integrate(self, observations: list):
         rgb, pc, sem_gt = observations[0]
         if not self.use_gt_sem:
             sem_gt = None
         T_new_prev = np.asarray(self.pose_provider(pc), dtype=np.float64)
         self.T_prev_origin = np.matmul(self.T_prev_origin, T_new_prev)
-        frame, semseg, H, W = self._frame_tensors(rgb, pc, sem_gt)
-
-        if len(self._track) > 0:          # move everything stored so far into the new ego frame (K2, owed to the next reader)
+        fast = self._obs_pointers(rgb, pc, sem_gt) if self._fast else None
+        general = self._frame_tensors(rgb, pc, sem_gt) if fast is None else None
+        if len(self._track) > 0:           # move everything stored so far into the new ego frame (K2, owed to the next reader)
             self.update_sem_pcs(T_new_prev)
-        self.store.append_kitti([frame], self.P_velo_frame, H, W, self.semseg_filters, sample_mode=self.sample_mode)
-        # the pose bookkeeping of the frame in one call: update_poses, the new pose [0,0,0], the newest path segment and
-        # the horizon eviction (sem_pc_accum.py:156-228; kitti360_sem_pc_accum.py:60-88)
-        idx, path_length = self._track.step(T_new_prev, self.horizon_dist)
+        if fast is not None:
+            # ONE library call: staging + upload of the host arrays, K1, and the pose bookkeeping of the frame (update_poses,
+            # the new pose [0,0,0], the newest path segment, the horizon eviction: sem_pc_accum.py:156-228)
+            obs, semseg, H, W, keep = fast
+            idx, path_length = self.store.append_kitti_obs(obs, self.P_velo_frame, H, W, self.semseg_filters, self.sample_mode,
+                                                           self._track, T_new_prev, self.horizon_dist)
+            del keep
+            if idx is None:                # a numpy pose track: its step stays here
+                idx, path_length = self._track.step(T_new_prev, self.horizon_dist)
+        else:
+            frame, semseg, H, W = general
+            self.store.append_kitti([frame], self.P_velo_frame, H, W, self.semseg_filters, sample_mode=self.sample_mode)
+            idx, path_length = self._track.step(T_new_prev, self.horizon_dist)
         self.rgbs.append(rgb)
         self.semsegs.append(semseg)
         if idx:
@@ -228,5 +298,78 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
 
     # ---- BEV -----------------------------------------------------------------------------------
     def generate_bev(self, present_idx: int = None, bev_num: int = 1, gen_future: bool = False):
+        if bev_num == 1 and gen_future and self._fast_bev_ok(present_idx):
+            return [self._generate_bev_fast(present_idx)]
         pcs, trajs = self._window_inputs(present_idx, gen_future)
         return self._run_bev(pcs, trajs, bev_num)
+
+    def generate_bev_device(self, present_idx: int, out=None):
+        """Extension (no reference counterpart): generate_bev(present_idx, 1, gen_future=True)[0] with the 21 planes left in
+        HBM -- {'planes_f16': cuda float16 [21,px,px] (`out` if given), 'trajs_present' / '_future' / '_full'} -- for callers
+        that gather or post-process on the device (the sharded runner, the benchmark)."""
+        if self._fast_bev_ok(present_idx):
+            return self._generate_bev_fast(present_idx, out=out, to_host=False)
+        pcs, trajs = self._window_inputs(present_idx, True)
+        return self.sem_bev_generator.generate(pcs, trajs, device_only=True, out=out)
+
+    def _fast_bev_ok(self, present_idx):
+        import os
+
+        from bev_generator.sem_bev import SemBEVGenerator
+        gen = self.sem_bev_generator
+        if not self._fast or type(gen) is not SemBEVGenerator or gen.do_aug or gen.do_warp or self._store is None \
+                or getattr(self._track, '_h', None) is None or os.environ.get('PCA_SYNC_BEV'):
+            return False
+        if not isinstance(present_idx, (int, np.integer)):
+            return False
+        n = self._store.n_frames
+        split = int(present_idx) if present_idx >= 0 else n + int(present_idx)
+        return 0 < split < n and n == len(self._track)
+
+    def _generate_bev_fast(self, present_idx, out=None, to_host=True):
+        """One un-augmented sample through ONE library call (pca_kitti_generate_bev): ego polylines, raster with the owed
+        re-transforms riding along, and the planes' way to the host.  Same numbers as the general path (_window_inputs ->
+        generate -> rasterise -> to_host_async), which stays for everything else (augmentation, warp, bev_num > 1, ...)."""
+        import ctypes as C
+
+        import torch
+        from bev_generator.sem_bev import LazyBev, _PendingCopy
+        from pca_amd import host_logic as hl
+        st, gen, track = self.store, self.sem_bev_generator, self._track
+        ctx = st.ctx
+        st.poll_status()
+        n = st.n_frames
+        present_idx = int(present_idx)
+        split = present_idx if present_idx >= 0 else n + present_idx
+        poses = track.as_array()
+        origin = poses[split].copy()
+        # heading from the last two PRESENT poses (bev_generator.py:87-93), evaluated with numpy as the general path does
+        rot_mat = hl.rotation_matrix_3d(hl.heading_rot_ang(poses[max(split - 2, 0):split] - origin))
+        px = gen.pixel_size
+        prm = gen._raster_params(origin, rot_mat, 0., 0., 1. * gen.view_size, st.intensity_div255)
+        max_points = st.bev_workspace(px)
+        n_pend, pend_T, pend_ends, write_back = st.bev_pending(0, n)
+        if out is None:
+            out = torch.empty((21, px, px), dtype=torch.float16, device=st.device)
+        else:
+            assert out.dtype == torch.float16 and out.is_contiguous() and tuple(out.shape) == (21, px, px)
+        host = torch.empty((1, 21, px, px), dtype=torch.float16, pin_memory=True) if to_host else None
+        rows = np.empty((max(2 * (n - 1), 1), 3))
+        start = np.zeros(max(n, 1), dtype=np.int32)
+        n_rows = C.c_int32(0)
+        cst = st.c_store()
+        ticket = ctx.lib.pca_kitti_generate_bev(ctx.h, C.byref(cst), st.frame_off.data_ptr(), st.head, st.head + split,
+                                                st.head + n, max_points, C.byref(prm), pend_T, pend_ends, n_pend, write_back,
+                                                st._ws.data_ptr(), st._ws.numel(), out.data_ptr(),
+                                                None if host is None else host.data_ptr(), track._h, rows.ctypes.data,
+                                                start.ctypes.data, C.byref(n_rows), ctx.stream())
+        if ticket < 0:
+            ctx.check(ticket)
+        st.bev_done(write_back)
+        rows = rows[:n_rows.value]
+        empty = np.zeros((0, 3))
+        ego_p = rows[:start[split - 1]].copy() if split >= 2 else empty      # edges 0 .. split-2 belong to the present polyline
+        ego_f = rows[start[split]:].copy() if n - split >= 2 else empty
+        if not to_host:
+            return {'planes_f16': out, 'trajs_present': [ego_p], 'trajs_future': [ego_f], 'trajs_full': [rows]}
+        return LazyBev(host, 0, _PendingCopy(ctx, ticket, (out, host)), ([ego_p], [ego_f], [rows]))

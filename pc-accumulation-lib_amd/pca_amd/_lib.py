@@ -24,7 +24,8 @@ EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error',
            'pca_host_gemv4_probe', 'pca_host_gemv4_mode', 'pca_host_incr_probe', 'pca_host_incr_blocks', 'pca_host_track_create', 'pca_host_track_destroy', 'pca_host_track_len', 'pca_host_track_n_segments',
            'pca_host_track_poses', 'pca_host_track_segments', 'pca_host_track_set', 'pca_host_track_transform',
            'pca_host_track_append', 'pca_host_track_push_segment', 'pca_host_track_incr', 'pca_host_track_evict_beyond',
-           'pca_host_track_step', 'pca_host_track_trigger', 'pca_host_stage_h2d', 'pca_host_d2h_async', 'pca_host_d2h_wait',
+           'pca_host_track_step', 'pca_host_track_trigger', 'pca_host_stage_h2d', 'pca_host_stage_h2d_pipelined', 'pca_host_d2h_async', 'pca_host_d2h_wait',
+           'pca_kitti_integrate', 'pca_kitti_generate_bev',
            'pca_profile_enable', 'pca_profile_read')
 
 KERNEL_IDS = ('kitti_project_sample_filter', 'nusc_sample_filter_transform', 'nusc_project_cams', 'retransform',
@@ -35,6 +36,11 @@ BEV_EXTRA_PLANES = ('elevation_max', 'elevation_mean', 'intensity_mean')
 class PcaStore(C.Structure):
     _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('z', C.c_void_p), ('intensity', C.c_void_p),
                 ('rgbs', C.c_void_p), ('inst', C.c_void_p), ('dyn', C.c_void_p), ('capacity', C.c_int64)]
+
+
+class PcaKittiObs(C.Structure):
+    _fields_ = [('pts', C.c_void_p), ('rgb', C.c_void_p), ('sem', C.c_void_p), ('sem_gt', C.c_void_p),
+                ('n', C.c_int32), ('host_mask', C.c_uint32)]
 
 
 class PcaKittiFrame(C.Structure):
@@ -176,8 +182,14 @@ def load():
     lib.pca_host_track_trigger.argtypes = [vp, C.c_double, i64, C.c_double]
     lib.pca_host_track_trigger.restype = i64
     lib.pca_host_stage_h2d.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.pca_host_stage_h2d_pipelined.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     lib.pca_host_d2h_async.argtypes = [vp, vp, vp, i64, vp]
     lib.pca_host_d2h_wait.argtypes = [vp, i32]
+    lib.pca_kitti_integrate.argtypes = [vp, C.POINTER(PcaKittiObs), C.POINTER(C.c_double), i32, i32, C.POINTER(C.c_uint64),
+                                        C.POINTER(PcaStore), vp, i32, i32, vp, vp, C.c_double, C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_double), vp]
+    lib.pca_kitti_generate_bev.argtypes = [vp, C.POINTER(PcaStore), vp, i32, i32, i32, i64, C.POINTER(PcaBevParams), vp, vp,
+                                           i32, i32, vp, i64, vp, vp, vp, vp, vp, C.POINTER(C.c_int32), vp]
     lib.pca_profile_enable.argtypes = [vp, i32]
     lib.pca_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = lib

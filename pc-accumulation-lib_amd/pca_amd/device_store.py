@@ -45,6 +45,10 @@ class DeviceStore:
         self._ws_many = None
         self._ws_points, self._ws_px = 0, 0
         self._dedup_ws = None
+        self._obs_out = None
+        self._pend_T = (C.c_double * (16 * self.CHAIN_MAX))()      # the owed chain as the C calls take it
+        self._pend_T_np = np.frombuffer(self._pend_T, dtype=np.float64)
+        self._pend_ends = (C.c_int * self.CHAIN_MAX)()
 
     # ---- memory ----------------------------------------------------------------------------
     def _alloc(self, cap):
@@ -174,6 +178,39 @@ class DeviceStore:
         self.ub_tail += n_in
         self._ub += [int(f['pts'].shape[0]) for f in frames]
         self._ub_sum += n_in
+
+    def append_kitti_obs(self, obs, P, H, W, filters, sample_mode='nearest', track=None, T_new_prev=None, horizon=0.):
+        """One observation through pca_kitti_integrate: `obs` is a _lib.PcaKittiObs whose pointers are device pointers or --
+        where its host_mask says so -- host arrays (staged by the library: one pinned block, one H2D copy).  With `track` (a
+        host_logic.CPoseTrack) the pose bookkeeping of the frame happens in the same call: returns (evicted frames, path
+        length | None); without, (None, None) and the caller steps its own track.  The caller evicts."""
+        lib, ctx = self.ctx.lib, self.ctx
+        n = int(obs.n)
+        self.reserve(n, 1)
+        key = (np.asarray(P, dtype=np.float64).tobytes(), tuple(int(c) for c in (filters or ())))
+        if self._k1_cache is None or self._k1_cache[0] != key:
+            self._k1_cache = (key, _lib.f64_array(P, 12), _lib.class_mask(filters))
+        Pc, fmask = self._k1_cache[1], self._k1_cache[2]
+        st = self.c_store()
+        th = getattr(track, '_h', None)
+        Tc = None
+        if th is not None:
+            Tc = np.ascontiguousarray(T_new_prev, dtype=np.float64)
+        if self._obs_out is None:
+            self._obs_out = (C.c_int64(0), C.c_double(0.0))
+        ev, pl = self._obs_out
+        ctx.check(lib.pca_kitti_integrate(ctx.h, C.byref(obs), Pc, int(H), int(W), fmask, C.byref(st),
+                                          self.frame_off.data_ptr(), self.tail, _lib.SAMPLE_MODES[sample_mode], th,
+                                          None if Tc is None else Tc.ctypes.data, float(horizon), C.byref(ev), C.byref(pl),
+                                          ctx.stream()))
+        self.tail += 1
+        self.ub_tail += n
+        self._ub.append(n)
+        self._ub_sum += n
+        if th is None:
+            return None, None
+        v = pl.value
+        return int(ev.value), (None if v != v else np.float64(v))
 
     # ---- K1n: NuScenes --------------------------------------------------------------------
     def append_nusc(self, pc, cam_idx, imgs, sems, T, filters, sample_mode='nearest'):
@@ -324,30 +361,13 @@ class DeviceStore:
         ctx, lib = self.ctx, self.ctx.lib
         last_frame = self.n_frames if last_frame is None else last_frame
         px = int(prm.px)
-        max_points = self.max_window_points()
-        if self._ws is None or max_points > self._ws_points or px != self._ws_px:
-            # sized with headroom so that a window growing frame by frame does not reallocate every call
-            self._ws_points, self._ws_px = int(max_points * 1.25) + 1, px
-            need = lib.pca_bev_workspace_bytes(self._ws_points, px)
-            if self._ws is None or self._ws.numel() < need:
-                self._ws = torch.empty(int(need) + 256, dtype=torch.uint8, device=self.device)
+        max_points = self.bev_workspace(px)
         if out16 is not None:
             assert out16.dtype == torch.float16 and out16.is_contiguous() and tuple(out16.shape) == (21, px, px)
         p16 = out16 if out16 is not None else torch.empty((21, px, px), dtype=torch.float16, device=self.device)
         p64 = torch.empty((21, px, px), dtype=torch.float64, device=self.device) if want_f64 else None
         st = self.c_store()
-        # the owed re-transforms ride along (oldest first); they are written back only when CHAIN_K of them are owed
-        n_pend, pend_T, pend_ends, write_back = 0, None, None, 1
-        if self._pending:
-            if first_frame == 0 and self._pending[-1][1] <= self.head + last_frame:
-                live = [(T, e) for T, e in self._pending if e > self.head]
-                n_pend = len(live)
-                if n_pend:
-                    pend_T = _lib.f64_array(np.concatenate([T for T, _ in live]), 16 * n_pend)
-                    pend_ends = (C.c_int * n_pend)(*[int(e) for _, e in live])
-                write_back = 1 if n_pend >= self.CHAIN_K else 0
-            else:
-                self.flush_pending()
+        n_pend, pend_T, pend_ends, write_back = self.bev_pending(first_frame, last_frame)
         if extra is not None:
             assert extra.dtype == torch.float64 and extra.is_contiguous() \
                 and tuple(extra.shape) == (3, len(_lib.BEV_EXTRA_PLANES), px, px)
@@ -357,9 +377,42 @@ class DeviceStore:
                                              write_back, self._ws.data_ptr(), self._ws.numel(),
                                              None if p64 is None else p64.data_ptr(), p16.data_ptr(),
                                              None if extra is None else extra.data_ptr(), ctx.stream()))
-        if self._pending and write_back:
-            self._pending = []                 # only now: a failed call above leaves the owed re-transforms owed
+        self.bev_done(write_back)                  # only now: a failed call above leaves the owed re-transforms owed
         return p16, p64
+
+    def bev_workspace(self, px):
+        """Makes sure the raster's scratch fits the live window at `px`; returns the window's point bound (max_points)."""
+        max_points = self.max_window_points()
+        if self._ws is None or max_points > self._ws_points or px != self._ws_px:
+            # sized with headroom so that a window growing frame by frame does not reallocate every call
+            self._ws_points, self._ws_px = int(max_points * 1.25) + 1, px
+            need = self.ctx.lib.pca_bev_workspace_bytes(self._ws_points, px)
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(int(need) + 256, dtype=torch.uint8, device=self.device)
+        return max_points
+
+    def bev_pending(self, first_frame, last_frame):
+        """The owed re-transforms as a raster over live frames [first_frame, last_frame) takes them (oldest first; they are
+        written back only when CHAIN_K of them are owed): (n_pend, Ts, slot ends, write_back) for pca_bev_generate_chain.
+        A raster that does not cover what they are owed to gets them flushed first (K2)."""
+        if not self._pending:
+            return 0, None, None, 1
+        if first_frame != 0 or self._pending[-1][1] > self.head + last_frame:
+            self.flush_pending()
+            return 0, None, None, 1
+        n_pend = 0
+        for T, e in self._pending:
+            if e > self.head:
+                self._pend_T_np[16 * n_pend:16 * n_pend + 16] = T
+                self._pend_ends[n_pend] = int(e)
+                n_pend += 1
+        if n_pend == 0:
+            return 0, None, None, 0
+        return n_pend, self._pend_T, self._pend_ends, (1 if n_pend >= self.CHAIN_K else 0)
+
+    def bev_done(self, write_back):
+        if self._pending and write_back:
+            self._pending = []
 
     def bev_many(self, jobs, out16):
         """jobs: [(split_frame, prm, first_frame, last_frame | None)]; out16: cuda float16 [len(jobs),21,px,px].  All rasters

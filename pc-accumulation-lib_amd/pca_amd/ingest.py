@@ -6,7 +6,7 @@ resident in HBM (the accumulators accept cuda tensors in place of numpy / PIL in
     for observations in loader:
         acc.integrate(observations)
 
-A small pool of reader threads (PCA_INGEST_THREADS, default 8; the decoders release the GIL) does the part that has
+A small pool of reader threads (PCA_INGEST_THREADS, default min(32, cores // 8) but at least 8; the decoders release the GIL) does the part that has
 nothing to do with the GPU -- file reads, PNG decode, label remapping -- up to `depth` batches ahead, delivered in
 order.  Everything that talks to HIP stays on the consumer's thread (measured: HIP calls from a second
 Python thread, even a lone event wait, cost the first one milliseconds per step): when batch k is handed out, batch k+1
@@ -134,11 +134,10 @@ def _upload_stack(self, kind, arrays):
     dev = torch.empty((k, ) + tuple(shape), dtype=tdtype, device=self.device)
     each = arrays[0].nbytes
     vp = C.c_void_p * k
-    rc = _lib.load().pca_host_stage_h2d(k, vp(*[a.ctypes.data for a in arrays]), vp(*[slot[0].data_ptr() + j * each for j in range(k)]),
-                                        vp(*[dev.data_ptr() + j * each for j in range(k)]), (C.c_int64 * k)(*([each] * k)),
-                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
-    if rc != 0:
-        raise RuntimeError(f'pca_host_stage_h2d failed ({rc})')
+    ctx = _lib.Context.get(self.device)
+    ctx.check(ctx.lib.pca_host_stage_h2d_pipelined(
+        ctx.h, k, vp(*[a.ctypes.data for a in arrays]), vp(*[slot[0].data_ptr() + j * each for j in range(k)]),
+        vp(*[dev.data_ptr() + j * each for j in range(k)]), (C.c_int64 * k)(*([each] * k)), ctx.stream()))
     ev = torch.cuda.Event()
     ev.record()
     ring[1][i] = (slot[0], ev)
@@ -146,6 +145,12 @@ def _upload_stack(self, kind, arrays):
 
 
 PinnedUploader.upload_stack = _upload_stack
+
+
+def default_ingest_threads():
+    """Reader / decoder threads of the prefetching loaders: file reads and PNG decodes release the GIL, a 376x1408 PNG takes
+    ~7 ms to decode, the device needs a frame every ~0.1 ms -- so as many as the host reasonably spares."""
+    return max(8, min(32, (os.cpu_count() or 8) // 8))
 
 
 def check_ring_lifetime(tensors, n_batches):
@@ -281,7 +286,7 @@ class PrefetchingLoader:
         n, bs = len(self.loader), self.loader.batch_size
         torch.cuda.set_device(self.device)
         # host-only work on the pool's threads: no HIP call there.  Batches are submitted in order and collected in order.
-        n_threads = int(os.environ.get('PCA_INGEST_THREADS', '8')) if os.environ.get('PCA_INGEST_THREAD', '1') != '0' else 0
+        n_threads = int(os.environ.get('PCA_INGEST_THREADS', default_ingest_threads())) if os.environ.get('PCA_INGEST_THREAD', '1') != '0' else 0
         pool = ThreadPoolExecutor(max_workers=n_threads) if n_threads > 0 else None
         pending = collections.deque()
         state = {'idx': 0}
@@ -404,9 +409,8 @@ class NuScenesPrefetchingLoader:
                 dev.append(dev_im.data_ptr() + k * each); nbytes.append(each)
         import ctypes as C                                   # pinned copies on the library's staging threads, H2D enqueued
         vp = C.c_void_p * len(src)
-        if lib.pca_host_stage_h2d(len(src), vp(*src), vp(*pin), vp(*dev), (C.c_int64 * len(src))(*nbytes),
-                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0:
-            raise RuntimeError('pca_host_stage_h2d failed')
+        ctx.check(lib.pca_host_stage_h2d_pipelined(ctx.h, len(src), vp(*src), vp(*pin), vp(*dev),
+                                                   (C.c_int64 * len(src))(*nbytes), ctx.stream()))
         if real:
             images = DeviceImages(obs['images'], dev_im)
         ev = torch.cuda.Event()
@@ -441,7 +445,7 @@ class NuScenesPrefetchingLoader:
         import torch
         n, bs = len(self.loader), self.loader.batch_size
         torch.cuda.set_device(self.device)
-        n_threads = int(os.environ.get('PCA_INGEST_THREADS', '8'))
+        n_threads = int(os.environ.get('PCA_INGEST_THREADS', default_ingest_threads()))
         pool = ThreadPoolExecutor(max_workers=max(n_threads, 1))
         pending = collections.deque()
         idx = 0

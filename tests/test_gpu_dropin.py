@@ -1304,3 +1304,64 @@ def test_device_errors_surface_through_the_kitti_dropin_without_check_status(tmp
     acc.integrate(_gt_obs(rng, 2000))
     assert acc.generate_bev(None, 1, gen_future=True)[0]['road_full'].shape == (32, 32)
     assert acc.store.ctx.peek_status() == 0
+
+
+def test_one_call_paths_equal_the_general_paths():
+    """integrate() / generate_bev() go through ONE library call each (pca_kitti_integrate, pca_kitti_generate_bev) where that
+    applies; `_fast = False` takes the general Python path.  Same stored rows, poses, evictions, planes and polylines -- with
+    host arrays, device tensors and a mix of both as inputs, through eviction and every state of the owed chain."""
+    import torch
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    from pca_amd import host_logic as hl
+    rng = np.random.default_rng(21)
+    P = np.array([[40., 0, 48, 0], [0, 40., 32, 0], [0, 0, 1, 0]]) @ np.array(
+        [[0., -1, 0, 0], [0, 0, -1, 0], [1, 0, 0, 0], [0, 0, 0, 1]])
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': P}
+    T = np.eye(4)
+    T[:3, :3] = hl.rotation_matrix_3d(-0.01)
+    T[:3, 3] = [-1.0, 0.02, 0.0]
+    for use_gt in (False, True):
+        accs = []
+        for fast in (True, False):
+            acc = Kitti360SemanticPointCloudAccumulator(9., calib, 1e3, 'fake.onnx', KITTI_FILTERS, SEM_IDXS, use_gt,
+                                                        dict(BEV_KITTI))
+            acc.pose_provider = lambda pc: T
+            acc._fast = fast
+            accs.append(acc)
+        frames = []
+        for k in range(16):
+            n = int(rng.integers(1, 3000))
+            pc = np.stack([rng.uniform(0.5, 20, n), rng.uniform(-9, 9, n), rng.uniform(-1, 2, n), rng.uniform(0, 1, n)],
+                          1).astype(np.float32)
+            img = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
+            sem_gt = rng.integers(0, 19, (n, 1)).astype(np.int64)
+            frames.append((img, pc, sem_gt))
+        for k, (img, pc, sem_gt) in enumerate(frames):
+            # host arrays, device tensors, and one of each
+            if k % 3 == 0:
+                obs = (img, pc, sem_gt)
+            elif k % 3 == 1:
+                obs = (torch.from_numpy(img).cuda(), torch.from_numpy(pc).cuda(), torch.from_numpy(sem_gt[:, -1].astype(np.uint8)).cuda())
+            else:
+                obs = (torch.from_numpy(img).cuda(), pc, sem_gt)
+            if not use_gt and isinstance(obs[0], torch.Tensor):
+                obs = (img, ) + obs[1:]                  # (the fake model of these tests reads host images)
+            removed = [acc.integrate([obs]) for acc in accs]
+            assert removed[0] == removed[1]
+            if k >= 3:
+                idx = len(accs[0].poses) - 2 - (k % 2)
+                a, b = (acc.generate_bev(idx, 1, gen_future=True)[0] for acc in accs)
+                assert set(a.keys()) == set(b.keys())
+                for key in a.keys():
+                    if key.startswith('trajs_'):
+                        assert len(a[key]) == len(b[key]) and all(np.array_equal(x, y) for x, y in zip(a[key], b[key])), key
+                    else:
+                        assert np.array_equal(a[key].view(np.uint16), b[key].view(np.uint16)), (k, key)
+                d = accs[0].generate_bev_device(idx)
+                assert np.array_equal(d['planes_f16'].cpu().numpy()[0].view(np.uint16), a['road_present'].view(np.uint16))
+                assert np.array_equal(d['trajs_full'][0], a['trajs_full'][0])
+        assert np.array_equal(np.concatenate(accs[0].sem_pcs), np.concatenate(accs[1].sem_pcs))
+        assert np.array_equal(np.array(accs[0].poses), np.array(accs[1].poses))
+        assert np.array_equal(np.array(accs[0].seg_dists), np.array(accs[1].seg_dists))
+        assert sum(1 for _ in accs[0].rgbs) == len(accs[0].poses)
+        accs[0].store.check_status()

@@ -10,6 +10,8 @@ if what == 'config4':
     out = bench.config4_pass()
 elif what == 'nuscenes_scene':
     out = bench.nuscenes_scene_pass(reps=3)
+elif what == 'nuscenes_scene_sweep':
+    out = bench.nuscenes_scene_pass(reps=3, order='sweep')
 elif what == 'ring':
     out = bench.ring_model_pass(50)
 elif what == 'k1':

@@ -69,10 +69,11 @@ def main():
     copy_stats(out, 'stats_k1_64', f'{tag}_kernel_stats_k1_batched_distinct64.csv')
     copy_stats(out, 'stats_k1_ring', f'{tag}_kernel_stats_k1_batched_ring64.csv')
     copy_stats(out, 'stats_nusc', f'{tag}_kernel_stats_nuscenes_scene.csv')
-    for suffix, name in (('head', ''), ('ring', '_ring'), ('config4', '_config4'), ('nusc', '_nusc')):
+    copy_stats(out, 'stats_nusc_ring', f'{tag}_kernel_stats_nuscenes_scene_sweep_order.csv')
+    for suffix, name in (('head', ''), ('ring', '_ring'), ('config4', '_config4'), ('nusc', '_nusc'), ('nusc_ring', '_nusc_ring')):
         json.dump({'note': note, 'kernels': traffic(out, suffix)}, open(os.path.join(out, f'{tag}_pmc_traffic{name}.json'), 'w'), indent=1)
     # batched K1
-    summ = {'note': note + '; physical_MB = (2 FETCH + WRITE) / 1000 per call; GBps_physical = physical bytes / kernel time'}
+    summ = {'note': note + '; FETCH_SIZE / WRITE_SIZE are KiB (x 1024 bytes) everywhere: physical_MB = (2 FETCH_KB + WRITE_KB) x 1024 / 1e6 per call, as bench.py:pmc_traffic computes it; GBps_physical = physical bytes / kernel time'}
     lines = []
     for pool, sub in ((8, 'stats_k1_8'), (64, 'stats_k1_64')):
         st, tr = stats(out, sub), traffic(out, f'k1_{pool}')
