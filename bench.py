@@ -49,7 +49,7 @@ MIN_TIMED_S = 0.25                        # ... and as many as it takes to have 
 MAX_REPEATS = 2000
 GATHER_CHUNK = 16                         # multi-GPU: BEV samples per asynchronous gather to rank 0
 HBM_PEAK_GBS = 8000.0                     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_TAG = 'r03'                       # profiles/<tag>_pmc_traffic*.json: rocprofv3 PMC passes of THESE kernels
+PROFILE_TAG = 'r04'                       # profiles/<tag>_pmc_traffic*.json: rocprofv3 PMC passes of THESE kernels
 KITTI360_LENGTHS = [11270, 14384, 730, 11440, 6610, 9578, 2960, 13855, 3540]   # run_kitti360_bev_gen.py:172-173, end - start
 
 CAM_TO_VELO = np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418],

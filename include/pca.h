@@ -367,12 +367,6 @@ int pca_kitti_generate_bev(pca_ctx *ctx, const pca_store *store, const int64_t *
  * ------------------------------------------------------------------------------------------------ */
 int pca_host_stage_h2d(int n, const void *const *src, void *const *pinned, void *const *dev, const int64_t *bytes,
                        void *stream);
-/* The same as a PIPELINE for large transfers (the six camera images of a NuScenes observation,
- * nuscenes_obs_dataloader.py:162-202: 26 MB per frame): 4 MB pieces, the pool fills piece c + 1 while piece c crosses PCIe,
- * pieces alternate between two copy streams of the context; `stream` waits for both before the call returns its work to
- * it.  Below PCA_H2D_PIPELINE_MIN bytes (default 8 MB) it is pca_host_stage_h2d. */
-int pca_host_stage_h2d_pipelined(pca_ctx *ctx, int n, const void *const *src, void *const *pinned, void *const *dev,
-                                 const int64_t *bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A device result on its way to the host (the BEV planes of a sample: sem_bev.py hands them back as host float16

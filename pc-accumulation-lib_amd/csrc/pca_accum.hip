@@ -782,7 +782,9 @@ int pca_nusc_sample_filter_transform_batch(pca_ctx *ctx, const pca_nusc_frame *f
     int64_t total = 0;
     for (int k = 0; k < n_frames; ++k) {
         const pca_nusc_frame &f = frames[k];
-        if (f.n < 0 || (f.n > 0 && (!f.pc || !f.cam_idx || !f.imgs || !f.sems)) || !f.T) { ctx->err = "k1n: bad frame"; return -1; }
+        // (the image stacks are required for EMPTY frames too: an empty frame still runs one tile, whose gathers read
+        // pixel 0 -- "always a legal address" -- of that frame's stacks)
+        if (f.n < 0 || (f.n > 0 && (!f.pc || !f.cam_idx)) || !f.imgs || !f.sems || !f.T) { ctx->err = "k1n: bad frame (points, camera indices, image and class stacks, T)"; return -1; }
         total += f.n > 0 ? (f.n + TILE_PTS - 1) / TILE_PTS : 1;
     }
     if (total > K1N_MAX_BATCH_TILES) { ctx->err = "k1n: batch too large (split it: at most 16384 tiles of 512 points)"; return -1; }

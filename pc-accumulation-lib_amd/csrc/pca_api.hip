@@ -173,11 +173,8 @@ void pca_ctx_destroy(pca_ctx *ctx)
     for (auto &e : ctx->d2h_done) if (e) (void)hipEventDestroy(e);
     if (ctx->d2h_go) (void)hipEventDestroy(ctx->d2h_go);
     if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
-    for (int j = 0; j < 2; ++j) {
-        if (ctx->h2d_done[j]) (void)hipEventDestroy(ctx->h2d_done[j]);
-        if (ctx->h2d_stream[j]) { (void)hipStreamSynchronize(ctx->h2d_stream[j]); (void)hipStreamDestroy(ctx->h2d_stream[j]); }
-    }
-    if (ctx->h2d_go) (void)hipEventDestroy(ctx->h2d_go);
+    if (ctx->h2d_done[0]) (void)hipEventDestroy(ctx->h2d_done[0]);
+    if (ctx->h2d_stream[0]) { (void)hipStreamSynchronize(ctx->h2d_stream[0]); (void)hipStreamDestroy(ctx->h2d_stream[0]); }
     if (ctx->k1n_ws) (void)hipFree(ctx->k1n_ws);
     if (ctx->k1n_desc_dev) (void)hipFree(ctx->k1n_desc_dev);
     if (ctx->k1n_pin) (void)hipHostFree(ctx->k1n_pin);

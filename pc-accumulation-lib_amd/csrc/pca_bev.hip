@@ -20,6 +20,7 @@
 // 'full' = present (+) future is formed per cell (counts add, min of mins, median of the union).
 #include "pca_bev_common.h"
 #include <cstdlib>
+#include <mutex>
 
 #define KEY_INVALID 0xffffffffu
 #define TS 8                      // tile side [cells]
@@ -1666,6 +1667,15 @@ int pca_bev_generate_many(pca_ctx *ctx, const pca_store *store, const double *in
     const size_t lds = (size_t)T * 8;
     // a few resident workgroups per sample drain whatever heavy tiles there are (any number of them does)
     const int heavy_grid = T < 8 ? T : 8;
+    // The argument blocks live in ONE constant array per device (g_bev_many): a call on another stream or from another
+    // context of this device must not overwrite it while this call's kernels may still read it.  Calls take turns on the
+    // host (mutex) and on the device (every call first waits for the event the previous one recorded behind its kernels).
+    static std::mutex many_mutex;
+    static hipEvent_t many_last[64] = {};
+    std::lock_guard<std::mutex> many_lock(many_mutex);
+    hipEvent_t &last = many_last[ctx->device & 63];
+    if (last) PCA_CHECK(ctx, hipStreamWaitEvent(s, last, 0));
+    else PCA_CHECK(ctx, hipEventCreateWithFlags(&last, hipEventDisableTiming));
     if (ctx->profiling) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
     for (int k0 = 0; k0 < n_jobs; k0 += PCA_BEV_MANY_MAX) {
         const int nk = n_jobs - k0 < PCA_BEV_MANY_MAX ? n_jobs - k0 : PCA_BEV_MANY_MAX;
@@ -1682,6 +1692,7 @@ int pca_bev_generate_many(pca_ctx *ctx, const pca_store *store, const double *in
     }
     PCA_CHECK(ctx, hipEventRecord(ctx->bevm_ev, s));
     ctx->bevm_busy = true;
+    PCA_CHECK(ctx, hipEventRecord(last, s));
     if (ctx->profiling) pca_prof_end(ctx, s);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;

@@ -54,10 +54,9 @@ struct pca_ctx {
     hipEvent_t d2h_go = nullptr;
     hipEvent_t d2h_done[64] = {};
     uint32_t d2h_next = 0;
-    // pca_host_stage_h2d_pipelined: two copy streams for large uploads, the event that lets them start, their ends
-    hipStream_t h2d_stream[2] = {nullptr, nullptr};
-    hipEvent_t h2d_go = nullptr;
-    hipEvent_t h2d_done[2] = {nullptr, nullptr};
+    // pca_kitti_integrate: the copy stream an observation's upload leaves on, and the event K1 waits for
+    hipStream_t h2d_stream[1] = {nullptr};
+    hipEvent_t h2d_done[1] = {nullptr};
     // pca_kitti_integrate: host observations on their way to the device -- a ring of pinned + device blocks, each free
     // again when the K1 launch that read it has finished
     struct Stage { void *pin = nullptr; void *dev = nullptr; int64_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };

@@ -492,65 +492,14 @@ extern "C" int pca_host_stage_h2d(int n, const void *const *src, void *const *pi
     for (int k = 0; k < n; ++k)
         if (bytes[k] < 0 || (bytes[k] > 0 && (!src[k] || !pinned[k] || !dev[k]))) return -1;
     pca_stage_copy(src, pinned, bytes, n);
-    for (int k = 0; k < n; ++k)
-        if (bytes[k] > 0 && hipMemcpyAsync(dev[k], pinned[k], (size_t)bytes[k], hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
-            return -2;
-    return 0;
-}
-
-// The same for LARGE transfers (the six camera images of a NuScenes observation: 26 MB per frame, 1 GB per scene), as a
-// pipeline: the arrays are cut into 4 MB pieces; while piece c is on its way over PCIe the pool already fills the pinned
-// bytes of piece c + 1, and the pieces alternate between two copy streams of the context (two SDMA engines instead of one).
-// `stream` waits for both at the end, so for the caller the call looks like pca_host_stage_h2d: everything enqueued on
-// `stream` afterwards sees the data; the pinned blocks may be reused once `stream` has passed this point.
-// Below PCA_H2D_PIPELINE_MIN bytes (default 8 MB) it IS pca_host_stage_h2d (the two event hops cost more than they hide).
-extern "C" int pca_host_stage_h2d_pipelined(pca_ctx *ctx, int n, const void *const *src, void *const *pinned, void *const *dev,
-                                            const int64_t *bytes, void *stream)
-{
-    if (!ctx) return -1;
-    if (n < 0 || (n > 0 && (!src || !pinned || !dev || !bytes))) { ctx->err = "stage_h2d_pipelined: bad arguments"; return -1; }
-    int64_t total = 0;
-    for (int k = 0; k < n; ++k) {
-        if (bytes[k] < 0 || (bytes[k] > 0 && (!src[k] || !pinned[k] || !dev[k]))) { ctx->err = "stage_h2d_pipelined: bad arguments"; return -1; }
-        total += bytes[k];
-    }
-    static int64_t min_bytes = -1;
-    if (min_bytes < 0) { const char *e = getenv("PCA_H2D_PIPELINE_MIN"); min_bytes = e ? atoll(e) : (8ll << 20); }
-    if (total < min_bytes) {
-        const int rc = pca_host_stage_h2d(n, src, pinned, dev, bytes, stream);
-        if (rc != 0) ctx->err = "stage_h2d: a copy could not be enqueued";
-        return rc;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    PCA_CHECK(ctx, hipSetDevice(ctx->device));
-    static int n_streams = -1;                              // PCA_H2D_STREAMS: 0 = the caller's stream, 1 or 2 copy streams
-    if (n_streams < 0) { const char *e = getenv("PCA_H2D_STREAMS"); n_streams = e ? atoi(e) : 1; if (n_streams < 0 || n_streams > 2) n_streams = 1; }
-    hipStream_t cs[2] = {s, s};
-    for (int j = 0; j < n_streams; ++j) {
-        if (!ctx->h2d_stream[j]) PCA_CHECK(ctx, hipStreamCreateWithFlags(&ctx->h2d_stream[j], hipStreamNonBlocking));
-        if (!ctx->h2d_done[j]) PCA_CHECK(ctx, hipEventCreateWithFlags(&ctx->h2d_done[j], hipEventDisableTiming));
-        cs[j] = ctx->h2d_stream[j];
-    }
-    if (n_streams == 1) cs[1] = cs[0];
-    if (n_streams > 0) {
-        if (!ctx->h2d_go) PCA_CHECK(ctx, hipEventCreateWithFlags(&ctx->h2d_go, hipEventDisableTiming));
-        // the copies may start once everything enqueued on `stream` so far is done (whoever still reads the device buffers)
-        PCA_CHECK(ctx, hipEventRecord(ctx->h2d_go, s));
-        for (int j = 0; j < n_streams; ++j) PCA_CHECK(ctx, hipStreamWaitEvent(ctx->h2d_stream[j], ctx->h2d_go, 0));
-    }
-    constexpr int64_t PIECE = 4ll << 20;
-    int c = 0;
-    for (int k = 0; k < n; ++k)
-        for (int64_t o = 0; o < bytes[k]; o += PIECE, ++c) {
-            const int64_t len = bytes[k] - o < PIECE ? bytes[k] - o : PIECE;
-            const void *ps = (const char *)src[k] + o;
-            void *pp = (char *)pinned[k] + o;
-            pca_stage_copy(&ps, &pp, &len, 1);
-            PCA_CHECK(ctx, hipMemcpyAsync((char *)dev[k] + o, pp, (size_t)len, hipMemcpyHostToDevice, cs[c & 1]));
-        }
-    for (int j = 0; j < n_streams; ++j) {
-        PCA_CHECK(ctx, hipEventRecord(ctx->h2d_done[j], ctx->h2d_stream[j]));
-        PCA_CHECK(ctx, hipStreamWaitEvent(s, ctx->h2d_done[j], 0));
+    // arrays that lie back to back in BOTH the pinned block and the device buffer (the six camera images of a NuScenes
+    // observation) leave as ONE copy: a copy command has a fixed cost of tens of microseconds on this stack
+    for (int k = 0; k < n;) {
+        int64_t len = bytes[k];
+        int m = k + 1;
+        while (m < n && (const char *)pinned[m] == (const char *)pinned[k] + len && (const char *)dev[m] == (const char *)dev[k] + len) len += bytes[m++];
+        if (len > 0 && hipMemcpyAsync(dev[k], pinned[k], (size_t)len, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return -2;
+        k = m;
     }
     return 0;
 }

@@ -24,7 +24,7 @@ EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error',
            'pca_host_gemv4_probe', 'pca_host_gemv4_mode', 'pca_host_incr_probe', 'pca_host_incr_blocks', 'pca_host_track_create', 'pca_host_track_destroy', 'pca_host_track_len', 'pca_host_track_n_segments',
            'pca_host_track_poses', 'pca_host_track_segments', 'pca_host_track_set', 'pca_host_track_transform',
            'pca_host_track_append', 'pca_host_track_push_segment', 'pca_host_track_incr', 'pca_host_track_evict_beyond',
-           'pca_host_track_step', 'pca_host_track_trigger', 'pca_host_stage_h2d', 'pca_host_stage_h2d_pipelined', 'pca_host_d2h_async', 'pca_host_d2h_wait',
+           'pca_host_track_step', 'pca_host_track_trigger', 'pca_host_stage_h2d', 'pca_host_d2h_async', 'pca_host_d2h_wait',
            'pca_kitti_integrate', 'pca_kitti_generate_bev',
            'pca_profile_enable', 'pca_profile_read')
 
@@ -182,7 +182,6 @@ def load():
     lib.pca_host_track_trigger.argtypes = [vp, C.c_double, i64, C.c_double]
     lib.pca_host_track_trigger.restype = i64
     lib.pca_host_stage_h2d.argtypes = [i32, vp, vp, vp, vp, vp]
-    lib.pca_host_stage_h2d_pipelined.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     lib.pca_host_d2h_async.argtypes = [vp, vp, vp, i64, vp]
     lib.pca_host_d2h_wait.argtypes = [vp, i32]
     lib.pca_kitti_integrate.argtypes = [vp, C.POINTER(PcaKittiObs), C.POINTER(C.c_double), i32, i32, C.POINTER(C.c_uint64),

@@ -134,10 +134,11 @@ def _upload_stack(self, kind, arrays):
     dev = torch.empty((k, ) + tuple(shape), dtype=tdtype, device=self.device)
     each = arrays[0].nbytes
     vp = C.c_void_p * k
-    ctx = _lib.Context.get(self.device)
-    ctx.check(ctx.lib.pca_host_stage_h2d_pipelined(
-        ctx.h, k, vp(*[a.ctypes.data for a in arrays]), vp(*[slot[0].data_ptr() + j * each for j in range(k)]),
-        vp(*[dev.data_ptr() + j * each for j in range(k)]), (C.c_int64 * k)(*([each] * k)), ctx.stream()))
+    rc = _lib.load().pca_host_stage_h2d(k, vp(*[a.ctypes.data for a in arrays]), vp(*[slot[0].data_ptr() + j * each for j in range(k)]),
+                                        vp(*[dev.data_ptr() + j * each for j in range(k)]), (C.c_int64 * k)(*([each] * k)),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f'pca_host_stage_h2d failed ({rc})')
     ev = torch.cuda.Event()
     ev.record()
     ring[1][i] = (slot[0], ev)
@@ -363,20 +364,32 @@ class NuScenesPrefetchingLoader:
         self.depth = depth
         self.device = torch.device('cuda', self.ctx.device_index)
         bs = max(int(getattr(loader, 'batch_size', 1)), 1)
-        self._ring = [dict(pin={}, dev={}, copied=None) for _ in range(self.RING * bs)]
+        # device buffers: one slot per batch element of the ring (what the consumer may still be using); the PINNED staging
+        # blocks are a small ring of their own (depth + 1 uploads in flight at most: a 26 MB page-locked block per device slot
+        # was 1.8 GB of pinned memory per loader), and scratch that only ever lives on the device has no pinned twin
+        self._ring = [dict(dev={}) for _ in range(self.RING * bs)]
+        self._pins = [dict(pin={}, copied=None) for _ in range((max(int(depth), 1) + 1) * bs)]
         self._next = 0
 
     def __len__(self):
         return len(self.loader)
 
-    def _buffers(self, slot, name, shape, dtype):
+    def _dev_buffer(self, slot, name, shape, dtype):
+        """device buffer `name` of a ring slot, grown on demand and reused from then on"""
         import torch
         n = int(np.prod(shape))
-        pin, dev = slot['pin'].get(name), slot['dev'].get(name)
-        if pin is None or pin.numel() < n or pin.dtype != dtype:
-            pin = slot['pin'][name] = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+        dev = slot['dev'].get(name)
+        if dev is None or dev.numel() < n or dev.dtype != dtype:
             dev = slot['dev'][name] = torch.empty(max(n, 1), dtype=dtype, device=self.device)
-        return pin[:n].view(*shape), dev[:n].view(*shape)
+        return dev[:n].view(*shape)
+
+    def _pin_buffer(self, pslot, name, shape, dtype):
+        import torch
+        n = int(np.prod(shape))
+        pin = pslot['pin'].get(name)
+        if pin is None or pin.numel() < n or pin.dtype != dtype:
+            pin = pslot['pin'][name] = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+        return pin[:n].view(*shape)
 
     def _host_part(self, idx):
         obs, geom = self.loader.read_host(idx)
@@ -390,18 +403,20 @@ class NuScenesPrefetchingLoader:
         from . import _lib
         obs, geom, imgs = item
         slot = self._ring[self._next % len(self._ring)]
+        pslot = self._pins[self._next % len(self._pins)]
         self._next += 1
-        if slot['copied'] is not None:
-            slot['copied'].synchronize()                   # the copies out of this slot's pinned blocks, RING batches ago
+        if pslot['copied'] is not None:
+            pslot['copied'].synchronize()                  # the copies out of this pinned block, a few uploads ago
         lib, ctx = self.ctx.lib, self.ctx
         pc = np.ascontiguousarray(geom['pc'], dtype=np.float64)
         n, ncam = pc.shape[0], len(geom['cams_K'])
-        pin_pc, dev_pc = self._buffers(slot, 'pc', pc.shape, torch.float64)
+        pin_pc, dev_pc = self._pin_buffer(pslot, 'pc', pc.shape, torch.float64), self._dev_buffer(slot, 'pc', pc.shape, torch.float64)
         images = obs['images']
         real = all(isinstance(im, np.ndarray) and im.ndim == 3 for im in imgs) and len({im.shape for im in imgs}) == 1
         src, pin, dev, nbytes = [pc.ctypes.data], [pin_pc.data_ptr()], [dev_pc.data_ptr()], [pc.nbytes]
         if real:
-            pin_im, dev_im = self._buffers(slot, 'img', (len(imgs), ) + imgs[0].shape, torch.uint8)
+            ishape = (len(imgs), ) + imgs[0].shape
+            pin_im, dev_im = self._pin_buffer(pslot, 'img', ishape, torch.uint8), self._dev_buffer(slot, 'img', ishape, torch.uint8)
             imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in imgs]
             each = imgs[0].nbytes
             for k, im in enumerate(imgs):
@@ -409,19 +424,20 @@ class NuScenesPrefetchingLoader:
                 dev.append(dev_im.data_ptr() + k * each); nbytes.append(each)
         import ctypes as C                                   # pinned copies on the library's staging threads, H2D enqueued
         vp = C.c_void_p * len(src)
-        ctx.check(lib.pca_host_stage_h2d_pipelined(ctx.h, len(src), vp(*src), vp(*pin), vp(*dev),
-                                                   (C.c_int64 * len(src))(*nbytes), ctx.stream()))
+        if lib.pca_host_stage_h2d(len(src), vp(*src), vp(*pin), vp(*dev), (C.c_int64 * len(src))(*nbytes),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0:
+            raise RuntimeError('pca_host_stage_h2d failed')
         if real:
             images = DeviceImages(obs['images'], dev_im)
         ev = torch.cuda.Event()
         ev.record()
-        slot['copied'] = ev
+        pslot['copied'] = ev
         # projection (K0n) on the device, rows [x, y, z (ego), intensity, u, v, instance] assembled there
         xyz = dev_pc[:, :3].contiguous()
-        _, ego = self._buffers(slot, 'ego', (n, 3), torch.float64)
-        _, uv = self._buffers(slot, 'uv', (n, 2), torch.float64)
-        _, cam = self._buffers(slot, 'cam', (n, ), torch.int64)
-        _, rows = self._buffers(slot, 'rows', (n, 7), torch.float64)
+        ego = self._dev_buffer(slot, 'ego', (n, 3), torch.float64)
+        uv = self._dev_buffer(slot, 'uv', (n, 2), torch.float64)
+        cam = self._dev_buffer(slot, 'cam', (n, ), torch.int64)
+        rows = self._dev_buffer(slot, 'rows', (n, 7), torch.float64)
         cam_from_glob = np.stack([np.linalg.inv(T) for T in geom['cams_glob_from_self']])
         ctx.check(lib.pca_nusc_project_cams(
             ctx.h, xyz.data_ptr(), n, _lib.f64_array(geom['ego_from_lidar'], 16), _lib.f64_array(geom['glob_from_ego'], 16),

@@ -51,14 +51,20 @@ def check_bev(bev, g, prefix='bev_'):
                                for s in ('present', 'future', 'full')} | ({'gt_lanes'} & set(bev.keys()))
 
 
-def test_kitti_accumulator_sequence(golden, capsys):
+@pytest.mark.parametrize('track', ['default', 'numpy'])
+def test_kitti_accumulator_sequence(golden, capsys, track):
+    """track='numpy': the fallback pose track (the reference's numpy expressions themselves, what the accumulator uses when a
+    probe of the C track fails on a machine) through the same golden sequence, on the GPU box."""
     from PIL import Image
 
     from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    from pca_amd import host_logic as hl
     g = golden('kitti_accum')
     calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': g['P']}
     acc = Kitti360SemanticPointCloudAccumulator(float(g['horizon']), calib, 1e3, 'fake.onnx', KITTI_FILTERS, SEM_IDXS,
                                                 False, dict(BEV_KITTI))
+    if track == 'numpy':
+        acc._track = hl.NumpyPoseTrack()
     queue = list(g['Ts'])
     acc.pose_provider = lambda pc: queue.pop(0)
     removed = []
