@@ -33,8 +33,11 @@ int pca_kitti_integrate(pca_ctx *ctx, const pca_kitti_obs *obs, const double P[1
     const void *dev[4] = {in[0], in[1], in[2], in[3]};
     // ---- host arrays: one pinned block, one device block, one copy ----
     int64_t off[4] = {0, 0, 0, 0}, total = 0;
-    for (int k = 0; k < 4; ++k)
-        if (in[k] && ((obs->host_mask >> k) & 1u) && size[k] > 0) { off[k] = total; total += up256(size[k]); }
+    for (int k = 0; k < 4; ++k) {
+        if (!(in[k] && ((obs->host_mask >> k) & 1u))) continue;
+        if (size[k] > 0) { off[k] = total; total += up256(size[k]); }
+        else dev[k] = nullptr;                             // an empty host array: nothing to stage, nothing the device may touch
+    }
     pca_ctx::Stage *slot_st = nullptr;
     if (total > 0) {
         pca_ctx::Stage &st = ctx->stage[ctx->stage_next++ % PCA_STAGE_DEPTH];

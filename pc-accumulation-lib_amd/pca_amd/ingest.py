@@ -6,7 +6,7 @@ resident in HBM (the accumulators accept cuda tensors in place of numpy / PIL in
     for observations in loader:
         acc.integrate(observations)
 
-A small pool of reader threads (PCA_INGEST_THREADS, default min(32, cores // 8) but at least 8; the decoders release the GIL) does the part that has
+A small pool of reader threads (PCA_INGEST_THREADS, default 4: measured, see default_ingest_threads; the decoders release the GIL) does the part that has
 nothing to do with the GPU -- file reads, PNG decode, label remapping -- up to `depth` batches ahead, delivered in
 order.  Everything that talks to HIP stays on the consumer's thread (measured: HIP calls from a second
 Python thread, even a lone event wait, cost the first one milliseconds per step): when batch k is handed out, batch k+1
@@ -149,9 +149,11 @@ PinnedUploader.upload_stack = _upload_stack
 
 
 def default_ingest_threads():
-    """Reader / decoder threads of the prefetching loaders: file reads and PNG decodes release the GIL, a 376x1408 PNG takes
-    ~7 ms to decode, the device needs a frame every ~0.1 ms -- so as many as the host reasonably spares."""
-    return max(8, min(32, (os.cpu_count() or 8) // 8))
+    """Reader / decoder threads of the prefetching loaders.  Measured on a 256-core box (tools/experiments/loader_step.py,
+    full-size synthetic KITTI-360 tree, ms per frame with / without images): 1 thread 6.4 / 2.1, 4 threads 2.2 / 0.53,
+    8 threads 2.3 / 1.2, 16 threads 2.8 / 2.0, 32 threads 5.7 / 1.9 -- the decoders release the GIL, the label remap and the
+    array bookkeeping around them do not, and beyond a handful of threads they queue for it.  Four."""
+    return 4
 
 
 def check_ring_lifetime(tensors, n_batches):
@@ -296,7 +298,8 @@ class PrefetchingLoader:
             return [self._read(i0 + k) for k in range(bs)]
 
         def stage():
-            while state['idx'] + bs <= n and len(pending) < max(self.depth, 1):
+            # (as many batches in flight as reader threads can work on: a depth of 4 kept 28 of 32 threads idle)
+            while state['idx'] + bs <= n and len(pending) < max(self.depth, n_threads + n_threads // 2, 1):
                 i0 = state['idx']
                 state['idx'] += bs
                 pending.append(pool.submit(read_batch, i0) if pool is not None else i0)

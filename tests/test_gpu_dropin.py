@@ -1371,3 +1371,37 @@ def test_one_call_paths_equal_the_general_paths():
         assert np.array_equal(np.array(accs[0].seg_dists), np.array(accs[1].seg_dists))
         assert sum(1 for _ in accs[0].rgbs) == len(accs[0].poses)
         accs[0].store.check_status()
+
+
+def test_one_call_integrate_edge_cases():
+    """pca_kitti_integrate with the inputs the reference's loader can produce at the edges: an empty sweep, a single point, a
+    one-pixel image (smaller than the 4-byte colour gather), non-contiguous / wrongly typed host arrays (converted like the
+    general path converts them), and shapes that do not fit together (refused before anything changes)."""
+    import torch
+    rng = np.random.default_rng(2)
+    accs = []
+    for fast in (True, False):
+        acc = _kitti_gt_accumulator()
+        acc.use_gt_sem = False
+        acc.semseg_model = FakeSemSeg()
+        acc._fast = fast
+        accs.append(acc)
+    big = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
+    cases = [
+        (big, np.zeros((0, 4), np.float32)),                                            # empty sweep
+        (big, np.array([[5.0, 0.1, 0.2, 0.5]], np.float32)),                            # one point
+        (np.full((1, 1, 3), 7, np.uint8), np.array([[5.0, 0.0, 0.0, 0.5]] * 3, np.float32)),   # one-pixel image
+        (big[:, ::-1], np.asfortranarray(rng.uniform(1, 9, (500, 4)).astype(np.float32))),      # strided / F-ordered inputs
+        (big.astype(np.int64), rng.uniform(1, 9, (300, 4))),                            # int64 image, float64 points
+    ]
+    for img, pc in cases:
+        out = [acc.integrate([(img, pc, None)]) for acc in accs]
+        assert out[0] == out[1]
+    a, b = (np.concatenate(acc.sem_pcs) for acc in accs)
+    assert a.shape[0] > 100 and np.array_equal(a, b)
+    assert np.array_equal(np.array(accs[0].poses), np.array(accs[1].poses))
+    n_before = accs[0].store.n_frames
+    with pytest.raises(ValueError):
+        accs[0].integrate([(big, rng.uniform(1, 9, (10, 3)).astype(np.float32), None)])          # (N,3) points
+    assert accs[0].store.n_frames == n_before and len(accs[0].poses) == n_before
+    accs[0].store.check_status()

@@ -190,7 +190,7 @@ def test_icp_search_cap_against_the_uncapped_model(step, tol):
     1e-5 -- once the first iterations have pulled the sweeps together no nearest neighbour is farther than the cap; at 2 and
     3 m they differ by 0.37 mm and 2.2 mm (measured): the points at the sweeps' non-overlapping ends
     keep partners beyond 4 m at convergence, which pull on the uncapped optimum and are left out of the capped one.  Both stay
-    within centimetres of the true motion.  (Dense scene: every 30-neighbourhood lies inside the normals' search cap.)"""
+    within centimetres of the true motion (7 cm at the 3 m step).  (Dense scene: every 30-neighbourhood lies inside the normals' search cap.)"""
     from pca_amd.icp import GpuIcp
     prev = sweep(0.0, 0.0, 0.0, 11, n_beams=64, n_az=700, max_range=18.0)
     new = sweep(step, 0.04, 0.01, 12, n_beams=64, n_az=700, max_range=18.0)
@@ -199,4 +199,4 @@ def test_icp_search_cap_against_the_uncapped_model(step, tol):
     assert np.linalg.norm(res.transformation[:3, 3] - T_ref[:3, 3]) < tol, (res.transformation, T_ref)
     assert rot_err_deg(res.transformation[:3, :3] @ T_ref[:3, :3].T) < 60 * tol
     T_true = np.linalg.inv(pose_T(step, 0.04, 0.01))
-    assert np.linalg.norm(res.transformation[:3, 3] - T_true[:3, 3]) < 0.05
+    assert np.linalg.norm(res.transformation[:3, 3] - T_true[:3, 3]) < 0.02 + 0.03 * step      # (7 cm at 3 m, either model)

@@ -53,6 +53,8 @@ for images in ('1', '0'):
     os.environ['PCA_INGEST_THREAD'] = '0'
     run(PrefetchingLoader(mk(), depth=8), 'Prefetching, images=%s, inline reads' % images)
     os.environ['PCA_INGEST_THREAD'] = '1'
-    for th in (1, 4, 8):
+    for th, depth in ((1, 8), (4, 8), (8, 8), (16, 24), (32, 48)):
         os.environ['PCA_INGEST_THREADS'] = str(th)
-        run(PrefetchingLoader(mk(), depth=8), 'Prefetching, images=%s, %d reader threads' % (images, th))
+        run(PrefetchingLoader(mk(), depth=depth), 'Prefetching, images=%s, %d reader threads, depth %d' % (images, th, depth))
+    os.environ.pop('PCA_INGEST_THREADS', None)
+    run(PrefetchingLoader(mk(), depth=48), 'Prefetching, images=%s, default threads, depth 48' % images)
