@@ -9,6 +9,8 @@ from oracle import oracle as orc
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(lo, hi):
+    if seed % 200 == 0:
+        print('seed', seed, flush=True)                    # (a long silent run looks hung to the GPU runner)
     try:
         t.test_bev_randomised_configs_match_oracle.__wrapped__(T, orc, seed) if hasattr(t.test_bev_randomised_configs_match_oracle, '__wrapped__') else t.test_bev_randomised_configs_match_oracle(T, orc, seed)
     except AssertionError as e:
