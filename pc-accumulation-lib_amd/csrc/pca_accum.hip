@@ -797,7 +797,7 @@ int pca_nusc_sample_filter_transform_batch(pca_ctx *ctx, const pca_nusc_frame *f
     if (up_bytes > ctx->k1n_pin_cap) {
         if (ctx->k1n_pin) PCA_CHECK(ctx, hipHostFree(ctx->k1n_pin));
         ctx->k1n_pin = nullptr; ctx->k1n_pin_cap = 0;
-        PCA_CHECK(ctx, hipHostMalloc(&ctx->k1n_pin, (size_t)(2 * up_bytes)));
+        PCA_CHECK(ctx, hipHostMalloc(&ctx->k1n_pin, (size_t)(2 * up_bytes), hipHostMallocMapped));
         ctx->k1n_pin_cap = 2 * up_bytes;
     }
     if (!ctx->k1n_ev) PCA_CHECK(ctx, hipEventCreateWithFlags(&ctx->k1n_ev, hipEventDisableTiming));
@@ -819,7 +819,12 @@ int pca_nusc_sample_filter_transform_batch(pca_ctx *ctx, const pca_nusc_frame *f
     const int64_t need = 3 * slots * 8 + 3 * slots * 4 + 2 * ((total * 4 + 255) & ~255ll) + 1024;
     if (accum_grow(ctx, &ctx->k1n_ws, &ctx->k1n_ws_cap, need, s)) return -1;
     if (ctx->profiling == 1) pca_prof_begin(ctx, PCA_K_NUSC, s);
-    PCA_CHECK(ctx, hipMemcpyAsync(ctx->k1n_desc_dev, ctx->k1n_pin, (size_t)up_bytes, hipMemcpyHostToDevice, s));
+    // (descriptors + tile table, ~20 KB: fetched by a kernel from the mapped host block -- a copy command of this size was
+    // 13-17 us of a 60-95 us call; PCA_SMALL_COPY=1 restores it for A/B)
+    static int small_copy = -1;
+    if (small_copy < 0) { const char *e = getenv("PCA_SMALL_COPY"); small_copy = e ? atoi(e) : 0; }
+    if (small_copy) PCA_CHECK(ctx, hipMemcpyAsync(ctx->k1n_desc_dev, ctx->k1n_pin, (size_t)up_bytes, hipMemcpyHostToDevice, s));
+    else if (pca_fetch_block(ctx, ctx->k1n_pin, ctx->k1n_desc_dev, up_bytes, s)) return -1;
     PCA_CHECK(ctx, hipEventRecord(ctx->k1n_ev, s));
     ctx->k1n_busy = true;
     K1nBatchArgs a;

@@ -62,7 +62,7 @@
 struct __attribute__((aligned(16))) RecF { double z; uint32_t iw; uint32_t cw; };                     // 16 B
 struct RecD { double z; double inten; uint32_t c; uint32_t fk; };                                      // 24 B (f64 intensities)
 
-struct BevArgs {
+struct alignas(16) BevArgs {                             // (16: pca_fetch_block moves it in 16-byte words)
     pca_store st;
     const double *intensity64;
     const int64_t *frame_off;
@@ -1648,7 +1648,7 @@ int pca_bev_generate_many(pca_ctx *ctx, const pca_store *store, const double *in
     if (up_bytes > ctx->bevm_cap) {
         if (ctx->bevm_pin) PCA_CHECK(ctx, hipHostFree(ctx->bevm_pin));
         ctx->bevm_pin = nullptr; ctx->bevm_cap = 0;
-        PCA_CHECK(ctx, hipHostMalloc(&ctx->bevm_pin, (size_t)(2 * up_bytes)));
+        PCA_CHECK(ctx, hipHostMalloc(&ctx->bevm_pin, (size_t)(2 * up_bytes), hipHostMallocMapped));
         ctx->bevm_cap = 2 * up_bytes;
     }
     if (!ctx->bevm_ev) PCA_CHECK(ctx, hipEventCreateWithFlags(&ctx->bevm_ev, hipEventDisableTiming));
@@ -1679,7 +1679,14 @@ int pca_bev_generate_many(pca_ctx *ctx, const pca_store *store, const double *in
     if (ctx->profiling) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
     for (int k0 = 0; k0 < n_jobs; k0 += PCA_BEV_MANY_MAX) {
         const int nk = n_jobs - k0 < PCA_BEV_MANY_MAX ? n_jobs - k0 : PCA_BEV_MANY_MAX;
-        PCA_CHECK(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_bev_many), ha + k0, sizeof(BevArgs) * (size_t)nk, 0, hipMemcpyHostToDevice, s));
+        // (the argument blocks, 1.3 KB per sample: fetched by a kernel from the mapped host block instead of a copy command,
+        // see pca_fetch_block; PCA_SMALL_COPY=1 restores the copy for A/B)
+        static int small_copy = -1;
+        static void *many_dev[64] = {};
+        if (small_copy < 0) { const char *e = getenv("PCA_SMALL_COPY"); small_copy = e ? atoi(e) : 0; }
+        if (!many_dev[ctx->device & 63]) PCA_CHECK(ctx, hipGetSymbolAddress(&many_dev[ctx->device & 63], HIP_SYMBOL(g_bev_many)));
+        if (small_copy) PCA_CHECK(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_bev_many), ha + k0, sizeof(BevArgs) * (size_t)nk, 0, hipMemcpyHostToDevice, s));
+        else if (pca_fetch_block(ctx, ha + k0, many_dev[ctx->device & 63], (int64_t)sizeof(BevArgs) * nk, s)) return -1;
         if (intensity64) {
             hipLaunchKernelGGL(bev_tile_bin_many<true>, dim3(G, nk), dim3(AB_THREADS), lds, s);
             hipLaunchKernelGGL(bev_tile_cells_many<true>, dim3(T, nk), dim3(C_THREADS), 0, s);
