@@ -824,7 +824,7 @@ int pca_nusc_sample_filter_transform_batch(pca_ctx *ctx, const pca_nusc_frame *f
     static int small_copy = -1;
     if (small_copy < 0) { const char *e = getenv("PCA_SMALL_COPY"); small_copy = e ? atoi(e) : 0; }
     if (small_copy) PCA_CHECK(ctx, hipMemcpyAsync(ctx->k1n_desc_dev, ctx->k1n_pin, (size_t)up_bytes, hipMemcpyHostToDevice, s));
-    else if (pca_fetch_block(ctx, ctx->k1n_pin, ctx->k1n_desc_dev, up_bytes, s)) return -1;
+    else if (pca_fetch_block(ctx, ctx->k1n_pin, 0, ctx->k1n_desc_dev, up_bytes, s)) return -1;
     PCA_CHECK(ctx, hipEventRecord(ctx->k1n_ev, s));
     ctx->k1n_busy = true;
     K1nBatchArgs a;

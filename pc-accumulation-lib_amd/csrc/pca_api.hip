@@ -6,11 +6,12 @@ __global__ __launch_bounds__(256) void pca_fetch_block_kernel(const uint4 *src, 
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
 }
 
-int pca_fetch_block(pca_ctx *ctx, const void *mapped_host, void *dev, int64_t bytes, hipStream_t s)
+int pca_fetch_block(pca_ctx *ctx, const void *mapped_host, int64_t offset, void *dev, int64_t bytes, hipStream_t s)
 {
     if (bytes <= 0) return 0;
     void *src = nullptr;
     PCA_CHECK(ctx, hipHostGetDevicePointer(&src, const_cast<void *>(mapped_host), 0));
+    src = reinterpret_cast<char *>(src) + offset;
     const int64_t n16 = (bytes + 15) / 16;
     const int grid = (int)((n16 + 255) / 256 < 64 ? (n16 + 255) / 256 : 64);
     hipLaunchKernelGGL(pca_fetch_block_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint4 *>(src),

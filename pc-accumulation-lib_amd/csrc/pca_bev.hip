@@ -1686,7 +1686,7 @@ int pca_bev_generate_many(pca_ctx *ctx, const pca_store *store, const double *in
         if (small_copy < 0) { const char *e = getenv("PCA_SMALL_COPY"); small_copy = e ? atoi(e) : 0; }
         if (!many_dev[ctx->device & 63]) PCA_CHECK(ctx, hipGetSymbolAddress(&many_dev[ctx->device & 63], HIP_SYMBOL(g_bev_many)));
         if (small_copy) PCA_CHECK(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_bev_many), ha + k0, sizeof(BevArgs) * (size_t)nk, 0, hipMemcpyHostToDevice, s));
-        else if (pca_fetch_block(ctx, ha + k0, many_dev[ctx->device & 63], (int64_t)sizeof(BevArgs) * nk, s)) return -1;
+        else if (pca_fetch_block(ctx, ha, (int64_t)sizeof(BevArgs) * k0, many_dev[ctx->device & 63], (int64_t)sizeof(BevArgs) * nk, s)) return -1;
         if (intensity64) {
             hipLaunchKernelGGL(bev_tile_bin_many<true>, dim3(G, nk), dim3(AB_THREADS), lds, s);
             hipLaunchKernelGGL(bev_tile_cells_many<true>, dim3(T, nk), dim3(C_THREADS), 0, s);

@@ -112,8 +112,9 @@ void pca_prof_end(pca_ctx *ctx, hipStream_t s);
 // Small argument blocks (frame descriptors, raster parameters: a few KB) from MAPPED host memory into device memory by a
 // KERNEL that reads the host block over PCIe: a copy command of that size costs 13-17 us on this stack (measured as the gap
 // between the HIP-event time of a batched K1n call and the sum of its kernels), a launch 2-3.  `mapped_host`: from
-// hipHostMalloc(..., hipHostMallocMapped); bytes: a multiple of 16.
-int pca_fetch_block(pca_ctx *ctx, const void *mapped_host, void *dev, int64_t bytes, hipStream_t s);
+// hipHostMalloc(..., hipHostMallocMapped) -- the START of the allocation, the block begins `offset` bytes into it (the device
+// address is asked for the allocation, not for an interior pointer); offset and bytes: multiples of 16.
+int pca_fetch_block(pca_ctx *ctx, const void *mapped_host, int64_t offset, void *dev, int64_t bytes, hipStream_t s);
 int pca_ctx_reserve_tiles(pca_ctx *ctx, int64_t tiles, hipStream_t s);
 uint32_t pca_ctx_next_epoch(pca_ctx *ctx, hipStream_t s);
 

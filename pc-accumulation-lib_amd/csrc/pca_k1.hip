@@ -787,7 +787,7 @@ int pca_kitti_project_sample_filter_ex(pca_ctx *ctx, const pca_kitti_frame *fram
         if (ctx->profiling == 1) { pca_prof_begin(ctx, PCA_K_KITTI, s); prof_open = true; }   // one event pair around the unit's GPU work
         if (n_frames > 1 && need_upload) {
             // (fetched by a kernel from the mapped host block: a copy command of a few KB costs 13-17 us, see pca_fetch_block)
-            if (pca_fetch_block(ctx, hf, ctx->k1_frames_dev, (int64_t)sizeof(K1Frame) * n_frames, s)) return -1;
+            if (pca_fetch_block(ctx, hf, 0, ctx->k1_frames_dev, (int64_t)sizeof(K1Frame) * n_frames, s)) return -1;
             PCA_CHECK(ctx, hipEventRecord(ctx->k1_pin_ev[slot], s));
             ctx->k1_pin_busy[slot] = true;
         }

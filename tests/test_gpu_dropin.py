@@ -1093,6 +1093,14 @@ def test_generate_bev_many_equals_single_calls(golden):
     copies = kacc.generate_bev(2, 3, gen_future=True)
     for c in copies:
         same(c, km[1])
+    # more samples than one launch group holds (48 argument blocks in constant memory): the second group's blocks are
+    # fetched from an offset inside the mapped host block
+    idxs = [1, 2, 3] * 17
+    km = kacc.generate_bev_many(idxs, gen_future=True)
+    ref = {idx: kacc.generate_bev(idx, 1, gen_future=True)[0] for idx in (1, 2, 3)}
+    assert len(km) == 51
+    for idx, b in zip(idxs, km):
+        same(b, ref[idx])
 
 
 def test_nuscenes_prefetching_loader_equals_plain_loader_and_feeds_the_accumulator(golden, monkeypatch):
