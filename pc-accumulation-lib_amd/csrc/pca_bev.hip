@@ -211,21 +211,25 @@ __device__ __forceinline__ BinPoint bin_point(const BevArgs &a, const ViewConst 
     r.key = view_key_lean(vc, X, Y, Z, D != 1, p >= w.sp ? 1u : 0u);
     return r;
 }
-// packs and stores one kept record (pass B)
+// packs and stores one kept record (pass B).  dynbits: the 256-bit set of 'dynamic object' classes as eight dwords in LDS
+// (the kernel's copy of prm.dynobj_mask): indexed by the point's class straight out of the kernel arguments it was a
+// VECTOR load from the argument segment per record -- a memory round trip, waited for, in front of every record store of
+// pass B (twelve in a row per thread).
 template <bool I64>
-__device__ __forceinline__ void bin_store(const BevArgs &a, uint32_t pos, uint32_t key, uint32_t rgbs, double z_store, double iv)
+__device__ __forceinline__ void bin_store(const BevArgs &a, const uint32_t *dynbits, uint32_t pos, uint32_t key, uint32_t rgbs, double z_store,
+                                          double iv, float iv32)
 {
     const pca_bev_params &q = a.prm;
     const unsigned sem = rgbs >> 24;
     uint32_t c = rgbs & 0xffffffu;
     if ((int)sem == q.road_class) c |= FLAG_ROAD;
-    if ((q.dynobj_mask[sem >> 6] >> (sem & 63)) & 1ull) c |= FLAG_DYNOBJ;
+    if ((dynbits[sem >> 5] >> (sem & 31u)) & 1u) c |= FLAG_DYNOBJ;
     const double z = z_store - q.origin[2];                 // rotation about z: row 3 of R is (0,0,1)
     if (I64) {
         RecD r; r.z = z; r.inten = iv; r.c = c; r.fk = key & 127u;
         reinterpret_cast<RecD *>(a.recs)[pos] = r;
     } else {
-        const float fi = (float)iv;
+        const float fi = iv32;
         if (fi < 0.0f) pca_raise(a.status, PCA_STATUS_NEGATIVE_INTENSITY);
         RecF r; r.z = z;
         r.iw = (__float_as_uint(fi) & 0x7fffffffu) | ((key & 1u) << 31);
@@ -297,7 +301,14 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     constexpr int UNR = BIN_RUNR;   // independent points per thread and iteration of the register path
     extern __shared__ uint32_t s_lds[];                     // [T] histogram, [T] cursors
     __shared__ uint32_t s_wsum[AB_THREADS / 64];
+    __shared__ uint32_t s_dyn[8];                           // prm.dynobj_mask as dwords (see bin_store)
     uint32_t *s_h = s_lds, *s_cur = s_lds + a.T;
+    if (threadIdx.x < 8) {                                  // (a select chain over scalar registers, no indexed read)
+        uint32_t w = (uint32_t)a.prm.dynobj_mask[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) w = (int)threadIdx.x == i ? (uint32_t)(a.prm.dynobj_mask[i >> 1] >> (32 * (i & 1))) : w;
+        s_dyn[threadIdx.x] = w;
+    }
     BIN_STAMP(0);
     int g;                                                  // this workgroup's chunk
     const Window w = chunk_of(a, g);
@@ -456,7 +467,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
             if (t >= a.T) break;
             const uint32_t c = s_h[t];
             s_cur[t] = run;
-            // tile-major tables [tile][workgroup]: a tile's workgroup of level 2 reads its G counters as one range
+            // tile-major tables [tile][place of the workgroup]: a tile's workgroup of level 2 reads its counters as one range
             a.bh[(int64_t)t * a.Gr + gp] = c;
             a.boff[(int64_t)t * a.Gr + gp] = run;
             run += c;
@@ -478,12 +489,25 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
             rrgb[j] = cb[ic];
             rinten[j] = ib[ic];
         }
-        // (all cursor atomics first, then all stores: no gain, 62.2 against 61.5 us)
+        // Every gathered word is touched HERE, once: behind the divergent `continue`s below the compiler cannot count what is
+        // still in flight and waited for EVERYTHING (vmcnt(0)) in front of each record -- i.e. also for the previous record's
+        // store.  After this point no load is pending and the stores follow one another without a wait.  (Measured: within
+        // the noise, 56.8-57.0 against 56.8-57.3 us -- the other waves of the SIMD cover the waits; kept because it is free.)
+        {
+            uint32_t touch = 0;
+#pragma unroll
+            for (int j = 0; j < REG_P; ++j) touch |= rrgb[j] ^ __float_as_uint(rinten[j]);
+            asm volatile("" ::"v"(touch));
+        }
+        // (all cursor atomics first, then all stores: no gain, 62.2 against 61.5 us.  Round 4, same box, alternating runs: the
+        // counter tables stored at the very end of the kernel instead of in front of these gathers 57.1-57.3 against 56.8-57.2;
+        // origin z / road class / record pointer / segment base parked in vector registers for the loop instead of being
+        // re-read as scalars per record 57.8-58.0 against 57.2-57.3: neither kept.)
 #pragma unroll
         for (int j = 0; j < REG_P; ++j) {
             if (rkey[j] == KEY_INVALID) continue;
             const uint32_t pos = seg + atomicAdd(&s_cur[rkey[j] >> 7], 1u);
-            bin_store<I64>(a, pos, rkey[j], rrgb[j], rz[j], (double)rinten[j]);
+            bin_store<I64>(a, s_dyn, pos, rkey[j], rrgb[j], rz[j], 0.0, rinten[j]);
         }
     }
     BIN_STAMP(4);
@@ -512,7 +536,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
         }
 #pragma unroll
         for (int u = 0; u < MUNR; ++u)
-            if (key[u] != KEY_INVALID) bin_store<I64>(a, pos[u], key[u], rgbs[u], zz[u], iv[u]);
+            if (key[u] != KEY_INVALID) bin_store<I64>(a, s_dyn, pos[u], key[u], rgbs[u], zz[u], iv[u], (float)iv[u]);
     }
     BIN_STAMP(5);
     if ((a.dbg & 32) && threadIdx.x == 0 && blockIdx.x < 1024) { g_dbg_stamps[blockIdx.x][6] = (unsigned long long)a.n_pend * 2 + a.write_back; g_dbg_stamps[blockIdx.x][7] = __smid(); }

@@ -122,7 +122,18 @@ struct Mat34 { double m[12]; };
 struct Mat44 { double m[16]; };
 struct ClassMask { uint64_t w[4]; };
 
-__device__ __forceinline__ bool in_mask(const ClassMask &m, unsigned c) { return (m.w[c >> 6] >> (c & 63)) & 1ull; }
+// (a select chain over the four words: `m.w[c >> 6]` with a per-lane class is a dynamically indexed read of the KERNEL
+// ARGUMENTS, which compiles to a vector load from the argument segment -- a memory round trip in the middle of the chain
+// class gather -> filter -> colour gather)
+__device__ __forceinline__ bool in_mask(const ClassMask &m, unsigned c)
+{
+    const unsigned w = c >> 6;
+    uint64_t v = m.w[0];
+    v = w == 1 ? m.w[1] : v;
+    v = w == 2 ? m.w[2] : v;
+    v = w == 3 ? m.w[3] : v;
+    return (v >> (c & 63)) & 1ull;
+}
 
 // row . [x y z 1], k order, fma chain  (== OpenBLAS dgemm for K = 4)
 __device__ __forceinline__ double row4(const double *r, double x, double y, double z)
