@@ -252,6 +252,7 @@ __device__ __forceinline__ ViewConst view_const(const BevArgs &a)
     c.r0 = q.R[0]; c.r1 = q.R[1]; c.r3 = q.R[3]; c.r4 = q.R[4];
     c.dx = q.dx; c.dy = q.dy;
     c.v = q.view; c.rv = 1.0 / q.view; c.vlo = -0.5 * q.view; c.vhi = 0.5 * q.view; c.pxd = (double)q.px; c.half_px = 0.5 * c.pxd;
+    // (handing 1 / view, (double)px and px / 2 over from the host instead was measured: 57.7-57.8 us against 56.8-57.2)
     c.hf = q.height_filter; c.use_h = !(q.height_filter != q.height_filter);
     c.px = q.px; c.tx = a.tx;
     return c;
@@ -514,24 +515,30 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     const bool stale = a.n_pend > 0 && !a.write_back;
     for (int64_t base = reg_hi + threadIdx.x; base < w.c_hi; base += MUNR * AB_THREADS) {
         uint32_t key[MUNR], pos[MUNR], rgbs[MUNR];
-        double zz[MUNR], iv[MUNR];
+        double zz[MUNR], iv[MUNR], xs[MUNR], ys[MUNR];
 #pragma unroll
         for (int u = 0; u < MUNR; ++u) {
             const int64_t p = base + u * AB_THREADS;
             key[u] = p < w.c_hi ? a.key[p - w.lo] : KEY_INVALID;
         }
+        // every load of the kept points first, nothing consumed in between (the owed chain used to be applied inside this loop:
+        // it waited for x, y, z of point u before the loads of point u + 1 were issued -- four round trips per iteration)
 #pragma unroll
         for (int u = 0; u < MUNR; ++u) {
             const int64_t p = base + u * AB_THREADS;
             const bool ok = key[u] != KEY_INVALID;
             rgbs[u] = ok ? a.st.rgbs[p] : 0u;
             zz[u] = ok ? a.st.z[p] : 0.0;
-            if (ok && stale) {                              // transforms still owed and not written back by pass A:
-                double X = a.st.x[p], Y = a.st.y[p];        // the store holds the coordinates from before them
-                apply_owed(a, pend_hi, p, X, Y, zz[u]);
-            }
+            xs[u] = (ok && stale) ? a.st.x[p] : 0.0;        // transforms still owed and not written back by pass A:
+            ys[u] = (ok && stale) ? a.st.y[p] : 0.0;        // the store holds the coordinates from before them
             if (I64) iv[u] = ok ? a.intensity64[p] : 0.0;
             else iv[u] = ok ? (double)a.st.intensity[p] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < MUNR; ++u) {
+            const int64_t p = base + u * AB_THREADS;
+            const bool ok = key[u] != KEY_INVALID;
+            if (ok && stale) apply_owed(a, pend_hi, p, xs[u], ys[u], zz[u]);
             pos[u] = ok ? seg + atomicAdd(&s_cur[key[u] >> 7], 1u) : 0u;
         }
 #pragma unroll
@@ -699,7 +706,18 @@ __device__ __forceinline__ void fx_split(double v, long long &hi, long long &lo)
         lo = (long long)rint((sc - fl) * FX_LO);
     }
 }
-__device__ __forceinline__ void run_add(Run &r, bool extra, uint32_t c, double z, double iv)
+// (iv: the record's intensity as stored; div255 -- NuScenes' i / 255. -- is applied HERE, to the road points that use it:
+// formed when the record was loaded, the IEEE division (12 vector instructions and a 16-cycle reciprocal) ran for every
+// record of every tile, KITTI's included, where it is never wanted)
+__device__ __forceinline__ double road_intensity(double iv, bool div255)
+{
+    if (div255) {                                           // (uniform)
+        asm volatile("" ::: "memory");                      // keeps this a BRANCH: written as a select the division runs regardless
+        iv = iv / 255.0;
+    }
+    return iv;
+}
+__device__ __forceinline__ void run_add(Run &r, bool extra, uint32_t c, double z, double iv, bool div255)
 {
     const unsigned long long zkey = f64_order_key(z);
     r.cnt++;
@@ -714,14 +732,14 @@ __device__ __forceinline__ void run_add(Run &r, bool extra, uint32_t c, double z
     if (c & FLAG_DYNOBJ) r.dyn++;
     if (c & FLAG_ROAD) {
         long long hi, lo;
-        fx_split(iv, hi, lo);
+        fx_split(road_intensity(iv, div255), hi, lo);
         r.road++;
         r.ihi += hi;
         r.ilo += lo;
     }
 }
 // one record on its own (a run of length one without the bookkeeping): returns its rank inside its (cell,set)
-__device__ __forceinline__ uint32_t rec_add(TileStats &S, bool extra, uint32_t key, uint32_t c, double z, double iv)
+__device__ __forceinline__ uint32_t rec_add(TileStats &S, bool extra, uint32_t key, uint32_t c, double z, double iv, bool div255)
 {
     const unsigned long long zkey = f64_order_key(z);
     const uint32_t rank = atomicAdd(&S.cnt[key], 1u);
@@ -736,7 +754,7 @@ __device__ __forceinline__ uint32_t rec_add(TileStats &S, bool extra, uint32_t k
     if (c & FLAG_DYNOBJ) atomicAdd(&S.dyn[key], 1u);
     if (c & FLAG_ROAD) {
         long long hi, lo;
-        fx_split(iv, hi, lo);
+        fx_split(road_intensity(iv, div255), hi, lo);
         atomicAdd(&S.road[key], 1u);
         atomicAdd(&S.ihi[key], (unsigned long long)hi);
         atomicAdd(&S.ilo[key], (unsigned long long)lo);
@@ -773,9 +791,25 @@ __device__ __forceinline__ void load_rec(const BevArgs &a, uint32_t r, uint32_t 
         k = ((rec.cw >> 26) << 1) | (rec.iw >> 31);
         c = rec.cw & 0x03ffffffu;
         z = rec.z;
-        const double raw = (double)__uint_as_float(rec.iw & 0x7fffffffu);
-        iv = a.prm.intensity_div255 ? raw / 255.0 : raw;
+        iv = (double)__uint_as_float(rec.iw & 0x7fffffffu);                   // (/ 255: see run_add)
     }
+}
+// A RecF as one 16-byte word, and its fields.  The tile kernels load the records of a round with EVERY lane issuing EVERY load
+// (a lane past the tile's end re-reads a record that exists) and decode afterwards: a load inside `if (r < r_hi)` is consumed
+// inside that branch, so the compiler waited for each record before it asked for the next -- a chain of sixteen memory round
+// trips per thread was what "pass 1" of a tile consisted of (ISA: global_load_dwordx4; s_waitcnt vmcnt(0), per record).
+__device__ __forceinline__ uint4 recf_raw(const BevArgs &a, uint32_t pos)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4 *>(reinterpret_cast<uintptr_t>(a.recs) + (size_t)pos * 16);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void recf_fields(const uint4 w, uint32_t &k, uint32_t &c, double &z, double &iv)
+{
+    k = ((w.w >> 26) << 1) | (w.z >> 31);
+    c = w.w & 0x03ffffffu;
+    z = __hiloint2double((int)w.y, (int)w.x);
+    iv = (double)__uint_as_float(w.z & 0x7fffffffu);
 }
 // fine key and colour only
 template <bool I64>
@@ -1060,6 +1094,7 @@ __device__ __forceinline__ void cells_drain(const BevArgs &a, TileLds &L, unsign
     if (s_drain_n == 0) return;
     __threadfence();
     const bool extra = a.extra != nullptr;
+    const bool div255 = !I64 && a.prm.intensity_div255;
     RecMap &M = *reinterpret_cast<RecMap *>(s_buf);
     uint32_t (*hist)[256] = reinterpret_cast<uint32_t (*)[256]>(s_buf + ((sizeof(RecMap) + 15) & ~(size_t)15));
     static_assert(((sizeof(RecMap) + 15) & ~(size_t)15) + 3 * 256 * 4 <= RGB_CAP * 4, "RecMap + histograms live in the colour buffer");
@@ -1082,7 +1117,7 @@ __device__ __forceinline__ void cells_drain(const BevArgs &a, TileLds &L, unsign
                     if (run.key != RUN_NONE) run_flush(S, extra, run);
                     run_reset(run, kk);
                 }
-                run_add(run, extra, c, z, iv);
+                run_add(run, extra, c, z, iv, div255);
             }
             if (run.key != RUN_NONE) run_flush(S, extra, run);
             __syncthreads();
@@ -1166,24 +1201,46 @@ __device__ __forceinline__ void bev_tile_cells_body(const BevArgs &a)
     constexpr int RPT = RGB_CAP / C_THREADS;
     constexpr int HALF = RPT / 2;                           // two rounds of loads: bounds the registers in flight
     const bool contig = (r_hi - r_lo) > CONTIG_MIN;
+    const bool div255 = !I64 && a.prm.intensity_div255;
     uint32_t kr[RPT], cc[RPT];
-    if (!contig) {
+    // the HALF records of one round of thread-record numbers rec(u): all loads first (see recf_raw), then the fields
+    auto load_round = [&](auto rec, uint32_t (&k)[HALF], uint32_t (&c)[HALF], double (&z)[HALF], double (&iv)[HALF]) {
+        if constexpr (I64) {
+#pragma unroll
+            for (int u = 0; u < HALF; ++u) {
+                const uint32_t r = rec(u);
+                k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
+                if (r < r_hi) load_rec<I64>(a, recmap_at(M, L.owner, r), k[u], c[u], z[u], iv[u]);
+            }
+        } else {
+            uint4 w[HALF];
+#pragma unroll
+            for (int u = 0; u < HALF; ++u) {
+                const uint32_t r = rec(u);
+                w[u] = recf_raw(a, recmap_at(M, L.owner, r < r_hi ? r : r_lo));      // (r_lo exists: the tile is not empty)
+            }
+#pragma unroll
+            for (int u = 0; u < HALF; ++u) {
+                recf_fields(w[u], k[u], c[u], z[u], iv[u]);
+                if (!(rec(u) < r_hi)) { k[u] = RUN_NONE; c[u] = 0; }
+            }
+        }
+    };
+    if (r_hi == r_lo) {                                     // (uniform) an empty tile: nothing to load, nothing to count
+#pragma unroll
+        for (int uu = 0; uu < RPT; ++uu) { kr[uu] = RUN_NONE; cc[uu] = 0; }
+    } else if (!contig) {
         // records a workgroup-width apart share a cell only by chance: every record is counted on its own
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             uint32_t k[HALF], c[HALF];
             double z[HALF], iv[HALF];
-#pragma unroll
-            for (int u = 0; u < HALF; ++u) {
-                const uint32_t r = r_lo + (uint32_t)(h * HALF + u) * C_THREADS + threadIdx.x;
-                k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
-                if (r < r_hi) load_rec<I64>(a, recmap_at(M, L.owner, r), k[u], c[u], z[u], iv[u]);
-            }
+            load_round([&](int u) { return r_lo + (uint32_t)(h * HALF + u) * C_THREADS + threadIdx.x; }, k, c, z, iv);
 #pragma unroll
             for (int u = 0; u < HALF; ++u) {
                 const int uu = h * HALF + u;
                 kr[uu] = RUN_NONE; cc[uu] = c[u] & 0xffffffu;
-                if (k[u] != RUN_NONE) kr[uu] = k[u] | (rec_add(L.S, extra, k[u], c[u], z[u], iv[u]) << 8);
+                if (k[u] != RUN_NONE) kr[uu] = k[u] | (rec_add(L.S, extra, k[u], c[u], z[u], iv[u], div255) << 8);
             }
         }
     } else {
@@ -1195,12 +1252,7 @@ __device__ __forceinline__ void bev_tile_cells_body(const BevArgs &a)
         for (int h = 0; h < 2; ++h) {
             uint32_t k[HALF], c[HALF];
             double z[HALF], iv[HALF];
-#pragma unroll
-            for (int u = 0; u < HALF; ++u) {
-                const uint32_t r = r_lo + threadIdx.x * RPT + (uint32_t)(h * HALF + u);
-                k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
-                if (r < r_hi) load_rec<I64>(a, recmap_at(M, L.owner, r), k[u], c[u], z[u], iv[u]);
-            }
+            load_round([&](int u) { return r_lo + threadIdx.x * RPT + (uint32_t)(h * HALF + u); }, k, c, z, iv);
 #pragma unroll
             for (int u = 0; u < HALF; ++u) {
                 const int uu = h * HALF + u;
@@ -1211,7 +1263,7 @@ __device__ __forceinline__ void bev_tile_cells_body(const BevArgs &a)
                     run_reset(run, k[u]);
                 }
                 kr[uu] = k[u] | (run.cnt << 8);             // position in the run, for now
-                run_add(run, extra, c[u], z[u], iv[u]);
+                run_add(run, extra, c[u], z[u], iv[u], div255);
             }
         }
         uint32_t b = run.key != RUN_NONE ? run_flush(L.S, extra, run) : 0u;
@@ -1340,6 +1392,7 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
     __shared__ uint32_t s_next;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool extra = a.extra != nullptr;
+    const bool div255 = !I64 && a.prm.intensity_div255;
     // the queue: HQ_CLASSES lists of tile ids, larger tiles first; item -> (class, place) by the classes' running counts
     __shared__ uint32_t s_cls[HQ_CLASSES + 1];
     if (threadIdx.x == 0) {
@@ -1387,10 +1440,25 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
             double z[UNR], iv[UNR];
             RecWalk walk;
             recwalk_seek(walk, L.M, a.Gr, r0);
+            if constexpr (I64) {
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
-                if (r0 + u < r_hi) load_rec<I64>(a, recwalk_next(walk, L.M, a.Gr, r_hi), k[u], c[u], z[u], iv[u]);
+                for (int u = 0; u < UNR; ++u) {
+                    k[u] = RUN_NONE; c[u] = 0; z[u] = 0; iv[u] = 0;
+                    if (r0 + u < r_hi) load_rec<I64>(a, recwalk_next(walk, L.M, a.Gr, r_hi), k[u], c[u], z[u], iv[u]);
+                }
+            } else {                                        // places first, then every load by every lane (see recf_raw)
+                uint32_t at[UNR];
+                uint4 w[UNR];
+                const uint32_t at0 = walk.at;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) at[u] = r0 + u < r_hi ? recwalk_next(walk, L.M, a.Gr, r_hi) : at0;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) w[u] = recf_raw(a, at[u]);
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    recf_fields(w[u], k[u], c[u], z[u], iv[u]);
+                    if (!(r0 + u < r_hi)) { k[u] = RUN_NONE; c[u] = 0; }
+                }
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -1399,7 +1467,7 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
                     if (run.key != RUN_NONE) run_flush(L.S, extra, run);
                     run_reset(run, k[u]);
                 }
-                run_add(run, extra, c[u], z[u], iv[u]);
+                run_add(run, extra, c[u], z[u], iv[u], div255);
                 uint32_t *row = hist + ((((k[u] >> 1) % H_CELLS) * 2 + (k[u] & 1u)) * 3) * 128;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) hist16_add(row + ch * 128, (c[u] >> (8 * ch)) & 255u, 1u);
