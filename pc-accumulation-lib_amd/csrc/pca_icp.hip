@@ -10,18 +10,25 @@
 //
 //   icp_grid_count / icp_cell_scan / icp_grid_fill   two uniform grids around the sensor (0.5 m and 0.25 m cells):
 //                     counting sort of the target points by cell -- a cell's points are contiguous, a row of cells is
-//                     one range, and a neighbour search streams them (four loads in flight)
+//                     one range, and a neighbour search streams them (four loads in flight).  One kernel each for both
+//                     grids; only the slabs (cells along z) the cloud occupies are scanned and searched
 //   icp_normals       per target point (8 lanes each): the K = 30 nearest neighbours (shell-by-shell grid search, exact
 //                     within the search cap), covariance, eigenvector of the smallest eigenvalue (cyclic Jacobi, f64)
-//   icp_match         per source point (8 lanes each): q = T p, nearest target point (exact within the cap; the previous
-//                     iteration's partner bounds the search from the start)
-//   icp_accumulate    per source point: r = (q - t).n, J = [q x n, n]; per-workgroup partial sums of J^T J, J^T r,
-//                     |q - t|^2, inlier count.  The last workgroup to finish adds the partials up in workgroup order
-//                     (deterministic) and takes the step: 6x6 Cholesky solve, T <- exp(x) T, fitness / rmse, convergence
-//                     flag -- two launches per iteration, and the host looks at the flag only every sixth pass.
-// Measured on two 120 k-point sweeps (round 2): 10.9 ms -> 2.8 ms per registration (normals 1.63 -> 0.67 ms, a pass
-// 0.91 -> 0.17 ms); what changed is in the comments of icp_visit_shell, icp_match and icp_solve_step.
+//   icp_match         per source point (8 lanes each): q = T p; from the third pass on, first the question whether the partner
+//                     of the last pass provably is still the unique nearest target (then no search); else the nearest target
+//                     (exact within the cap; the previous partner bounds the search from the start); the correspondence's
+//                     point-to-plane row r = (q - t).n, J = [q x n, n]; per workgroup one column of partial sums of J^T J,
+//                     J^T r, |q - t|^2, pair count (fixed order)
+//   icp_solve         30 workgroups, one per accumulator, add the columns up in a fixed order (deterministic); the last to
+//                     arrive takes the step: 6x6 Cholesky solve, T <- exp(x) T, fitness / rmse, convergence flag -- two
+//                     launches per iteration, and the host looks at the flag only every sixth pass.
+// Measured on two 120 k-point sweeps: round 2 10.9 ms -> 2.8 ms per registration; round 4 2.71 -> 2.1 ms (grids 278 -> 131 us,
+// rows + solve 35 -> 9 us per pass, late passes 130 -> 80 us); what changed is in the comments of icp_cell_scan, icp_visit_shell,
+// icp_match and icp_solve_step, the measurements in profiles/r04_experiments/icp_second_session.txt.
 #include "pca_common.h"
+#include <cstring>
+#include <cstdio>
+#include <cstdlib>
 
 // Two uniform grids of 512 x 512 x 64 cells around the sensor: level 0 = 0.5 m cells (256 m x 256 m x 32 m), level 1 =
 // 0.25 m cells (128 m x 128 m x 16 m).  Next to the sensor a 0.5 m cell holds ~300 returns: a query settles in the fine
@@ -41,7 +48,6 @@ template <int LV> struct IcpLevel {
 #define ICP_THREADS 256
 #define ICP_NACC 30              // 21 (J^T J upper) + 6 (J^T r) + sum d^2 + inliers + sum r^2
 #define ICP_CHECK_EVERY 6         // the host looks at the convergence flag after every 6th pass
-#define ICP_MAX_GRID 512          // workgroups of icp_accumulate = rows of partial sums its last workgroup adds up
 
 struct IcpGrid {
     uint32_t *cnt;               // [cells] points per cell (counting pass), all zero again after the fill pass
@@ -56,15 +62,19 @@ struct IcpArgs {
     IcpGrid g[2];                // [0] coarse, [1] fine
     float *normal;               // [n_tgt,4]  nx, ny, nz, valid -- by ORIGINAL index
     int32_t *nn_prev;            // [n_src] original index of the previous iteration's correspondence, -1 = none
-    double *nn_d2;               // [n_src] its squared distance (icp_match -> icp_accumulate)
+    int32_t *nn_cell;            // [n_src] coarse cell the query lay in when it was searched last, -1 = outside the grid
+    float *nn_slack;             // [n_src] how far the query may still move before its partner has to be searched again (icp_match)
+    int no_skip;                 // PCA_ICP_NO_SKIP=1: every pass searches every query (A/B)
+    int dbg;                     // PCA_ICP_DBG=1: searched queries per pass counted in state[48 + pass] and printed by the host
     uint64_t *lb_state;          // decoupled look-back of the cell scan
-    uint32_t *ticket;
     uint32_t epoch;
-    int scan_level;              // grid the scan kernel works on
-    double *partial;             // [grid][ICP_NACC]
+    double *partial;             // [ICP_NACC][grid] partial sums, one column per workgroup of icp_match
     double *state;               // [0..15] T (row-major), [16] fitness, [17] rmse, [18] prev fitness, [19] prev rmse,
-                                 // [20] converged flag, [21] iterations done
-    uint32_t *arrived;           // workgroups of the running icp_accumulate that have written their partial sums
+                                 // [20] converged flag, [21] iterations done, [24..25] zr, [32..43] T of the pass before
+    uint32_t *zr;                // [4] occupied slab range of the two grids: zmin, zmax of level 0, then of level 1 (cells along z;
+                                 // zmin > zmax: no point inside).  Counting fills it; only these slabs are scanned and searched
+    uint32_t *status;            // context status word
+    uint32_t *arrived;           // workgroups of the running icp_solve that have written their sum
     double max_dist2;
     double rel_fitness, rel_rmse;
     int grid;
@@ -80,39 +90,68 @@ __device__ __forceinline__ bool icp_cell_of(double x, double y, double z, int &c
     return true;
 }
 __device__ __forceinline__ int icp_cell_index(int cx, int cy, int cz) { return (cz * ICP_NY + cy) * ICP_NX + cx; }
+// the slabs of a grid that hold points (icp_grid_count): lo > hi = none
+struct IcpSlab { int lo, hi; };
 
 #define ICP_SCAN_THREADS 1024
-#define ICP_SCAN_TILE (4 * ICP_SCAN_THREADS)
+#define ICP_SCAN_PER 16                                    // cells per thread of the scan
+#define ICP_SCAN_TILE (ICP_SCAN_PER * ICP_SCAN_THREADS)
 
-template <int LV>
+// one thread per target point: its cell in both grids counted, and the slabs (cells along z) the cloud occupies -- the
+// grids are 64 slabs of 512 x 512 cells and a lidar sweep fills a quarter to a half of them: only those are scanned
+// (icp_cell_scan) and searched (icp_visit_shell treats every other slab as outside the grid; its start[] is never read)
 __global__ __launch_bounds__(ICP_THREADS) void icp_grid_count(const IcpArgs a)
 {
     const int p = blockIdx.x * ICP_THREADS + threadIdx.x;
-    if (p >= a.n_tgt) return;
-    const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
-    int cx, cy, cz;
-    if (icp_cell_of<LV>(v.x, v.y, v.z, cx, cy, cz)) atomicAdd(&a.g[LV].cnt[icp_cell_index(cx, cy, cz)], 1u);   // else: not in this grid
+    uint32_t zlo0 = 0xffffffffu, zhi0 = 0u, zlo1 = 0xffffffffu, zhi1 = 0u;   // (zhi + 1, so that 0 = none)
+    if (p < a.n_tgt) {
+        const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
+        int cx, cy, cz;
+        if (icp_cell_of<0>(v.x, v.y, v.z, cx, cy, cz)) { atomicAdd(&a.g[0].cnt[icp_cell_index(cx, cy, cz)], 1u); zlo0 = (uint32_t)cz; zhi0 = (uint32_t)cz + 1u; }
+        if (icp_cell_of<1>(v.x, v.y, v.z, cx, cy, cz)) { atomicAdd(&a.g[1].cnt[icp_cell_index(cx, cy, cz)], 1u); zlo1 = (uint32_t)cz; zhi1 = (uint32_t)cz + 1u; }
+    }
+    zlo0 = wave_reduce_min(zlo0); zhi0 = wave_reduce_max(zhi0); zlo1 = wave_reduce_min(zlo1); zhi1 = wave_reduce_max(zhi1);
+    // (one memory-side word serves ~90 atomics per microsecond: 7500 unconditional ones were 85 us of this kernel.  The range is
+    // looked at first -- a stale value only means an atomic that changes nothing -- and after the first waves nobody widens it)
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t c0 = __hip_atomic_load(&a.zr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c1 = __hip_atomic_load(&a.zr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       c2 = __hip_atomic_load(&a.zr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c3 = __hip_atomic_load(&a.zr[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (zhi0 && zlo0 < c0) atomicMin(&a.zr[0], zlo0);
+        if (zhi0 > c1) atomicMax(&a.zr[1], zhi0);
+        if (zhi1 && zlo1 < c2) atomicMin(&a.zr[2], zlo1);
+        if (zhi1 > c3) atomicMax(&a.zr[3], zhi1);
+    }
 }
 
-// exclusive scan of the per-cell counts (single pass, decoupled look-back; tiles handed out by ticket)
+// exclusive scan of the per-cell counts of the occupied slabs of both grids (single pass, decoupled look-back; blockIdx.x <
+// tiles per grid: level 0, else level 1).  A slab is ICP_NX * ICP_NY / ICP_SCAN_TILE whole tiles, so the range starts and
+// ends on tile borders; start[] of the cell behind the range gets the total (the end of the last row).  zr holds zmin and
+// zmax + 1 here (icp_grid_count).  Tile = position in the launch: workgroups are dispatched in that order, so a tile's
+// predecessors have started when it looks back (the spin is bounded all the same: PCA_STATUS_LOOKBACK_TIMEOUT).  Round 2
+// drew tiles by ticket from one word: 4096 returning atomics per grid at ~90 per microsecond were 46 of the scan's 72 us.
+#define ICP_SLAB_TILES (ICP_NX * ICP_NY / ICP_SCAN_TILE)
 __global__ __launch_bounds__(ICP_SCAN_THREADS) void icp_cell_scan(const IcpArgs a)
 {
-    __shared__ int s_tile;
     __shared__ uint32_t s_w[ICP_SCAN_THREADS / 64];
     __shared__ uint64_t s_excl;
-    const IcpGrid &g = a.g[a.scan_level];
-    const int n_tiles = (int)(ICP_CELLS / ICP_SCAN_TILE);
-    if (threadIdx.x == 0) {
-        const uint32_t t = atomicAdd(a.ticket, 1u);
-        if ((int)t == n_tiles - 1) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_tile = (int)t;
-    }
-    __syncthreads();
-    const int tile = s_tile;
+    const int tiles_per_grid = (int)(ICP_CELLS / ICP_SCAN_TILE);
+    const int lv = (int)blockIdx.x >= tiles_per_grid ? 1 : 0;
+    const IcpGrid &g = a.g[lv];
+    const uint32_t zlo = a.zr[2 * lv], zhi1 = a.zr[2 * lv + 1];
+    if (zhi1 == 0u) return;                                 // no point inside this grid: nothing is ever looked up
+    const int n_tiles = (int)(zhi1 - zlo) * ICP_SLAB_TILES;
+    const int tile = (int)blockIdx.x - lv * tiles_per_grid;
+    if (tile >= n_tiles) return;                            // (uniform) a workgroup beyond the occupied slabs
+    uint64_t *lb = a.lb_state + (size_t)lv * tiles_per_grid;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t base = (int64_t)tile * ICP_SCAN_TILE + threadIdx.x * 4;
-    const uint4 c = *reinterpret_cast<const uint4 *>(g.cnt + base);
-    const uint32_t tsum = c.x + c.y + c.z + c.w;
+    // (thread t owns ICP_SCAN_PER consecutive cells)
+    const int64_t base = ((int64_t)zlo * ICP_SLAB_TILES + tile) * ICP_SCAN_TILE + (int64_t)threadIdx.x * ICP_SCAN_PER;
+    uint4 c[ICP_SCAN_PER / 4];
+#pragma unroll
+    for (int u = 0; u < ICP_SCAN_PER / 4; ++u) c[u] = *reinterpret_cast<const uint4 *>(g.cnt + base + 4 * u);
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int u = 0; u < ICP_SCAN_PER / 4; ++u) tsum += c[u].x + c[u].y + c[u].z + c[u].w;
     const uint32_t inc = wave_incl_scan_add(tsum);
     if (lane == 63) s_w[wave] = inc;
     __syncthreads();
@@ -121,41 +160,63 @@ __global__ __launch_bounds__(ICP_SCAN_THREADS) void icp_cell_scan(const IcpArgs 
         const uint32_t winc = wave_incl_scan_add(v);
         if (lane < ICP_SCAN_THREADS / 64) s_w[lane] = winc - v;
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)winc, 63);
-        const uint64_t e = lb_exclusive_prefix(a.lb_state, tile, (uint64_t)total, a.epoch, a.ticket + 1);
+        const uint64_t e = lb_exclusive_prefix(lb, tile, (uint64_t)total, a.epoch, a.status);
         if (lane == 0) s_excl = (e << 32) | total;
     }
     __syncthreads();
     const uint32_t excl = (uint32_t)(s_excl >> 32), total = (uint32_t)s_excl;
-    const uint32_t r0 = excl + s_w[wave] + (inc - tsum);
-    *reinterpret_cast<uint4 *>(g.start + base) = make_uint4(r0, r0 + c.x, r0 + c.x + c.y, r0 + c.x + c.y + c.z);
-    if (tile == n_tiles - 1 && threadIdx.x == ICP_SCAN_THREADS - 1) g.start[ICP_CELLS] = excl + total;
+    uint32_t r0 = excl + s_w[wave] + (inc - tsum);
+#pragma unroll
+    for (int u = 0; u < ICP_SCAN_PER / 4; ++u) {
+        *reinterpret_cast<uint4 *>(g.start + base + 4 * u) = make_uint4(r0, r0 + c[u].x, r0 + c[u].x + c[u].y, r0 + c[u].x + c[u].y + c[u].z);
+        r0 += c[u].x + c[u].y + c[u].z + c[u].w;
+    }
+    if (tile == n_tiles - 1 && threadIdx.x == ICP_SCAN_THREADS - 1) g.start[base + ICP_SCAN_PER] = excl + total;
 }
 
-template <int LV>
 __global__ __launch_bounds__(ICP_THREADS) void icp_grid_fill(const IcpArgs a)
 {
     const int p = blockIdx.x * ICP_THREADS + threadIdx.x;
     if (p >= a.n_tgt) return;
     const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
+    const float4 rec = make_float4(v.x, v.y, v.z, __int_as_float(p));
     int cx, cy, cz;
-    if (!icp_cell_of<LV>(v.x, v.y, v.z, cx, cy, cz)) return;
-    const IcpGrid &g = a.g[LV];
-    const int cell = icp_cell_index(cx, cy, cz);
-    const uint32_t pos = g.start[cell] + atomicSub(&g.cnt[cell], 1u) - 1u;     // fills the cell's range from the back
-    g.spts[pos] = make_float4(v.x, v.y, v.z, __int_as_float(p));
+    // (both lookups and both decrements before either record store: two chains side by side)
+    uint32_t pos0 = 0xffffffffu, pos1 = 0xffffffffu;
+    if (icp_cell_of<0>(v.x, v.y, v.z, cx, cy, cz)) {
+        const int cell = icp_cell_index(cx, cy, cz);
+        pos0 = a.g[0].start[cell] + atomicSub(&a.g[0].cnt[cell], 1u) - 1u;     // fills the cell's range from the back
+    }
+    if (icp_cell_of<1>(v.x, v.y, v.z, cx, cy, cz)) {
+        const int cell = icp_cell_index(cx, cy, cz);
+        pos1 = a.g[1].start[cell] + atomicSub(&a.g[1].cnt[cell], 1u) - 1u;
+    }
+    if (pos0 != 0xffffffffu) a.g[0].spts[pos0] = rec;
+    if (pos1 != 0xffffffffu) a.g[1].spts[pos1] = rec;
+}
+
+__device__ __forceinline__ IcpSlab icp_slab(const IcpArgs &a, int lv)
+{
+    IcpSlab sl;
+    sl.lo = (int)a.zr[2 * lv];                              // (0xffffffff -> -1 if the grid is empty: lo > hi either way)
+    sl.hi = (int)a.zr[2 * lv + 1] - 1;
+    if (a.zr[2 * lv + 1] == 0u) { sl.lo = 1; sl.hi = 0; }
+    return sl;
 }
 
 // the records [s0, e) of a range of cells, four loads in flight (a one-record-per-trip loop is a chain of memory latencies:
 // measured 1 ms per 120 k queries, independent of how much the search is culled)
-// SGN > 1: SGN neighbouring lanes share one query; lane `sub` takes every SGN-th record, two loads in flight
+// SGN > 1: SGN neighbouring lanes share one query; lane `sub` takes every SGN-th record, four loads in flight
 template <int SGN, typename F>
 __device__ __forceinline__ void icp_scan_range_sg(const float4 *spts, uint32_t s0, uint32_t e, int sub, F &&f)
 {
-    for (uint32_t q = s0 + (uint32_t)sub; q < e; q += 2 * SGN) {
-        const uint32_t q1 = q + SGN;
-        const float4 w0 = spts[q], w1 = spts[q1 < e ? q1 : q];
+    for (uint32_t q = s0 + (uint32_t)sub; q < e; q += 4 * SGN) {        // (four loads in flight: a dense cell next to the sensor
+        const uint32_t q1 = q + SGN, q2 = q + 2 * SGN, q3 = q + 3 * SGN;   //  holds hundreds of records, and its scan is the longest chain of a pass)
+        const float4 w0 = spts[q], w1 = spts[q1 < e ? q1 : q], w2 = spts[q2 < e ? q2 : q], w3 = spts[q3 < e ? q3 : q];
         f(w0);
         if (q1 < e) f(w1);
+        if (q2 < e) f(w2);
+        if (q3 < e) f(w3);
     }
 }
 
@@ -186,7 +247,7 @@ __device__ __forceinline__ void icp_scan_range(const float4 *spts, uint32_t s0, 
 // (measured per query with s_memrealtime: 0-5 m 36 us mean / 218 us max, beyond 20 m 13 us).  All loops have group-uniform
 // trip counts; the eight lanes must be converged at every call.
 template <int LV, int SGN, typename B, typename F>
-__device__ __forceinline__ void icp_visit_shell(const IcpGrid &g, int cx, int cy, int cz, int r, double qx, double qy,
+__device__ __forceinline__ void icp_visit_shell(const IcpGrid &g, const IcpSlab sl, int cx, int cy, int cz, int r, double qx, double qy,
                                                 double qz, int sub, B &&bound, F &&f)
 {
     using G = IcpLevel<LV>;
@@ -207,6 +268,7 @@ __device__ __forceinline__ void icp_visit_shell(const IcpGrid &g, int cx, int cy
         }
     };
     if (r == 0) {
+        if (cz < sl.lo || cz > sl.hi) return;               // (group-uniform) an empty slab: its start[] was never written
         const int c0 = icp_cell_index(cx, cy, cz);
         if (SGN == 1) icp_scan_range(g.spts, g.start[c0], g.start[c0 + 1], f);
         else icp_scan_range_sg<SGN>(g.spts, g.start[c0], g.start[c0 + 1], sub, f);
@@ -214,24 +276,28 @@ __device__ __forceinline__ void icp_visit_shell(const IcpGrid &g, int cx, int cy
     }
     const int n = 2 * r + 1, m = 2 * r - 1;
     const int x_lo = cx - r < 0 ? 0 : cx - r, x_hi = cx + r >= ICP_NX ? ICP_NX - 1 : cx + r;
-    for (int i0 = 0; i0 < 2 * n + 2 * m; i0 += SGN) {
-        const int i = i0 + sub;
-        uint32_t s0 = 0u, e0 = 0u;
-        if (i < 2 * n + 2 * m) {
+    // (four row lookups in flight per lane, as for the single cells below: one lookup per trip made a far-field query's outer
+    // shells -- 8 r rows each -- a chain of r + 1 round trips per shell, and such queries are the last to finish in a pass)
+    for (int i0 = 0; i0 < 2 * n + 2 * m; i0 += 4 * SGN) {
+        uint32_t s0[4], e0[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s0[u] = e0[u] = 0u;
+            const int i = i0 + u * SGN + sub;
+            if (i >= 2 * n + 2 * m) continue;
             int dz, dy;
             if (i < 2 * n) { dz = i < n ? -r : r; dy = (i < n ? i : i - n) - r; }
             else { const int j = i - 2 * n; dy = j < m ? -r : r; dz = (j < m ? j : j - m) - (r - 1); }
             const int z = cz + dz, y = cy + dy;
-            if (z >= 0 && z < ICP_NZ && y >= 0 && y < ICP_NY) {
-                const double ez = gap(qz, G::oz + z * G::cell), ey = gap(qy, G::oy + y * G::cell);
-                if (ey * ey + ez * ez < bound()) {
-                    const int c0 = icp_cell_index(x_lo, y, z);
-                    s0 = g.start[c0];
-                    e0 = g.start[c0 + (x_hi - x_lo) + 1];
-                }
-            }
+            if (z < sl.lo || z > sl.hi || y < 0 || y >= ICP_NY) continue;
+            const double ez = gap(qz, G::oz + z * G::cell), ey = gap(qy, G::oy + y * G::cell);
+            if (ey * ey + ez * ez >= bound()) continue;
+            const int c0 = icp_cell_index(x_lo, y, z);
+            s0[u] = g.start[c0];
+            e0[u] = g.start[c0 + (x_hi - x_lo) + 1];
         }
-        scan_found(s0, e0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) scan_found(s0[u], e0[u]);
     }
     const int ncell = 2 * m * m;
     for (int k0 = 0; k0 < ncell; k0 += 4 * SGN) {
@@ -243,7 +309,7 @@ __device__ __forceinline__ void icp_visit_shell(const IcpGrid &g, int cx, int cy
             if (k >= ncell) continue;
             const int mm = k >> 1, iz = mm / m;
             const int z = cz + iz - (r - 1), y = cy + (mm - iz * m) - (r - 1), x = cx + ((k & 1) ? r : -r);
-            if (z < 0 || z >= ICP_NZ || y < 0 || y >= ICP_NY || x < 0 || x >= ICP_NX) continue;
+            if (z < sl.lo || z > sl.hi || y < 0 || y >= ICP_NY || x < 0 || x >= ICP_NX) continue;
             const double ez = gap(qz, G::oz + z * G::cell), ey = gap(qy, G::oy + y * G::cell), ex = gap(qx, G::ox + x * G::cell);
             if (ex * ex + ey * ey + ez * ez >= bound()) continue;
             const int c0 = icp_cell_index(x, y, z);
@@ -346,6 +412,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
     if (p >= a.n_tgt) return;
     const int sub = threadIdx.x & (ICP_SG - 1);
     const int base = (int)(threadIdx.x & 63) & ~(ICP_SG - 1);
+    const IcpSlab sl0 = icp_slab(a, 0), sl1 = icp_slab(a, 1);
     const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
     float4 out = make_float4(0.f, 0.f, 1.f, 0.f);
     const int t = threadIdx.x;
@@ -379,7 +446,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
     bool settled = false;
     if (fine)
         for (int r = 0; r <= ICP_FINE_RINGS && !settled; ++r) {
-            icp_visit_shell<1, ICP_SG>(a.g[1], fx, fy, fz, r, v.x, v.y, v.z, sub, bound_k, [&](const float4 w) { offer(dist2(w)); });
+            icp_visit_shell<1, ICP_SG>(a.g[1], sl1, fx, fy, fz, r, v.x, v.y, v.z, sub, bound_k, [&](const float4 w) { offer(dist2(w)); });
             merge_kth();
             const float lim = (float)(r * IcpLevel<1>::cell);
             settled = kth <= lim * lim;
@@ -387,7 +454,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
     const bool coarse = icp_cell_of<0>(v.x, v.y, v.z, cx, cy, cz);
     if (!settled && coarse)
         for (int r = 0; r <= ICP_NORMAL_RINGS && !settled; ++r) {
-            icp_visit_shell<0, ICP_SG>(a.g[0], cx, cy, cz, r, v.x, v.y, v.z, sub, bound_k, [&](const float4 w) {
+            icp_visit_shell<0, ICP_SG>(a.g[0], sl0, cx, cy, cz, r, v.x, v.y, v.z, sub, bound_k, [&](const float4 w) {
                 if (fine && icp_in_fine_box(w, fx, fy, fz)) return;             // already offered by the fine pass
                 offer(dist2(w));
             });
@@ -418,10 +485,10 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
         const float fine_reach = (float)(ICP_FINE_RINGS * IcpLevel<1>::cell);
         if (fine && lim <= fine_reach * fine_reach) {                           // the whole ball lies in the fine box
             const int rmax = (int)ceil(sqrt((double)lim) / IcpLevel<1>::cell);
-            for (int r = 0; r <= rmax && r <= ICP_FINE_RINGS; ++r) icp_visit_shell<1, ICP_SG>(a.g[1], fx, fy, fz, r, v.x, v.y, v.z, sub, bound_l, add);
+            for (int r = 0; r <= rmax && r <= ICP_FINE_RINGS; ++r) icp_visit_shell<1, ICP_SG>(a.g[1], sl1, fx, fy, fz, r, v.x, v.y, v.z, sub, bound_l, add);
         } else if (coarse) {
             const int rmax = (int)ceil(sqrt((double)lim) / IcpLevel<0>::cell);
-            for (int r = 0; r <= rmax && r <= ICP_NORMAL_RINGS; ++r) icp_visit_shell<0, ICP_SG>(a.g[0], cx, cy, cz, r, v.x, v.y, v.z, sub, bound_l, add);
+            for (int r = 0; r <= rmax && r <= ICP_NORMAL_RINGS; ++r) icp_visit_shell<0, ICP_SG>(a.g[0], sl0, cx, cy, cz, r, v.x, v.y, v.z, sub, bound_l, add);
         }
         cnt = icp_group_sum(cnt);
         sx = icp_group_sum(sx); sy = icp_group_sum(sy); sz = icp_group_sum(sz);
@@ -444,23 +511,38 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
 }
 
 // Gauss-Newton step of one evaluation: fitness / rmse of the current transform, convergence test, 6x6 Cholesky solve,
-// T <- exp(x) T.  One thread.
-__device__ void icp_solve_step(const IcpArgs &a, const double *sum)
+// T <- exp(x) T.  Called by the first WAVE of icp_solve (all 64 lanes, converged): lane 0 solves, lanes 0-2 take the sine and
+// cosine of one angle each.  `prev`: T and the previous evaluation's fitness / rmse / iteration count, loaded by lane 0 at the
+// start of the kernel (their round trips run under the summation).  The serial part is a chain of dependent f64 operations on
+// one lane: one reciprocal per pivot instead of a division per element (6 instead of 27) and the three sincos side by side
+// took the kernel from 50 to ~20 us.
+struct IcpPrev { double T[12], fit, rmse, iters; };
+__device__ __forceinline__ double icp_lane0(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ double icp_from_lane(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ void icp_solve_step(const IcpArgs &a, const double *sum, const IcpPrev &pv)
 {
     double *S = a.state;
+    const int lane = threadIdx.x & 63;
     const double inl = sum[28];
     const double fitness = a.n_src > 0 ? inl / a.n_src : 0.0;
     const double rmse = inl > 0 ? sqrt(sum[27] / inl) : 0.0;
     // Open3D evaluates fitness / rmse of the CURRENT transform, then updates; convergence compares successive evaluations
-    const bool first = S[21] == 0.0;
-    S[16] = fitness; S[17] = rmse;
-    if (!first && fabs(S[18] - fitness) < a.rel_fitness && fabs(S[19] - rmse) < a.rel_rmse) { S[20] = 1.0; return; }
-    S[18] = fitness; S[19] = rmse;
-    if (inl < 6) { S[20] = 1.0; return; }
+    const bool first = pv.iters == 0.0;
+    if (lane == 0) { S[16] = fitness; S[17] = rmse; }
+    const bool conv = !first && fabs(pv.fit - fitness) < a.rel_fitness && fabs(pv.rmse - rmse) < a.rel_rmse;
+    if (icp_lane0(conv ? 1.0 : 0.0) != 0.0) { if (lane == 0) S[20] = 1.0; return; }
+    if (lane == 0) { S[18] = fitness; S[19] = rmse; }
+    if (inl < 6) { if (lane == 0) S[20] = 1.0; return; }    // (uniform: sum[] is shared)
     // solve (J^T J) x = -J^T r  (Cholesky, upper triangle stored row-wise in sum[0..20]).  Every loop has a constant trip
     // count and no early exit, so the 6x6 system lives in registers (indexed dynamically it sat in scratch memory: ~100
     // dependent scratch round trips, most of the kernel's 55 us)
-    double A[6][6], b[6], x[6];
+    double A[6][6], b[6], x[6], inv[6];
     {
         int k = 0;
 #pragma unroll
@@ -478,39 +560,43 @@ __device__ void icp_solve_step(const IcpArgs &a, const double *sum)
             double s = A[i][j];
 #pragma unroll
             for (int m = 0; m < j; ++m) s -= A[i][m] * A[j][m];
-            if (i == j) { ok = ok && (s > 1e-12); A[i][i] = sqrt(ok ? s : 1.0); }
-            else A[i][j] = s / A[j][j];
+            if (i == j) { ok = ok && (s > 1e-12); A[i][i] = sqrt(ok ? s : 1.0); inv[i] = 1.0 / A[i][i]; }
+            else A[i][j] = s * inv[j];
         }
     }
-    if (!ok) { S[20] = 1.0; return; }
+    if (!ok) { if (lane == 0) S[20] = 1.0; return; }        // (uniform)
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double s = b[i];
 #pragma unroll
         for (int m = 0; m < i; ++m) s -= A[i][m] * x[m];
-        x[i] = s / A[i][i];
+        x[i] = s * inv[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = x[i];
 #pragma unroll
         for (int m = i + 1; m < 6; ++m) s -= A[m][i] * x[m];
-        x[i] = s / A[i][i];
+        x[i] = s * inv[i];
     }
-    // x = (alpha, beta, gamma, tx, ty, tz): R = Rz(gamma) Ry(beta) Rx(alpha)
-    const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+    // x = (alpha, beta, gamma, tx, ty, tz): R = Rz(gamma) Ry(beta) Rx(alpha); lane l takes sin / cos of angle l
+    const double ang = lane == 0 ? x[0] : lane == 1 ? x[1] : x[2];
+    const double sn = sin(ang), cs = cos(ang);
+    const double sa = icp_from_lane(sn, 0), ca = icp_from_lane(cs, 0), sb = icp_from_lane(sn, 1), cb = icp_from_lane(cs, 1),
+                 sg = icp_from_lane(sn, 2), cg = icp_from_lane(cs, 2);
     const double U[12] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa, x[3],
                           sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa, x[4],
                           -sb, cb * sa, cb * ca, x[5]};
-    double N[12];
+    if (lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 12; ++i) S[32 + i] = pv.T[i];   // (icp_match: how far has a point moved since the last pass?)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            N[4 * i + j] = U[4 * i] * S[j] + U[4 * i + 1] * S[4 + j] + U[4 * i + 2] * S[8 + j] + (j == 3 ? U[4 * i + 3] : 0.0);
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int i = 0; i < 12; ++i) S[i] = N[i];
-    S[21] += 1.0;
+            for (int j = 0; j < 4; ++j)
+                S[4 * i + j] = U[4 * i] * pv.T[j] + U[4 * i + 1] * pv.T[4 + j] + U[4 * i + 2] * pv.T[8 + j] + (j == 3 ? U[4 * i + 3] : 0.0);
+        S[21] = pv.iters + 1.0;
+    }
 }
 
 // icp_match: ICP_SG neighbouring lanes share one source point.  The own cell's records and the rows of every further
@@ -518,165 +604,309 @@ __device__ void icp_solve_step(const IcpArgs &a, const double *sum)
 // on the group's best (DPP butterfly inside the 8 lanes), which tightens everybody's cull bound and decides whether the
 // search has settled.  One lane per query was a chain of dependent loads and row walks as long as the worst query of its
 // wave (~0.8 ms per pass at < 2 waves per SIMD).  Ties: lowest ORIGINAL index (the order inside a cell varies from run
-// to run).
-__device__ __forceinline__ void icp_group_best(double &best, int &bidx)
+// to run).  The partner's coordinates travel with its distance (they are in the record that was scanned: re-reading the
+// target by index afterwards is one more memory round trip at the end of the query's chain).
+struct IcpBest { double d2; int idx; float x, y, z; };
+__device__ __forceinline__ void icp_group_best(IcpBest &b)
 {
 #define ICP_BEST_STAGE(S)                                                                                              \
     {                                                                                                                  \
-        const uint32_t lo = lane_xor_fetch<S>((uint32_t)__double2loint(best)), hi = lane_xor_fetch<S>((uint32_t)__double2hiint(best)); \
-        const int oi = (int)lane_xor_fetch<S>((uint32_t)bidx);                                                         \
+        const uint32_t lo = lane_xor_fetch<S>((uint32_t)__double2loint(b.d2)), hi = lane_xor_fetch<S>((uint32_t)__double2hiint(b.d2)); \
+        const int oi = (int)lane_xor_fetch<S>((uint32_t)b.idx);                                                        \
+        const float ox = __uint_as_float(lane_xor_fetch<S>(__float_as_uint(b.x))), oy = __uint_as_float(lane_xor_fetch<S>(__float_as_uint(b.y))), \
+                    oz = __uint_as_float(lane_xor_fetch<S>(__float_as_uint(b.z)));                                     \
         const double od = __hiloint2double((int)hi, (int)lo);                                                          \
-        if (oi >= 0 && (bidx < 0 || od < best || (od == best && oi < bidx))) { best = od; bidx = oi; }                 \
+        if (oi >= 0 && (b.idx < 0 || od < b.d2 || (od == b.d2 && oi < b.idx))) { b.d2 = od; b.idx = oi; b.x = ox; b.y = oy; b.z = oz; } \
     }
     ICP_BEST_STAGE(1) ICP_BEST_STAGE(2) ICP_BEST_STAGE(4)
 #undef ICP_BEST_STAGE
 }
 
+// (the group's nearest G, and the smallest distance any lane has seen of a target that is not G)
+__device__ __forceinline__ void icp_group_merge(IcpBest &b, double &other)
+{
+    const IcpBest mine = b;
+    icp_group_best(b);
+    // this lane's nearest that is not G: its best -- unless that IS G (it found G, or a second copy of it)
+    double c = other;
+    if (mine.idx >= 0 && mine.idx != b.idx && mine.d2 < c) c = mine.d2;
+#define ICP_MIN_STAGE(S)                                                                                               \
+    {                                                                                                                  \
+        const double od = __hiloint2double((int)lane_xor_fetch<S>((uint32_t)__double2hiint(c)), (int)lane_xor_fetch<S>((uint32_t)__double2loint(c))); \
+        c = od < c ? od : c;                                                                                           \
+    }
+    ICP_MIN_STAGE(1) ICP_MIN_STAGE(2) ICP_MIN_STAGE(4)
+#undef ICP_MIN_STAGE
+    other = c;
+}
+
+// One pass = icp_match + icp_solve.  icp_match also turns every correspondence into its point-to-plane row
+// (r = (q - t).n, J = [q x n, n]) and leaves the workgroup's sums of J^T J, J^T r, |q - t|^2, pair count, r^2 as one column
+// of partial sums (fixed order: queries of a workgroup in ascending order, four at a time); icp_solve adds the columns up
+// (fixed order again: the result does not depend on timing) and takes the Gauss-Newton step.  (Round 2 had a third kernel
+// between the two -- one thread per source point re-reading partner and normal by index, 512 rows, the last workgroup to
+// arrive adding them up and solving: 35 us per pass, most of it that serial tail.)
+//
+// From the second pass on a query first asks whether the result of the last pass PROVABLY stands.  The last search left a
+// slack: with d1 the distance to the nearest target, every OTHER target was at least d1 + 2 slack away.  The query has moved
+// by delta = |T p - T_old p| since: the old partner is at most d1 + delta away now, every other target at least
+// d1 + 2 slack - delta -- while the movements since the search add up to less than the slack the partner is the unique
+// nearest: no search, the slack shrinks by delta.  A query WITHOUT a partner (nothing within the distance cap inside its
+// search box) stays without one while it stays in its coarse cell -- the box is a function of that cell -- and has moved less
+// than the margin by which the box's points lay beyond the cap.  To have a slack, the search culls cells against
+// (d1 + ICP_MARGIN)^2 instead of d1^2 -- everything within ICP_MARGIN of the nearest is seen, at the price of the few cells
+// that 2 cm more reach -- and keeps the smallest distance `other` of a seen target that is not the nearest: every other target
+// is at least min(other, d1 + ICP_MARGIN, r cell) away, r the last ring visited.
+// Measured on consecutive ring-model sweeps (tools/experiments/icp_skip_potential.py, PCA_ICP_DBG=1): the updates move the
+// points by 0.67 m, 0.14 m, 23 mm, 4 mm, 0.7 mm, 0.17 mm, ... against a median slack of 4.7 mm; searched queries per pass:
+// 120 000 x 4, 53 301, 18 831, 6 753, 2 584, 594.  The skipped search would have returned the same partner (it is the unique
+// nearest), and distance and row are computed by the same expressions: the pose is bit-identical with and without the shortcut
+// (PCA_ICP_NO_SKIP=1 switches it off: A/B).
+#define ICP_QPW (ICP_THREADS / ICP_SG)   // queries per workgroup of icp_match
+#define ICP_MARGIN 0.02                  // [m]
 __global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
 {
+    __shared__ double s_row[ICP_QPW][8];                    // per query: J[0..5], r, |q - t|^2
+    __shared__ uint32_t s_flag[ICP_QPW];                    // bit 0: has a partner, bit 1: the partner has a normal
+    __shared__ double s_part[ICP_QPW / 4][32];
     if (a.state[20] != 0.0) return;                         // converged: the remaining passes are no-ops
     const double *T = a.state;
     const int sub = threadIdx.x & (ICP_SG - 1);
-    const int p = (blockIdx.x * ICP_THREADS + threadIdx.x) / ICP_SG;
-    if (p >= a.n_src) return;
-    const float4 v = reinterpret_cast<const float4 *>(a.src)[p];
-    const double qx = T[0] * v.x + T[1] * v.y + T[2] * v.z + T[3];
-    const double qy = T[4] * v.x + T[5] * v.y + T[6] * v.z + T[7];
-    const double qz = T[8] * v.x + T[9] * v.y + T[10] * v.z + T[11];
-    double best = a.max_dist2;
-    int bidx = -1;
-    auto bound = [&]() { return best * (1.0 + 1e-12) + 1e-300; };
-    auto offer = [&](const float4 w) {
-        const double dx = w.x - qx, dy = w.y - qy, dz = w.z - qz;
-        const double d2 = dx * dx + dy * dy + dz * dz;
-        const int wi = __float_as_int(w.w);
-        if (d2 < best || (d2 == best && bidx >= 0 && wi < bidx)) { best = d2; bidx = wi; }
-    };
-    // warm start: the previous iteration's partner bounds the search from the first cell on (the transform moved by a
-    // fraction of a cell), so nearly every cell is culled; the result is still the exact nearest neighbour
-    // (first pass: the target point of the same index -- consecutive sweeps share their scan order -- provided the search
-    // below would reach it: inside the coarse grid and within the match cap; any such point is a valid upper bound)
-    int prev = a.nn_prev[p];
-    const bool first = prev == (int)0xfefefefe;
-    if (first) prev = p < a.n_tgt ? p : -1;
-    if (prev >= 0) {
-        const float4 t = reinterpret_cast<const float4 *>(a.tgt)[prev];
-        const double dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
-        constexpr double cap = ICP_MATCH_RINGS * IcpLevel<0>::cell;
-        int tx, ty, tz;
-        if (!first || (dx * dx + dy * dy + dz * dz <= cap * cap && icp_cell_of<0>(t.x, t.y, t.z, tx, ty, tz)))
-            offer(make_float4(t.x, t.y, t.z, __int_as_float(prev)));
+    const int ql = threadIdx.x / ICP_SG;                    // query of the workgroup
+    const int p = blockIdx.x * ICP_QPW + ql;
+    IcpBest b;
+    b.d2 = a.max_dist2; b.idx = -1; b.x = b.y = b.z = 0.f;
+    double qx = 0, qy = 0, qz = 0;
+    bool need = false;
+    if (p < a.n_src) {                                      // (uniform inside a group of eight lanes, as is everything up to the search)
+        const float4 v = reinterpret_cast<const float4 *>(a.src)[p];
+        int prev = a.nn_prev[p];
+        const int cell_ref = a.nn_cell[p];
+        const float slack0 = a.nn_slack[p];
+        qx = T[0] * v.x + T[1] * v.y + T[2] * v.z + T[3];
+        qy = T[4] * v.x + T[5] * v.y + T[6] * v.z + T[7];
+        qz = T[8] * v.x + T[9] * v.y + T[10] * v.z + T[11];
+        const bool first = prev == (int)0xfefefefe;
+        if (first) prev = p < a.n_tgt ? p : -1;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (prev >= 0) t = reinterpret_cast<const float4 *>(a.tgt)[prev];
+        int cx, cy, cz;
+        const bool in_coarse = icp_cell_of<0>(qx, qy, qz, cx, cy, cz);
+        need = true;
+        if (!first && !a.no_skip && slack0 > 0.f) {
+            const double *O = a.state + 32;                 // T of the last pass
+            const double mx = qx - (O[0] * v.x + O[1] * v.y + O[2] * v.z + O[3]);
+            const double my = qy - (O[4] * v.x + O[5] * v.y + O[6] * v.z + O[7]);
+            const double mz = qz - (O[8] * v.x + O[9] * v.y + O[10] * v.z + O[11]);
+            const double left = (double)slack0 - sqrt(mx * mx + my * my + mz * mz) * (1.0 + 1e-9) - 1e-12;
+            if (left > 0.0) {
+                if (prev >= 0) {
+                    const double dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 < a.max_dist2) { need = false; b.d2 = d2; b.idx = prev; b.x = t.x; b.y = t.y; b.z = t.z; }   // (else the search decides)
+                } else if ((in_coarse ? icp_cell_index(cx, cy, cz) : -1) == cell_ref) {
+                    need = false;                           // still nothing within the cap in the same box
+                }
+                if (!need && sub == 0) a.nn_slack[p] = (float)(left * (1.0 - 1e-6));
+            }
+        }
+        if (need) {
+            const IcpSlab sl0 = icp_slab(a, 0), sl1 = icp_slab(a, 1);
+            const double max_dist = sqrt(a.max_dist2);
+            // (no slack is collected in the first two passes -- the updates that follow them move the points by decimetres, no
+            // partner survives that -- so they cull against d1 itself, as a search without the shortcut would)
+            const double mg = a.state[21] >= 2.0 ? ICP_MARGIN : 0.0;
+            double other = 1e300;                           // smallest squared distance of a seen target that is not the nearest
+            double bnd = (max_dist + mg) * (max_dist + mg);     // cull bound: (d1 + margin)^2, d1 = the cap while there is no partner
+            auto bound = [&]() { return bnd; };
+            auto offer = [&](const float4 w) {
+                const int wi = __float_as_int(w.w);
+                if (wi == b.idx) return;                    // the nearest so far, met again (both grids hold every point)
+                const double dx = w.x - qx, dy = w.y - qy, dz = w.z - qz;
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 < b.d2 || (d2 == b.d2 && b.idx >= 0 && wi < b.idx)) {
+                    if (b.idx >= 0) other = b.d2;           // (the old nearest: not farther than anything seen before)
+                    b.d2 = d2; b.idx = wi; b.x = w.x; b.y = w.y; b.z = w.z;
+                    // (d1 + margin)^2 from above: d2 + 2 margin s + margin^2 with s >= sqrt(d2) (a single-precision root, rounded up)
+                    const double s1 = (double)(sqrtf((float)d2) * 1.000001f) + 1e-30;
+                    bnd = (d2 + 2.0 * mg * s1 + mg * mg) * (1.0 + 1e-12) + 1e-300;
+                } else if (d2 < other) {
+                    other = d2;
+                }
+            };
+            // warm start: the partner of the last pass bounds the search from the first cell on (the transform moved by a
+            // fraction of a cell), so nearly every cell is culled; the result is still the exact nearest neighbour
+            // (first pass: the target point of the same index -- consecutive sweeps share their scan order -- provided the search
+            // below would reach it: inside the coarse grid and within the match cap; any such point is a valid upper bound)
+            if (prev >= 0) {
+                const double dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
+                constexpr double cap = ICP_MATCH_RINGS * IcpLevel<0>::cell;
+                int tx, ty, tz;
+                if (!first || (dx * dx + dy * dy + dz * dz <= cap * cap && icp_cell_of<0>(t.x, t.y, t.z, tx, ty, tz)))
+                    offer(make_float4(t.x, t.y, t.z, __int_as_float(prev)));
+            }
+            int fx, fy, fz;
+            bool settled = false;
+            double reach = 0.0;                             // every target within this distance has been offered (or culled)
+            auto merged = [&]() {                           // the group's nearest, its `other`, the bound that follows
+                icp_group_merge(b, other);
+                if (b.idx >= 0) {
+                    const double s1 = (double)(sqrtf((float)b.d2) * 1.000001f) + 1e-30;
+                    bnd = (b.d2 + 2.0 * mg * s1 + mg * mg) * (1.0 + 1e-12) + 1e-300;
+                }
+            };
+            if (icp_fine_box(qx, qy, qz, fx, fy, fz))
+                for (int r = 0; r <= ICP_FINE_RINGS && !settled; ++r) {
+                    icp_visit_shell<1, ICP_SG>(a.g[1], sl1, fx, fy, fz, r, qx, qy, qz, sub, bound, offer);
+                    merged();
+                    reach = r * IcpLevel<1>::cell;
+                    settled = b.idx >= 0 && b.d2 <= reach * reach;
+                }
+            if (!settled && in_coarse)
+                for (int r = 0; r <= ICP_MATCH_RINGS && !settled; ++r) {
+                    icp_visit_shell<0, ICP_SG>(a.g[0], sl0, cx, cy, cz, r, qx, qy, qz, sub, bound, offer);   // re-offering a point is harmless
+                    merged();
+                    reach = r * IcpLevel<0>::cell;
+                    settled = b.idx >= 0 && b.d2 <= reach * reach;
+                }
+            if (sub == 0) {
+                a.nn_prev[p] = b.idx;
+                a.nn_cell[p] = in_coarse ? icp_cell_index(cx, cy, cz) : -1;
+                double slack;
+                const double oth = sqrt(other);             // (1e150 if nothing else was seen)
+                if (b.idx >= 0) {
+                    // every other target is at least min(other, d1 + margin, reach) away: half of what that leaves above d1
+                    const double d1 = sqrt(b.d2);
+                    double far = d1 + mg;
+                    far = oth < far ? oth : far;
+                    far = reach < far ? reach : far;
+                    slack = 0.5 * (far - d1);
+                } else {
+                    // nothing within the cap: every target of the box is at least min(other, cap + margin) away
+                    double far = max_dist + mg;
+                    far = oth < far ? oth : far;
+                    slack = far - max_dist;
+                }
+                slack = slack * (1.0 - 1e-6) - 1e-9;
+                a.nn_slack[p] = slack > 0.0 ? (float)(slack * (1.0 - 1e-6)) : 0.f;
+            }
+        }
     }
-    int fx, fy, fz, cx, cy, cz;
-    bool settled = false;
-    if (icp_fine_box(qx, qy, qz, fx, fy, fz))
-        for (int r = 0; r <= ICP_FINE_RINGS && !settled; ++r) {
-            icp_visit_shell<1, ICP_SG>(a.g[1], fx, fy, fz, r, qx, qy, qz, sub, bound, offer);
-            icp_group_best(best, bidx);
-            settled = bidx >= 0 && best <= (r * IcpLevel<1>::cell) * (r * IcpLevel<1>::cell);
+    if (a.dbg) { const uint64_t m = __ballot(need && sub == 0); if ((threadIdx.x & 63) == 0 && m) { const int it = (int)a.state[21]; atomicAdd(&a.state[48 + (it < 15 ? it : 15)], (double)__popcll(m)); } }
+    // the query's row (one lane of its group)
+    if (sub == 0) {
+        uint32_t flag = 0u;
+        double J[6] = {0, 0, 0, 0, 0, 0}, r = 0.0;
+        if (b.idx >= 0) {
+            flag = 1u;                                      // Open3D: fitness / rmse over all correspondences
+            const float4 nn = reinterpret_cast<const float4 *>(a.normal)[b.idx];
+            if (nn.w != 0.f) {                              // (no normal: the pair carries no point-to-plane row)
+                flag = 3u;
+                const double nx = nn.x, ny = nn.y, nz = nn.z;
+                r = (qx - b.x) * nx + (qy - b.y) * ny + (qz - b.z) * nz;
+                J[0] = qy * nz - qz * ny; J[1] = qz * nx - qx * nz; J[2] = qx * ny - qy * nx; J[3] = nx; J[4] = ny; J[5] = nz;
+            }
         }
-    if (!settled && icp_cell_of<0>(qx, qy, qz, cx, cy, cz))
-        for (int r = 0; r <= ICP_MATCH_RINGS && !settled; ++r) {
-            icp_visit_shell<0, ICP_SG>(a.g[0], cx, cy, cz, r, qx, qy, qz, sub, bound, offer);   // re-offering a point is harmless
-            icp_group_best(best, bidx);
-            settled = bidx >= 0 && best <= (r * IcpLevel<0>::cell) * (r * IcpLevel<0>::cell);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s_row[ql][i] = J[i];
+        s_row[ql][6] = r;
+        s_row[ql][7] = b.d2;
+        s_flag[ql] = flag;
+    }
+    __syncthreads();
+    // accumulator k (the 21 products of J^T J row-wise, the 6 of J^T r, |q - t|^2, pairs, r^2) of four queries per thread
+    {
+        const int k = threadIdx.x & 31, part = threadIdx.x >> 5;        // ICP_QPW / 4 = 8 parts of four queries
+        int i = 0, j = 0;                                   // k < 21: the pair (i, j), i <= j, row-wise
+        {
+            int kk = k;
+            for (i = 0; i < 6 && kk >= 6 - i; ++i) kk -= 6 - i;
+            j = i + kk;
         }
-    if (sub == 0) { a.nn_prev[p] = bidx; a.nn_d2[p] = best; }
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = part * 4 + u;
+            const uint32_t f = s_flag[q];
+            double term = 0.0;
+            if (k < 21) term = (f & 2u) ? s_row[q][i] * s_row[q][j] : 0.0;
+            else if (k < 27) term = (f & 2u) ? s_row[q][k - 21] * s_row[q][6] : 0.0;
+            else if (k == 27) term = (f & 1u) ? s_row[q][7] : 0.0;
+            else if (k == 28) term = (f & 1u) ? 1.0 : 0.0;
+            else if (k == 29) term = (f & 2u) ? s_row[q][6] * s_row[q][6] : 0.0;
+            acc += term;
+        }
+        s_part[part][k] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < ICP_NACC) {
+        double v = 0.0;
+#pragma unroll
+        for (int part = 0; part < ICP_QPW / 4; ++part) v += s_part[part][threadIdx.x];
+        a.partial[(size_t)threadIdx.x * a.grid + blockIdx.x] = v;   // [accumulator][workgroup]: icp_solve reads rows of it coalesced
+    }
 }
 
-// icp_accumulate: one thread per source point turns its correspondence into a point-to-plane row; fixed-order reduction:
-// lanes (butterfly), waves (serial), workgroups (serial, by the last one to arrive) -> deterministic; that last workgroup
-// also takes the Gauss-Newton step, so an iteration is two launches and the loop never leaves the device.
-__global__ __launch_bounds__(ICP_THREADS) void icp_accumulate(const IcpArgs a)
+// icp_solve: workgroup k adds up accumulator k over the workgroups of icp_match in a fixed order (thread t: columns t, t + 256,
+// ... ascending; lanes: butterfly; waves: ascending); the last workgroup to finish takes the Gauss-Newton step.  (One
+// workgroup reading all thirty rows -- 450 KB through one CU's 64 B per clock -- and then solving took 30 us.)
+#define ICP_SOLVE_THREADS 256
+__global__ __launch_bounds__(ICP_SOLVE_THREADS) void icp_solve(const IcpArgs a)
 {
-    __shared__ double s_red[ICP_THREADS / 64][ICP_NACC];
-    __shared__ double s_sum[ICP_NACC];
+    __shared__ double s_red[ICP_SOLVE_THREADS / 64];
+    __shared__ double s_sum[32];
     __shared__ int s_last;
     if (a.state[20] != 0.0) return;
-    double acc[ICP_NACC];
+    IcpPrev pv;
+    if (threadIdx.x < 64) {                                 // (every lane of wave 0 holds them: the values are uniform)
 #pragma unroll
-    for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
-    const double *T = a.state;
-    for (int p = blockIdx.x * ICP_THREADS + threadIdx.x; p < a.n_src; p += a.grid * ICP_THREADS) {
-        const int bidx = a.nn_prev[p];
-        if (bidx < 0) continue;
-        const float4 v = reinterpret_cast<const float4 *>(a.src)[p];
-        const float4 w = reinterpret_cast<const float4 *>(a.tgt)[bidx];
-        const float4 nn = reinterpret_cast<const float4 *>(a.normal)[bidx];
-        const double qx = T[0] * v.x + T[1] * v.y + T[2] * v.z + T[3];
-        const double qy = T[4] * v.x + T[5] * v.y + T[6] * v.z + T[7];
-        const double qz = T[8] * v.x + T[9] * v.y + T[10] * v.z + T[11];
-        acc[27] += a.nn_d2[p];                              // Open3D: fitness / rmse over all correspondences
-        acc[28] += 1.0;
-        if (nn.w == 0.f) continue;                          // no normal: the pair carries no point-to-plane row
-        const double nx = nn.x, ny = nn.y, nz = nn.z;
-        const double r = (qx - w.x) * nx + (qy - w.y) * ny + (qz - w.z) * nz;
-        const double J[6] = {qy * nz - qz * ny, qz * nx - qx * nz, qx * ny - qy * nx, nx, ny, nz};
-        int k = 0;
+        for (int i = 0; i < 12; ++i) pv.T[i] = a.state[i];
+        pv.fit = a.state[18]; pv.rmse = a.state[19]; pv.iters = a.state[21];
+    }
+    const int k = blockIdx.x;
+    const double *row = a.partial + (size_t)k * a.grid;
+    double acc = 0.0;
+    for (int b0 = 0; b0 < a.grid; b0 += 4 * ICP_SOLVE_THREADS) {        // four loads in flight, added in ascending order
+        double v[4];
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int u = 0; u < 4; ++u) { const int b = b0 + u * ICP_SOLVE_THREADS + (int)threadIdx.x; v[u] = b < a.grid ? row[b] : 0.0; }
 #pragma unroll
-            for (int j = i; j < 6; ++j) acc[k++] += J[i] * J[j];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) acc[21 + i] += J[i] * r;
-        acc[29] += r * r;
+        for (int u = 0; u < 4; ++u) acc += v[u];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    auto block_sum = [&](double *out, bool to_global) {     // acc[] of the workgroup -> out[0..NACC)
-#pragma unroll
-        for (int k = 0; k < ICP_NACC; ++k) {
-            double v = acc[k];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0) s_red[wave][k] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < ICP_NACC) {
-            double v = 0.0;
-            for (int w = 0; w < ICP_THREADS / 64; ++w) v += s_red[w][threadIdx.x];
-            out[threadIdx.x] = v;
-            if (to_global) __threadfence();                 // release at agent scope by the (one) wave that wrote the row
-        }
-    };
-    // the row of partial sums is released by the wave that wrote it; the arrival counter follows after the barrier
-    block_sum(a.partial + (size_t)blockIdx.x * ICP_NACC, true);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) s_red[wave] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
+        double v = 0.0;
+        for (int w = 0; w < ICP_SOLVE_THREADS / 64; ++w) v += s_red[w];
+        double *sums = a.state + 64;
+        __hip_atomic_store(&sums[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();                                    // release at agent scope: the sum, then the arrival
         const uint32_t t = atomicAdd(a.arrived, 1u);
         s_last = (t == gridDim.x - 1);
         if (s_last) __hip_atomic_store(a.arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();                                        // acquire: the rows the other XCDs released
-    // thread t adds up the rows t, t + 256, ... (ascending), then the same lanes -> waves reduction: a fixed order
-#pragma unroll
-    for (int k = 0; k < ICP_NACC; ++k) acc[k] = 0.0;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += ICP_THREADS) {
-        const double2 *row = reinterpret_cast<const double2 *>(a.partial + (size_t)b * ICP_NACC);
-        double2 rv[ICP_NACC / 2];
-#pragma unroll
-        for (int k = 0; k < ICP_NACC / 2; ++k) rv[k] = row[k];
-#pragma unroll
-        for (int k = 0; k < ICP_NACC / 2; ++k) { acc[2 * k] += rv[k].x; acc[2 * k + 1] += rv[k].y; }
-    }
+    __threadfence();                                        // acquire: the sums the other XCDs released
+    if (threadIdx.x < 32) s_sum[threadIdx.x] = threadIdx.x < ICP_NACC ? __hip_atomic_load(a.state + 64 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     __syncthreads();
-    block_sum(s_sum, false);
-    __syncthreads();
-    if (threadIdx.x == 0) icp_solve_step(a, s_sum);
+    if (threadIdx.x < 64) icp_solve_step(a, s_sum, pv);
 }
 
 extern "C" {
 
 static inline int64_t icp_align(int64_t v) { return (v + 255) & ~255ll; }
-static inline int icp_grid(int n) { const int g = (n + ICP_THREADS - 1) / ICP_THREADS; return g < 1 ? 1 : (g > ICP_MAX_GRID ? ICP_MAX_GRID : g); }
+static inline int icp_grid(int n) { return (n + ICP_QPW - 1) / ICP_QPW; }   // workgroups of icp_match = columns of partial sums
 
 int64_t pca_icp_workspace_bytes(int32_t max_points)
 {
     if (max_points < 1) max_points = 1;
     return 2 * (icp_align(ICP_CELLS * 4) + icp_align((ICP_CELLS + 1) * 4) + icp_align((int64_t)max_points * 16)) +
-           icp_align((int64_t)max_points * 16) + icp_align((int64_t)max_points * 4) + icp_align((int64_t)max_points * 8) +
-           icp_align((int64_t)ICP_MAX_GRID * ICP_NACC * 8) +
-           icp_align(32 * 8) + 512;
+           icp_align((int64_t)max_points * 16) + 3 * icp_align((int64_t)max_points * 4) +
+           icp_align((int64_t)icp_grid(max_points) * ICP_NACC * 8) +
+           icp_align(128 * 8) + 512;
 }
 
 int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const float *tgt_pts, int32_t n_tgt,
@@ -701,42 +931,45 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
     }
     a.normal = reinterpret_cast<float *>(w); w += icp_align((int64_t)n_tgt * 16);
     a.nn_prev = reinterpret_cast<int32_t *>(w); w += icp_align((int64_t)n_src * 4);
-    a.nn_d2 = reinterpret_cast<double *>(w); w += icp_align((int64_t)n_src * 8);
-    a.partial = reinterpret_cast<double *>(w); w += icp_align((int64_t)ICP_MAX_GRID * ICP_NACC * 8);
+    a.nn_cell = reinterpret_cast<int32_t *>(w); w += icp_align((int64_t)n_src * 4);
+    a.nn_slack = reinterpret_cast<float *>(w); w += icp_align((int64_t)n_src * 4);
+    { static int ns = -1; if (ns < 0) { const char *e = getenv("PCA_ICP_NO_SKIP"); ns = e ? atoi(e) : 0; } a.no_skip = ns; }
+    { static int dg = -1; if (dg < 0) { const char *e = getenv("PCA_ICP_DBG"); dg = e ? atoi(e) : 0; } a.dbg = dg; }
+    a.partial = reinterpret_cast<double *>(w); w += icp_align((int64_t)icp_grid(n_src) * ICP_NACC * 8);
     a.state = reinterpret_cast<double *>(w);
-    a.arrived = reinterpret_cast<uint32_t *>(a.state + 24);            // zero with the state block
+    a.zr = reinterpret_cast<uint32_t *>(a.state + 24);                 // initialised with the state block
+    a.status = ctx->ticket + 1;
+    a.arrived = reinterpret_cast<uint32_t *>(a.state + 27);            // zero with the state block
     a.max_dist2 = max_corr_dist * max_corr_dist;
     a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse;
     a.grid = icp_grid(n_src);
-    double st[32] = {0};
+    double st[64] = {0};
     static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     for (int i = 0; i < 16; ++i) st[i] = init ? init[i] : eye[i];
+    {
+        const uint32_t zr0[4] = {0xffffffffu, 0u, 0xffffffffu, 0u};       // zmin, zmax + 1 of both grids: nothing seen yet
+        memcpy(&st[24], zr0, sizeof zr0);
+    }
     PCA_CHECK(ctx, hipMemsetAsync(a.g[0].cnt, 0, (size_t)cells * 4, s));
     PCA_CHECK(ctx, hipMemsetAsync(a.g[1].cnt, 0, (size_t)cells * 4, s));
     PCA_CHECK(ctx, hipMemsetAsync(a.nn_prev, 0xfe, (size_t)n_src * 4, s));        // 0xfefefefe: "first pass" (see icp_match)
     PCA_CHECK(ctx, hipMemcpyAsync(a.state, st, sizeof st, hipMemcpyHostToDevice, s));
     const int scan_tiles = (int)(cells / ICP_SCAN_TILE);
-    if (pca_ctx_reserve_tiles(ctx, scan_tiles, s)) return -1;
+    if (pca_ctx_reserve_tiles(ctx, 2 * scan_tiles, s)) return -1;
     a.lb_state = ctx->tile_state;
-    a.ticket = ctx->ticket;
     const dim3 per_point((n_tgt + ICP_THREADS - 1) / ICP_THREADS);
-    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_count<0>, per_point, dim3(ICP_THREADS), s, a);
-    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_count<1>, per_point, dim3(ICP_THREADS), s, a);
-    for (int lv = 0; lv < 2; ++lv) {
-        a.scan_level = lv;
-        a.epoch = pca_ctx_next_epoch(ctx, s);
-        PCA_LAUNCH(ctx, PCA_K_ICP, icp_cell_scan, dim3(scan_tiles), dim3(ICP_SCAN_THREADS), s, a);
-    }
-    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_fill<0>, per_point, dim3(ICP_THREADS), s, a);
-    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_fill<1>, per_point, dim3(ICP_THREADS), s, a);
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_count, per_point, dim3(ICP_THREADS), s, a);
+    a.epoch = pca_ctx_next_epoch(ctx, s);
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_cell_scan, dim3(2 * scan_tiles), dim3(ICP_SCAN_THREADS), s, a);
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_fill, per_point, dim3(ICP_THREADS), s, a);
     PCA_LAUNCH(ctx, PCA_K_ICP, icp_normals, dim3(((int64_t)n_tgt * ICP_SG + ICP_THREADS - 1) / ICP_THREADS), dim3(ICP_THREADS), s, a);
     // one more evaluation than updates: Open3D reports fitness / rmse of the final transform.  The loop never leaves the
     // device inside a group of ICP_CHECK_EVERY passes; between groups the host reads the convergence flag (a pass after
     // convergence is a no-op, the check only saves launching the rest of the 31)
     for (int it = 0; it <= max_iter; ++it) {
         if (it == max_iter) a.rel_fitness = a.rel_rmse = 1e300;              // last pass only evaluates
-        PCA_LAUNCH(ctx, PCA_K_ICP, icp_match, dim3(((int64_t)n_src * ICP_SG + ICP_THREADS - 1) / ICP_THREADS), dim3(ICP_THREADS), s, a);
-        PCA_LAUNCH(ctx, PCA_K_ICP, icp_accumulate, dim3(a.grid), dim3(ICP_THREADS), s, a);
+        PCA_LAUNCH(ctx, PCA_K_ICP, icp_match, dim3(a.grid), dim3(ICP_THREADS), s, a);
+        PCA_LAUNCH(ctx, PCA_K_ICP, icp_solve, dim3(ICP_NACC), dim3(ICP_SOLVE_THREADS), s, a);
         if (it % ICP_CHECK_EVERY == ICP_CHECK_EVERY - 1 && it < max_iter) {
             PCA_CHECK(ctx, hipMemcpyAsync(st, a.state, sizeof st, hipMemcpyDeviceToHost, s));
             PCA_CHECK(ctx, hipStreamSynchronize(s));
@@ -746,6 +979,7 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
     PCA_CHECK(ctx, hipMemcpyAsync(st, a.state, sizeof st, hipMemcpyDeviceToHost, s));
     PCA_CHECK(ctx, hipStreamSynchronize(s));
     for (int i = 0; i < 12; ++i) T_out[i] = st[i];
+    if (a.dbg) { fprintf(stderr, "icp: searched queries per pass:"); for (int i = 0; i < 16; ++i) fprintf(stderr, " %.0f", st[48 + i]); fprintf(stderr, "\n"); }
     T_out[12] = T_out[13] = T_out[14] = 0.0; T_out[15] = 1.0;
     if (fitness) *fitness = st[16];
     if (rmse) *rmse = st[17];

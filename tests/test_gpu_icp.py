@@ -200,3 +200,46 @@ def test_icp_search_cap_against_the_uncapped_model(step, tol):
     assert rot_err_deg(res.transformation[:3, :3] @ T_ref[:3, :3].T) < 60 * tol
     T_true = np.linalg.inv(pose_T(step, 0.04, 0.01))
     assert np.linalg.norm(res.transformation[:3, 3] - T_true[:3, 3]) < 0.02 + 0.03 * step      # (7 cm at 3 m, either model)
+
+
+def _register_pairs_for_child():
+    """(run in a child process by the test below) poses, fitness, rmse, iterations of a few registrations, printed as hex."""
+    import torch  # noqa: F401
+    from pca_amd.icp import GpuIcp
+    out = []
+    for (x1, yaw1, seed, shift_z) in ((0.9, 0.010, 1, 0.0), (0.4, -0.02, 5, 0.0), (1.6, 0.03, 9, 6.5)):
+        a = sweep(0.0, 0.0, 0.0, seed)
+        b = sweep(x1, 0.05, yaw1, seed + 100)
+        a[:, 2] += shift_z                                   # (the last pair sits in other slabs of the grids)
+        b[:, 2] += shift_z
+        r = GpuIcp().register(GpuIcp.to_device(a), GpuIcp.to_device(b), 1e3, np.eye(4))
+        out.append(np.concatenate([r.transformation.ravel(), [r.fitness, r.inlier_rmse, float(r.iterations)]]))
+    print('ICPHEX ' + np.stack(out).astype(np.float64).tobytes().hex())
+
+
+def test_icp_shortcut_is_bit_identical_to_searching_every_pass():
+    """From the third pass on a query keeps its partner without a search when it provably is still the unique nearest target
+    (csrc/pca_icp.hip, icp_match).  PCA_ICP_NO_SKIP=1 (read once per process) searches every query in every pass: poses,
+    fitness, rmse and iteration counts of both forms are equal bit for bit, and the shortcut does take place (PCA_ICP_DBG=1
+    prints the searched queries per pass)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ('import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_icp as t; t._register_pairs_for_child()'
+            % (here, os.path.join(os.path.dirname(here), 'pc-accumulation-lib_amd')))
+    res = {}
+    for name, extra in (('skip', {'PCA_ICP_DBG': '1'}), ('search', {'PCA_ICP_NO_SKIP': '1', 'PCA_ICP_DBG': '1'})):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('ICPHEX ')][-1]
+        counts = [[float(v) for v in ln.split(':')[-1].split()] for ln in r.stderr.splitlines() if ln.startswith('icp: searched')]
+        res[name] = (bytes.fromhex(line.split()[1]), counts)
+    assert res['skip'][0] == res['search'][0]
+    vals = np.frombuffer(res['skip'][0], np.float64).reshape(3, 19)
+    assert np.all(vals[:, 18] >= 3) and np.all(vals[:, 16] > 0.5)            # real registrations: iterations, fitness
+    for with_skip, without in zip(res['skip'][1], res['search'][1]):
+        n = without[0]
+        passes = int(sum(1 for v in without if v > 0))
+        assert all(v == n for v in without[:passes])                         # every pass searched every query
+        assert with_skip[:2] == [n, n] and min(with_skip[:passes]) < 0.5 * n   # the late passes search less than half
