@@ -401,42 +401,64 @@ __device__ __forceinline__ double icp_group_sum(double v)
 
 // icp_normals: per target point the K = 30 nearest neighbours, the covariance of everything within the K-th distance,
 // the eigenvector of its smallest eigenvalue.  Eight lanes per point: every lane keeps the K smallest distances of the
-// records IT scanned (sorted, in LDS); at the end of a shell the group merges the eight lists far enough to know the
-// K-th smallest distance of their union exactly (K steps of "smallest head"), which is the cull bound of the next shell
-// and decides whether the search has settled.  The covariance pass deals the records out the same way and adds the
+// records IT scanned (unsorted, in LDS); at the end of a shell the group finds the K-th smallest distance of the union of
+// the eight lists exactly (bisection on the bit patterns), which is the cull bound of the next shell and decides whether
+// the search has settled.  The covariance pass deals the records out the same way and adds the
 // eight partial sums up in a fixed butterfly.
 __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
 {
-    __shared__ float s_d[ICP_K][ICP_THREADS];               // per lane: the K smallest squared distances it saw, ascending
+    __shared__ float s_d[ICP_K][ICP_THREADS];               // per lane: the K smallest squared distances it saw (unsorted)
     const int p = (blockIdx.x * ICP_THREADS + threadIdx.x) / ICP_SG;   // original index
     if (p >= a.n_tgt) return;
     const int sub = threadIdx.x & (ICP_SG - 1);
-    const int base = (int)(threadIdx.x & 63) & ~(ICP_SG - 1);
     const IcpSlab sl0 = icp_slab(a, 0), sl1 = icp_slab(a, 1);
     const float4 v = reinterpret_cast<const float4 *>(a.tgt)[p];
     float4 out = make_float4(0.f, 0.f, 1.f, 0.f);
     const int t = threadIdx.x;
+    // A lane's list is UNSORTED: the K smallest squared distances it has seen, the largest of them and its place cached in
+    // registers.  An arrival below the largest replaces it and the list is read once to find the new largest -- K independent LDS
+    // reads.  (Round 2 kept the lists sorted by insertion: every arrival shifted half the list, a chain of ~30 DEPENDENT LDS
+    // round trips -- ~100 arrivals per lane made that chain 180 us per wave, the kernel's 670 us.)
     int found = 0;                                          // entries of this lane's list
+    float curmax = 0.f;                                     // the largest of them ...
+    int maxpos = 0;                                         // ... and where it is
     float kth = __builtin_huge_valf();                      // K-th smallest distance of the group so far (inf: fewer than K)
     auto bound_k = [&]() { return kth < __builtin_huge_valf() ? (double)kth * (1.0 + 1e-6) + 1e-12 : 1e300; };
-    auto offer = [&](float d2) {                            // insertion into the sorted list of the lane's K smallest
-        if (d2 > kth || (found == ICP_K && d2 >= s_d[ICP_K - 1][t])) return;
-        int i = found < ICP_K ? found : ICP_K - 1;
-        while (i > 0 && s_d[i - 1][t] > d2) { s_d[i][t] = s_d[i - 1][t]; --i; }
-        s_d[i][t] = d2;
-        if (found < ICP_K) ++found;
-    };
-    auto merge_kth = [&]() {                                // exact K-th smallest of the union of the eight lists
-        if (icp_group_sum((uint32_t)found) < ICP_K) return;
-        int head = 0;
-        float g = 0.f;
-        for (int step = 0; step < ICP_K; ++step) {
-            const float mine = head < found ? s_d[head][t] : __builtin_huge_valf();
-            g = icp_group_min(mine);
-            const uint32_t eq = (uint32_t)(__ballot(mine == g) >> base) & 0xffu;      // one of the equal heads advances
-            if (sub == __ffs(eq) - 1) ++head;
+    auto offer = [&](float d2) {
+        if (d2 > kth) return;
+        if (found < ICP_K) {
+            s_d[found][t] = d2;
+            if (found == 0 || d2 > curmax) { curmax = d2; maxpos = found; }
+            ++found;
+            return;
         }
-        kth = g;
+        if (d2 >= curmax) return;
+        s_d[maxpos][t] = d2;
+        float m = -1.f;
+        int mp = 0;
+#pragma unroll
+        for (int i = 0; i < ICP_K; ++i) {
+            const float w = s_d[i][t];
+            if (w > m) { m = w; mp = i; }
+        }
+        curmax = m; maxpos = mp;
+    };
+    // exact K-th smallest of the union of the eight lists: the smallest bit pattern v (distances are >= 0: patterns order like
+    // values) with K or more entries <= v, by bisection between the group's smallest and largest entry
+    auto merge_kth = [&]() {
+        if (icp_group_sum((uint32_t)found) < ICP_K) return;
+        float mn = __builtin_huge_valf();
+        for (int i = 0; i < found; ++i) mn = fminf(mn, s_d[i][t]);
+        uint32_t lo = __float_as_uint(icp_group_min(mn));
+        uint32_t hi = __float_as_uint(-icp_group_min(found > 0 ? -curmax : __builtin_huge_valf()));
+        if (kth < __builtin_huge_valf() && __float_as_uint(kth) < hi) hi = __float_as_uint(kth);   // (it only ever shrinks)
+        while (lo < hi) {                                   // (group-uniform)
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            uint32_t c = 0;
+            for (int i = 0; i < found; ++i) c += __float_as_uint(s_d[i][t]) <= mid ? 1u : 0u;
+            if (icp_group_sum(c) >= ICP_K) hi = mid; else lo = mid + 1u;
+        }
+        kth = __uint_as_float(lo);
     };
     auto dist2 = [&](const float4 w) { const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z; return dx * dx + dy * dy + dz * dz; };
     // pass A: the K-th smallest distance.  Fine grid first; every unvisited point is farther than r cells, so the K-th
@@ -467,7 +489,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
         // the search radius of pass B: the K-th distance, or -- fewer than K points inside the search cap -- the largest
         float lim = kth;
         if (!(lim < __builtin_huge_valf())) {
-            const float mine = found > 0 ? -s_d[found - 1][t] : __builtin_huge_valf();
+            const float mine = found > 0 ? -curmax : __builtin_huge_valf();
             lim = -icp_group_min(mine);
         }
         // pass B: covariance of every point within that distance (relative to the query: well conditioned)
