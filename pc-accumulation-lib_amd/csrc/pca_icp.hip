@@ -74,6 +74,8 @@ struct IcpArgs {
     uint32_t *zr;                // [4] occupied slab range of the two grids: zmin, zmax of level 0, then of level 1 (cells along z;
                                  // zmin > zmax: no point inside).  Counting fills it; only these slabs are scanned and searched
     uint32_t *status;            // context status word
+    uint32_t *zr_part;           // [workgroups of icp_grid_count][4] their zmin, zmax + 1 per grid
+    int n_count_blocks;
     uint32_t *arrived;           // workgroups of the running icp_solve that have written their sum
     double max_dist2;
     double rel_fitness, rel_rmse;
@@ -110,17 +112,40 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_grid_count(const IcpArgs a)
         if (icp_cell_of<0>(v.x, v.y, v.z, cx, cy, cz)) { atomicAdd(&a.g[0].cnt[icp_cell_index(cx, cy, cz)], 1u); zlo0 = (uint32_t)cz; zhi0 = (uint32_t)cz + 1u; }
         if (icp_cell_of<1>(v.x, v.y, v.z, cx, cy, cz)) { atomicAdd(&a.g[1].cnt[icp_cell_index(cx, cy, cz)], 1u); zlo1 = (uint32_t)cz; zhi1 = (uint32_t)cz + 1u; }
     }
+    // the workgroup's range into its row of zr_part: icp_cell_scan reduces the rows (no atomics: every wave of the launch runs at
+    // once and sees the initial range, so even "only if it widens the range" meant 7500 atomics on four words -- 50-90 us)
+    __shared__ uint32_t s_z[ICP_THREADS / 64][4];
     zlo0 = wave_reduce_min(zlo0); zhi0 = wave_reduce_max(zhi0); zlo1 = wave_reduce_min(zlo1); zhi1 = wave_reduce_max(zhi1);
-    // (one memory-side word serves ~90 atomics per microsecond: 7500 unconditional ones were 85 us of this kernel.  The range is
-    // looked at first -- a stale value only means an atomic that changes nothing -- and after the first waves nobody widens it)
-    if ((threadIdx.x & 63) == 0) {
-        const uint32_t c0 = __hip_atomic_load(&a.zr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c1 = __hip_atomic_load(&a.zr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                       c2 = __hip_atomic_load(&a.zr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c3 = __hip_atomic_load(&a.zr[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (zhi0 && zlo0 < c0) atomicMin(&a.zr[0], zlo0);
-        if (zhi0 > c1) atomicMax(&a.zr[1], zhi0);
-        if (zhi1 && zlo1 < c2) atomicMin(&a.zr[2], zlo1);
-        if (zhi1 > c3) atomicMax(&a.zr[3], zhi1);
+    if ((threadIdx.x & 63) == 0) { uint32_t *r = s_z[threadIdx.x >> 6]; r[0] = zlo0; r[1] = zhi0; r[2] = zlo1; r[3] = zhi1; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint32_t v = s_z[0][threadIdx.x];
+        for (int w = 1; w < ICP_THREADS / 64; ++w) v = (threadIdx.x & 1) ? (s_z[w][threadIdx.x] > v ? s_z[w][threadIdx.x] : v) : (s_z[w][threadIdx.x] < v ? s_z[w][threadIdx.x] : v);
+        a.zr_part[4 * blockIdx.x + threadIdx.x] = v;
     }
+}
+
+// the range of occupied slabs from the rows icp_grid_count left (every workgroup of the scan for itself; 1024 threads)
+__device__ __forceinline__ void icp_reduce_range(const IcpArgs &a, uint32_t (&zr)[4])
+{
+    __shared__ uint32_t s_r[ICP_SCAN_THREADS / 64][4];
+    __shared__ uint32_t s_zr[4];
+    uint32_t v[4] = {0xffffffffu, 0u, 0xffffffffu, 0u};
+    for (int b = threadIdx.x; b < a.n_count_blocks; b += ICP_SCAN_THREADS) {
+        const uint4 r = reinterpret_cast<const uint4 *>(a.zr_part)[b];
+        v[0] = r.x < v[0] ? r.x : v[0]; v[1] = r.y > v[1] ? r.y : v[1]; v[2] = r.z < v[2] ? r.z : v[2]; v[3] = r.w > v[3] ? r.w : v[3];
+    }
+    v[0] = wave_reduce_min(v[0]); v[1] = wave_reduce_max(v[1]); v[2] = wave_reduce_min(v[2]); v[3] = wave_reduce_max(v[3]);
+    if ((threadIdx.x & 63) == 0) { uint32_t *r = s_r[threadIdx.x >> 6]; r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint32_t m = s_r[0][threadIdx.x];
+        for (int w = 1; w < ICP_SCAN_THREADS / 64; ++w) m = (threadIdx.x & 1) ? (s_r[w][threadIdx.x] > m ? s_r[w][threadIdx.x] : m) : (s_r[w][threadIdx.x] < m ? s_r[w][threadIdx.x] : m);
+        s_zr[threadIdx.x] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) zr[i] = s_zr[i];
 }
 
 // exclusive scan of the per-cell counts of the occupied slabs of both grids (single pass, decoupled look-back; blockIdx.x <
@@ -137,10 +162,14 @@ __global__ __launch_bounds__(ICP_SCAN_THREADS) void icp_cell_scan(const IcpArgs 
     const int tiles_per_grid = (int)(ICP_CELLS / ICP_SCAN_TILE);
     const int lv = (int)blockIdx.x >= tiles_per_grid ? 1 : 0;
     const IcpGrid &g = a.g[lv];
-    const uint32_t zlo = a.zr[2 * lv], zhi1 = a.zr[2 * lv + 1];
+    const int tile = (int)blockIdx.x - lv * tiles_per_grid;
+    // (a workgroup far beyond any possible range leaves before the reduction: 64 slabs at most)
+    uint32_t zr[4];
+    icp_reduce_range(a, zr);
+    if (blockIdx.x == 0 && threadIdx.x < 4) a.zr[threadIdx.x] = zr[threadIdx.x];       // for the kernels that follow (icp_slab)
+    const uint32_t zlo = zr[2 * lv], zhi1 = zr[2 * lv + 1];
     if (zhi1 == 0u) return;                                 // no point inside this grid: nothing is ever looked up
     const int n_tiles = (int)(zhi1 - zlo) * ICP_SLAB_TILES;
-    const int tile = (int)blockIdx.x - lv * tiles_per_grid;
     if (tile >= n_tiles) return;                            // (uniform) a workgroup beyond the occupied slabs
     uint64_t *lb = a.lb_state + (size_t)lv * tiles_per_grid;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -927,7 +956,7 @@ int64_t pca_icp_workspace_bytes(int32_t max_points)
     if (max_points < 1) max_points = 1;
     return 2 * (icp_align(ICP_CELLS * 4) + icp_align((ICP_CELLS + 1) * 4) + icp_align((int64_t)max_points * 16)) +
            icp_align((int64_t)max_points * 16) + 3 * icp_align((int64_t)max_points * 4) +
-           icp_align((int64_t)icp_grid(max_points) * ICP_NACC * 8) +
+           icp_align((int64_t)icp_grid(max_points) * ICP_NACC * 8) + icp_align((int64_t)((max_points + ICP_THREADS - 1) / ICP_THREADS) * 16) +
            icp_align(128 * 8) + 512;
 }
 
@@ -958,6 +987,8 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
     { static int ns = -1; if (ns < 0) { const char *e = getenv("PCA_ICP_NO_SKIP"); ns = e ? atoi(e) : 0; } a.no_skip = ns; }
     { static int dg = -1; if (dg < 0) { const char *e = getenv("PCA_ICP_DBG"); dg = e ? atoi(e) : 0; } a.dbg = dg; }
     a.partial = reinterpret_cast<double *>(w); w += icp_align((int64_t)icp_grid(n_src) * ICP_NACC * 8);
+    a.n_count_blocks = (n_tgt + ICP_THREADS - 1) / ICP_THREADS;
+    a.zr_part = reinterpret_cast<uint32_t *>(w); w += icp_align((int64_t)a.n_count_blocks * 16);
     a.state = reinterpret_cast<double *>(w);
     a.zr = reinterpret_cast<uint32_t *>(a.state + 24);                 // initialised with the state block
     a.status = ctx->ticket + 1;
