@@ -277,8 +277,12 @@ __device__ __forceinline__ void icp_scan_range(const float4 *spts, uint32_t s0, 
 // trip counts; the eight lanes must be converged at every call.
 template <int LV, int SGN, typename B, typename F>
 __device__ __forceinline__ void icp_visit_shell(const IcpGrid &g, const IcpSlab sl, int cx, int cy, int cz, int r, double qx, double qy,
-                                                double qz, int sub, B &&bound, F &&f)
+                                                double qz, int sub, B &&bound, F &&f, const int rx = 0)
 {
+    // rx > 0 ("rows mode", group-uniform): the rows of the shell are taken across x in [cx - rx, cx + rx] instead of
+    // [cx - r, cx + r] and the two faces at |dx| = r are left out -- with rx >= r the cube of radius r is covered all the
+    // same, by 8 r lookups instead of 8 r + 2 (2r - 1)^2.  For a query that has NO candidate yet nothing can be culled: over nine
+    // coarse shells that is 289 lookups instead of 1650, and such queries (max-range returns, 245 us) are what a pass waits for.
     using G = IcpLevel<LV>;
     auto gap = [](double q, double lo) { return q < lo ? lo - q : (q > lo + G::cell ? q - (lo + G::cell) : 0.0); };
     // the ranges the lanes of the group hold in (s0, e0), each scanned by the whole group
@@ -296,15 +300,16 @@ __device__ __forceinline__ void icp_visit_shell(const IcpGrid &g, const IcpSlab 
             icp_scan_range_sg<SGN>(g.spts, s, e, sub, f);
         }
     };
+    const int half = rx > 0 ? rx : r;
+    const int x_lo = cx - half < 0 ? 0 : cx - half, x_hi = cx + half >= ICP_NX ? ICP_NX - 1 : cx + half;
     if (r == 0) {
         if (cz < sl.lo || cz > sl.hi) return;               // (group-uniform) an empty slab: its start[] was never written
-        const int c0 = icp_cell_index(cx, cy, cz);
-        if (SGN == 1) icp_scan_range(g.spts, g.start[c0], g.start[c0 + 1], f);
-        else icp_scan_range_sg<SGN>(g.spts, g.start[c0], g.start[c0 + 1], sub, f);
+        const int c0 = icp_cell_index(x_lo, cy, cz);        // (the own cell, or the own row)
+        if (SGN == 1) icp_scan_range(g.spts, g.start[c0], g.start[c0 + (x_hi - x_lo) + 1], f);
+        else icp_scan_range_sg<SGN>(g.spts, g.start[c0], g.start[c0 + (x_hi - x_lo) + 1], sub, f);
         return;
     }
     const int n = 2 * r + 1, m = 2 * r - 1;
-    const int x_lo = cx - r < 0 ? 0 : cx - r, x_hi = cx + r >= ICP_NX ? ICP_NX - 1 : cx + r;
     // (four row lookups in flight per lane, as for the single cells below: one lookup per trip made a far-field query's outer
     // shells -- 8 r rows each -- a chain of r + 1 round trips per shell, and such queries are the last to finish in a pass)
     for (int i0 = 0; i0 < 2 * n + 2 * m; i0 += 4 * SGN) {
@@ -328,7 +333,7 @@ __device__ __forceinline__ void icp_visit_shell(const IcpGrid &g, const IcpSlab 
 #pragma unroll
         for (int u = 0; u < 4; ++u) scan_found(s0[u], e0[u]);
     }
-    const int ncell = 2 * m * m;
+    const int ncell = rx > 0 ? 0 : 2 * m * m;
     for (int k0 = 0; k0 < ncell; k0 += 4 * SGN) {
         uint32_t s0[4], e0[4];
 #pragma unroll
@@ -815,7 +820,9 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
                 }
             if (!settled && in_coarse)
                 for (int r = 0; r <= ICP_MATCH_RINGS && !settled; ++r) {
-                    icp_visit_shell<0, ICP_SG>(a.g[0], sl0, cx, cy, cz, r, qx, qy, qz, sub, bound, offer);   // re-offering a point is harmless
+                    // (no candidate yet: rows mode -- nothing can be culled, and the cube is covered by rows alone; with a candidate:
+                    // cubic shells, culled against it.  Rows first, shells later keeps every inner cube covered.  Re-offering a point is harmless)
+                    icp_visit_shell<0, ICP_SG>(a.g[0], sl0, cx, cy, cz, r, qx, qy, qz, sub, bound, offer, b.idx < 0 ? ICP_MATCH_RINGS : 0);
                     merged();
                     reach = r * IcpLevel<0>::cell;
                     settled = b.idx >= 0 && b.d2 <= reach * reach;
