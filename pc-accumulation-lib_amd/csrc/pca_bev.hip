@@ -77,6 +77,7 @@ struct alignas(16) BevArgs {                             // (16: pca_fetch_block
     int Gr, Gp;           // counter tables: row length (>= G) and workgroups per XCD column block (table_pos)
     int tile_mult;        // bev_tile_cells: workgroup -> tile permutation (coprime to its period: T / 4 or T)
     int heavy_min;        // tiles with more records than this are bev_tile_cells_heavy's (<= RGB_CAP)
+    int stagger;          // bev_tile_cells: start offset between the workgroups that share a CU, in units of s_sleep(16) (PCA_BEV_STAGGER)
     uint32_t *key;        // [max_points]
     uint32_t *bh;         // [T][G] kept records per (tile, workgroup)
     uint32_t *boff;       // [T][G] exclusive scan of bh in that order
@@ -1183,6 +1184,16 @@ __device__ __forceinline__ void bev_tile_cells_body(const BevArgs &a)
     } else {
         tile = (int)(((int64_t)blockIdx.x * a.tile_mult) % a.T);
     }
+    // PCA_BEV_STAGGER = d (default 0: off): the four workgroups of a CU (blocks b, b + T/4, ...) start d x 0.43 us apart.  Left
+    // alone they run in lockstep on the uniform window: all 1024 tiles are resident from the first microsecond, every one asks
+    // for its counters and then its records at the same moment (44 MB in ~3 us) and computes while the memory system idles.
+    // Measured (profiles/r04_experiments/bev_cells_stagger.txt): steps of 0.9-1.7 us take the kernel from 34.5 to 33.0 us on the
+    // headline although a CU's last workgroup starts 4-5 us late -- but cost the ring model 1.4 us (its tiles are unequal and out
+    // of step anyway) and the many-sample launch 7 % (every workgroup of every round sleeps): a knob for A/B, not a default.
+    if (a.stagger > 0) {
+        const int slot = (int)blockIdx.x / ((a.T + 3) >> 2);
+        for (int k = 0; k < slot * a.stagger; ++k) __builtin_amdgcn_s_sleep(16);
+    }
     const unsigned long long t_begin = wall_clock64();
     RecMap &M = *reinterpret_cast<RecMap *>(s_buf);         // lives in the colour buffer until pass 2 fills that
     static_assert(sizeof(RecMap) <= sizeof(s_buf), "RecMap aliases the colour buffer");
@@ -1643,6 +1654,7 @@ static int bev_prepare(pca_ctx *ctx, const pca_store *store, const double *inten
     a.extra = extra_planes;
     { static int hm = -1; if (hm < 0) { const char *e = getenv("PCA_BEV_HEAVY_MIN"); hm = e ? atoi(e) : HEAVY_MIN_DEFAULT; if (hm < 1 || hm > RGB_CAP) hm = RGB_CAP; } a.heavy_min = hm; }
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("PCA_BEV_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
+    { static int sg = -1; if (sg < 0) { const char *e = getenv("PCA_BEV_STAGGER"); sg = e ? atoi(e) : 0; if (sg < 0 || sg > 64) sg = 0; } a.stagger = sg; }
     a.status = ctx->ticket + 1;
     {
         auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
