@@ -950,6 +950,19 @@ def test_k1_one_pixel_image(T, orc):
         assert ost.n > 10 and np.array_equal(rows, ost.rows())
 
 
+def test_tile_kernel_start_offsets_change_nothing_in_a_subprocess():
+    """PCA_BEV_STAGGER (read once per process; an experiment's knob, off by default): the workgroups of bev_tile_cells that share
+    a CU start a few microseconds apart.  Timing only -- the golden BEV and the randomised configurations come out bit for bit."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PCA_BEV_STAGGER='3')
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_kernels.py'), '-x', '-q', '-m', 'gpu', '-k',
+                        'bev_golden_and_oracle or randomised_configs'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'no tests ran' not in r.stdout
+
+
 def test_light_tile_kernel_thread_contiguous_mode_in_a_subprocess():
     """PCA_BEV_HEAVY_MIN is read once per process.  Raised to the LDS colour capacity (4096), tiles of 2561..4096 records
     stay with the light tile kernel and take its thread-contiguous mode (per-thread runs); the skewed and the dense-tile
