@@ -21,7 +21,7 @@
 //                     J^T r, |q - t|^2, pair count (fixed order)
 //   icp_solve         30 workgroups, one per accumulator, add the columns up in a fixed order (deterministic); the last to
 //                     arrive takes the step: 6x6 Cholesky solve, T <- exp(x) T, fitness / rmse, convergence flag -- two
-//                     launches per iteration, and the host looks at the flag only every sixth pass.
+//                     launches per iteration, and the host looks at the flag only every twelfth pass.
 // Measured on two 120 k-point sweeps: round 2 10.9 ms -> 2.8 ms per registration; round 4 2.71 -> 2.1 ms (grids 278 -> 131 us,
 // rows + solve 35 -> 9 us per pass, late passes 130 -> 80 us); what changed is in the comments of icp_cell_scan, icp_visit_shell,
 // icp_match and icp_solve_step, the measurements in profiles/r04_experiments/icp_second_session.txt.
@@ -47,7 +47,8 @@ template <int LV> struct IcpLevel {
 #define ICP_MATCH_RINGS 8        // search cap of a correspondence: 4 m (the reference passes 1e3 m = everything)
 #define ICP_THREADS 256
 #define ICP_NACC 30              // 21 (J^T J upper) + 6 (J^T r) + sum d^2 + inliers + sum r^2
-#define ICP_CHECK_EVERY 6         // the host looks at the convergence flag after every 6th pass
+#define ICP_CHECK_EVERY 12        // the host looks at the convergence flag after every 12th pass (a look = a copy + a wait: 45 us of idle
+                                  // GPU; a pass after convergence = two early-exit launches: 9 us.  Registrations take 5-15 updates)
 
 struct IcpGrid {
     uint32_t *cnt;               // [cells] points per cell (counting pass), all zero again after the fill pass
