@@ -812,15 +812,20 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
                     bnd = (b.d2 + 2.0 * mg * s1 + mg * mg) * (1.0 + 1e-12) + 1e-300;
                 }
             };
-            if (icp_fine_box(qx, qy, qz, fx, fy, fz))
+            const bool fine_done = icp_fine_box(qx, qy, qz, fx, fy, fz);
+            if (fine_done)
                 for (int r = 0; r <= ICP_FINE_RINGS && !settled; ++r) {
                     icp_visit_shell<1, ICP_SG>(a.g[1], sl1, fx, fy, fz, r, qx, qy, qz, sub, bound, offer);
                     merged();
                     reach = r * IcpLevel<1>::cell;
                     settled = b.idx >= 0 && b.d2 <= reach * reach;
                 }
+            // (after a complete fine pass the coarse rings 0 and 1 hold nothing new: that cube reaches 0.75 m from the centre of the
+            // query's coarse cell, i.e. at most 0.875 m from the centre of its fine cell, and the fine box reached 1.125 m)
+            // -- for cubic shells.  In rows mode rings 0 and 1 are the rows that reach beyond that cube in x: they stay.
+            const int r_first = (fine_done && b.idx >= 0 && bnd <= 4.0) ? 2 : 0;
             if (!settled && in_coarse)
-                for (int r = 0; r <= ICP_MATCH_RINGS && !settled; ++r) {
+                for (int r = r_first; r <= ICP_MATCH_RINGS && !settled; ++r) {
                     // (no candidate yet: rows mode -- nothing can be culled, and the cube is covered by rows alone; with a candidate:
                     // cubic shells, culled against it.  Rows first, shells later keeps every inner cube covered.  Re-offering a point is harmless)
                     // (the same while the candidate is more than 2 m away: the bound culls next to nothing then -- a max-range return

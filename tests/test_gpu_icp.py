@@ -243,3 +243,37 @@ def test_icp_shortcut_is_bit_identical_to_searching_every_pass():
         passes = int(sum(1 for v in without if v > 0))
         assert all(v == n for v in without[:passes])                         # every pass searched every query
         assert with_skip[:2] == [n, n] and min(with_skip[:passes]) < 0.5 * n   # the late passes search less than half
+
+
+@pytest.mark.parametrize('updates', [1, 4])
+def test_icp_final_evaluation_equals_exact_nearest_neighbours(updates):
+    """fitness / rmse of the returned pose are sums over EVERY source point's nearest target within the cap: recomputed with a
+    k-d tree at that pose.  The clouds carry what the searches treat specially: isolated far returns whose partner is 3-4 m
+    away (all coarse rings, rows mode), some without any target within the cap (no partner), dense near-field points, and a
+    second pass onwards the partners kept without a search."""
+    from scipy.spatial import cKDTree
+    from pca_amd.icp import GpuIcp
+    cap = 3.9                                             # below the search box's reach (4 m): "within the cap" is a ball, exactly
+    rng = np.random.default_rng(5)
+    a = sweep(0.0, 0.0, 0.0, 21)
+    b = sweep(0.8, 0.05, 0.01, 22)
+    n_far = 400
+    ang = rng.uniform(-np.pi, np.pi, n_far)
+    far = np.stack([70.0 * np.cos(ang), 70.0 * np.sin(ang), rng.uniform(-1.5, 3.0, n_far), np.zeros(n_far)], 1).astype(np.float32)
+    step = rng.normal(size=(n_far, 3))
+    step *= (rng.uniform(2.2, 4.6, n_far) / np.linalg.norm(step, axis=1))[:, None]       # partner 2.2 .. 4.6 m away
+    twin = far.copy()
+    twin[:, :3] += step.astype(np.float32) + np.float32([0.8, 0.05, 0.0])
+    a = np.concatenate([a, far]).astype(np.float32)
+    b = np.concatenate([b, twin]).astype(np.float32)
+    icp = GpuIcp()
+    icp.max_iteration = updates
+    r = icp.register(GpuIcp.to_device(a), GpuIcp.to_device(b), cap, np.eye(4))
+    assert r.iterations == updates
+    T = r.transformation
+    q = a[:, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    d, _ = cKDTree(b[:, :3].astype(np.float64)).query(q)
+    inl = d < cap
+    assert 0 < (~inl).sum() < n_far                       # some far returns have no partner, most have one
+    assert abs(r.fitness - inl.mean()) < 1e-12
+    assert abs(r.inlier_rmse - np.sqrt((d[inl] ** 2).mean())) < 1e-9
