@@ -457,10 +457,24 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
     int found = 0;                                          // entries of this lane's list
     float curmax = 0.f;                                     // the largest of them ...
     int maxpos = 0;                                         // ... and where it is
-    float kth = __builtin_huge_valf();                      // K-th smallest distance of the group so far (inf: fewer than K)
+    // kth: an UPPER BOUND of the group's K-th smallest distance while the shells are walked (inf: fewer than K seen) -- all it is
+    // used for there is culling and the settle test, and both are safe with anything not below the true value.  The exact K-th
+    // distance costs a bisection over the eight lists (31 steps x 30 entries: per-query stamps showed two or three of those per
+    // point were most of the kernel) and is found ONCE, after the walk.  The bound: every lane keeps its four smallest
+    // distances sorted in registers; if every lane has four that are <= x, the group has 32 >= K that are <= x.
+    float kth = __builtin_huge_valf();
+    float t0 = __builtin_huge_valf(), t1 = t0, t2 = t0, t3 = t0;
+    static_assert(4 * ICP_SG >= ICP_K, "four per lane make K");
     auto bound_k = [&]() { return kth < __builtin_huge_valf() ? (double)kth * (1.0 + 1e-6) + 1e-12 : 1e300; };
     auto offer = [&](float d2) {
         if (d2 > kth) return;
+        {
+            float x = d2, y;
+            y = fminf(t0, x); x = fmaxf(t0, x); t0 = y;
+            y = fminf(t1, x); x = fmaxf(t1, x); t1 = y;
+            y = fminf(t2, x); x = fmaxf(t2, x); t2 = y;
+            t3 = fminf(t3, x);
+        }
         if (found < ICP_K) {
             s_d[found][t] = d2;
             if (found == 0 || d2 > curmax) { curmax = d2; maxpos = found; }
@@ -482,18 +496,32 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
     // values) with K or more entries <= v, by bisection between the group's smallest and largest entry
     auto merge_kth = [&]() {
         if (icp_group_sum((uint32_t)found) < ICP_K) return;
+        // (the list into registers first -- the walk is over, its registers are free -- so that a step is compares and adds only)
+        uint32_t L[ICP_K];
         float mn = __builtin_huge_valf();
-        for (int i = 0; i < found; ++i) mn = fminf(mn, s_d[i][t]);
+#pragma unroll
+        for (int i = 0; i < ICP_K; ++i) {
+            const float w = i < found ? s_d[i][t] : __builtin_huge_valf();
+            L[i] = __float_as_uint(w);                      // (+inf: 0x7f800000, above every pivot)
+            mn = fminf(mn, w);
+        }
         uint32_t lo = __float_as_uint(icp_group_min(mn));
         uint32_t hi = __float_as_uint(-icp_group_min(found > 0 ? -curmax : __builtin_huge_valf()));
-        if (kth < __builtin_huge_valf() && __float_as_uint(kth) < hi) hi = __float_as_uint(kth);   // (it only ever shrinks)
+        if (kth < __builtin_huge_valf() && __float_as_uint(kth) < hi) hi = __float_as_uint(kth);   // (the bound: K or more are <= it)
         while (lo < hi) {                                   // (group-uniform)
             const uint32_t mid = lo + ((hi - lo) >> 1);
             uint32_t c = 0;
-            for (int i = 0; i < found; ++i) c += __float_as_uint(s_d[i][t]) <= mid ? 1u : 0u;
+#pragma unroll
+            for (int i = 0; i < ICP_K; ++i) c += L[i] <= mid ? 1u : 0u;
             if (icp_group_sum(c) >= ICP_K) hi = mid; else lo = mid + 1u;
         }
         kth = __uint_as_float(lo);
+    };
+    auto bound_up = [&]() {                                 // (after a shell) the cheap bound; never above the previous one
+        float ub = -icp_group_min(-t3);                     // max over the lanes of their fourth smallest (inf if a lane has fewer)
+        if (!(ub < __builtin_huge_valf()) && icp_group_sum((uint32_t)found) >= ICP_K)
+            ub = -icp_group_min(found > 0 ? -curmax : __builtin_huge_valf());    // K or more are stored: none is above the largest stored
+        if (ub < kth) kth = ub;
     };
     auto dist2 = [&](const float4 w) { const float dx = w.x - v.x, dy = w.y - v.y, dz = w.z - v.z; return dx * dx + dy * dy + dz * dz; };
     // pass A: the K-th smallest distance.  Fine grid first; every unvisited point is farther than r cells, so the K-th
@@ -504,22 +532,29 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
     if (fine)
         for (int r = 0; r <= ICP_FINE_RINGS && !settled; ++r) {
             icp_visit_shell<1, ICP_SG>(a.g[1], sl1, fx, fy, fz, r, v.x, v.y, v.z, sub, bound_k, [&](const float4 w) { offer(dist2(w)); });
-            merge_kth();
+            bound_up();
             const float lim = (float)(r * IcpLevel<1>::cell);
             settled = kth <= lim * lim;
         }
     const bool coarse = icp_cell_of<0>(v.x, v.y, v.z, cx, cy, cz);
+    // (a point whose K-th neighbour is 2 m away or farther -- an isolated return at range, a max-range return -- walks its coarse
+    // rings as rows, see icp_visit_shell: next to nothing is culled there.  One mode for the whole pass: a cell visited twice
+    // would put a point into the lists twice)
+    const bool rows_a = !(kth < 4.0f);
     if (!settled && coarse)
         for (int r = 0; r <= ICP_NORMAL_RINGS && !settled; ++r) {
+            int rx = 0;
+            if (rows_a) { rx = kth < __builtin_huge_valf() ? (int)(sqrtf(kth) * (float)(1.0 / IcpLevel<0>::cell)) + 1 : ICP_NORMAL_RINGS; rx = rx > ICP_NORMAL_RINGS ? ICP_NORMAL_RINGS : rx; }
             icp_visit_shell<0, ICP_SG>(a.g[0], sl0, cx, cy, cz, r, v.x, v.y, v.z, sub, bound_k, [&](const float4 w) {
                 if (fine && icp_in_fine_box(w, fx, fy, fz)) return;             // already offered by the fine pass
                 offer(dist2(w));
-            });
-            merge_kth();
+            }, rx);
+            bound_up();
             const float lim = (float)(r * IcpLevel<0>::cell);
             settled = kth <= lim * lim;
         }
     const uint32_t total = icp_group_sum((uint32_t)found);
+    if (kth < __builtin_huge_valf()) merge_kth();           // the exact K-th distance (at most the bound)
     if (total >= 3) {
         // the search radius of pass B: the K-th distance, or -- fewer than K points inside the search cap -- the largest
         float lim = kth;
@@ -545,7 +580,9 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
             for (int r = 0; r <= rmax && r <= ICP_FINE_RINGS; ++r) icp_visit_shell<1, ICP_SG>(a.g[1], sl1, fx, fy, fz, r, v.x, v.y, v.z, sub, bound_l, add);
         } else if (coarse) {
             const int rmax = (int)ceil(sqrt((double)lim) / IcpLevel<0>::cell);
-            for (int r = 0; r <= rmax && r <= ICP_NORMAL_RINGS; ++r) icp_visit_shell<0, ICP_SG>(a.g[0], sl0, cx, cy, cz, r, v.x, v.y, v.z, sub, bound_l, add);
+            int rx = 0;                                     // (rows for a wide ball, as in pass A; every row once)
+            if (lim > 4.0f) { rx = (int)(sqrtf(lim) * (float)(1.0 / IcpLevel<0>::cell)) + 1; rx = rx > ICP_NORMAL_RINGS ? ICP_NORMAL_RINGS : rx; }
+            for (int r = 0; r <= rmax && r <= ICP_NORMAL_RINGS; ++r) icp_visit_shell<0, ICP_SG>(a.g[0], sl0, cx, cy, cz, r, v.x, v.y, v.z, sub, bound_l, add, rx);
         }
         cnt = icp_group_sum(cnt);
         sx = icp_group_sum(sx); sy = icp_group_sum(sy); sz = icp_group_sum(sz);
