@@ -220,8 +220,8 @@ def _register_pairs_for_child():
 def test_icp_shortcut_is_bit_identical_to_searching_every_pass():
     """From the third pass on a query keeps its partner without a search when it provably is still the unique nearest target
     (csrc/pca_icp.hip, icp_match).  PCA_ICP_NO_SKIP=1 (read once per process) searches every query in every pass: poses,
-    fitness, rmse and iteration counts of both forms are equal bit for bit, and the shortcut does take place (PCA_ICP_DBG=1
-    prints the searched queries per pass)."""
+    fitness, rmse and iteration counts of both forms are equal, and the shortcut does take place (PCA_ICP_DBG=1
+    prints the searched queries per pass).  "Equal": see the comment at the comparison."""
     import os
     import subprocess
     import sys
@@ -235,8 +235,13 @@ def test_icp_shortcut_is_bit_identical_to_searching_every_pass():
         line = [ln for ln in r.stdout.splitlines() if ln.startswith('ICPHEX ')][-1]
         counts = [[float(v) for v in ln.split(':')[-1].split()] for ln in r.stderr.splitlines() if ln.startswith('icp: searched')]
         res[name] = (bytes.fromhex(line.split()[1]), counts)
-    assert res['skip'][0] == res['search'][0]
     vals = np.frombuffer(res['skip'][0], np.float64).reshape(3, 19)
+    ref = np.frombuffer(res['search'][0], np.float64).reshape(3, 19)
+    # (the two forms keep the same partners and evaluate the same expressions: bit-equal in every run so far.  The comparison allows
+    # 1e-10 because the order of a grid cell's points comes from atomics -- the normals' sums may round differently from one
+    # PROCESS to the next, with or without the shortcut)
+    assert np.array_equal(vals[:, 18], ref[:, 18])
+    assert np.allclose(vals, ref, rtol=0.0, atol=1e-10)
     assert np.all(vals[:, 18] >= 3) and np.all(vals[:, 16] > 0.5)            # real registrations: iterations, fitness
     for with_skip, without in zip(res['skip'][1], res['search'][1]):
         n = without[0]
