@@ -701,6 +701,7 @@ __device__ void icp_solve_step(const IcpArgs &a, const double *sum, const IcpPre
 // to run).  The partner's coordinates travel with its distance (they are in the record that was scanned: re-reading the
 // target by index afterwards is one more memory round trip at the end of the query's chain).
 struct IcpBest { double d2; int idx; float x, y, z; };
+template <int SG>
 __device__ __forceinline__ void icp_group_best(IcpBest &b)
 {
 #define ICP_BEST_STAGE(S)                                                                                              \
@@ -713,14 +714,17 @@ __device__ __forceinline__ void icp_group_best(IcpBest &b)
         if (oi >= 0 && (b.idx < 0 || od < b.d2 || (od == b.d2 && oi < b.idx))) { b.d2 = od; b.idx = oi; b.x = ox; b.y = oy; b.z = oz; } \
     }
     ICP_BEST_STAGE(1) ICP_BEST_STAGE(2) ICP_BEST_STAGE(4)
+    if (SG > 8) ICP_BEST_STAGE(8)
 #undef ICP_BEST_STAGE
 }
 
 // (the group's nearest G, and the smallest distance any lane has seen of a target that is not G)
+template <int SG>
 __device__ __forceinline__ void icp_group_merge(IcpBest &b, double &other)
 {
+    static_assert(SG == 8 || SG == 16, "the butterflies cover 8 or 16 lanes");
     const IcpBest mine = b;
-    icp_group_best(b);
+    icp_group_best<SG>(b);
     // this lane's nearest that is not G: its best -- unless that IS G (it found G, or a second copy of it)
     double c = other;
     if (mine.idx >= 0 && mine.idx != b.idx && mine.d2 < c) c = mine.d2;
@@ -730,6 +734,7 @@ __device__ __forceinline__ void icp_group_merge(IcpBest &b, double &other)
         c = od < c ? od : c;                                                                                           \
     }
     ICP_MIN_STAGE(1) ICP_MIN_STAGE(2) ICP_MIN_STAGE(4)
+    if (SG > 8) ICP_MIN_STAGE(8)
 #undef ICP_MIN_STAGE
     other = c;
 }
@@ -756,17 +761,21 @@ __device__ __forceinline__ void icp_group_merge(IcpBest &b, double &other)
 // 120 000 x 4, 53 301, 18 831, 6 753, 2 584, 594.  The skipped search would have returned the same partner (it is the unique
 // nearest), and distance and row are computed by the same expressions: the pose is bit-identical with and without the shortcut
 // (PCA_ICP_NO_SKIP=1 switches it off: A/B).
-#define ICP_QPW (ICP_THREADS / ICP_SG)   // queries per workgroup of icp_match
+// SG lanes share a query: 8 from the second pass on; 16 in the FIRST pass, whose searches start from a partner decimetres off
+// and read several times the records (measured, 4 / 8 / 16 lanes: first pass 460 / 280 / 246 us, later full passes 178 / 112 / 125)
+#define ICP_QPW_MAX (ICP_THREADS / 8)     // queries per workgroup of icp_match, at most
 #define ICP_MARGIN 0.02                  // [m]
+template <int SG>
 __global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
 {
+    constexpr int ICP_QPW = ICP_THREADS / SG;
     __shared__ double s_row[ICP_QPW][8];                    // per query: J[0..5], r, |q - t|^2
     __shared__ uint32_t s_flag[ICP_QPW];                    // bit 0: has a partner, bit 1: the partner has a normal
-    __shared__ double s_part[ICP_QPW / 4][32];
+    __shared__ double s_part[8][32];
     if (a.state[20] != 0.0) return;                         // converged: the remaining passes are no-ops
     const double *T = a.state;
-    const int sub = threadIdx.x & (ICP_SG - 1);
-    const int ql = threadIdx.x / ICP_SG;                    // query of the workgroup
+    const int sub = threadIdx.x & (SG - 1);
+    const int ql = threadIdx.x / SG;                    // query of the workgroup
     const int p = blockIdx.x * ICP_QPW + ql;
     IcpBest b;
     b.d2 = a.max_dist2; b.idx = -1; b.x = b.y = b.z = 0.f;
@@ -843,7 +852,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
             bool settled = false;
             double reach = 0.0;                             // every target within this distance has been offered (or culled)
             auto merged = [&]() {                           // the group's nearest, its `other`, the bound that follows
-                icp_group_merge(b, other);
+                icp_group_merge<SG>(b, other);
                 if (b.idx >= 0) {
                     const double s1 = (double)(sqrtf((float)b.d2) * 1.000001f) + 1e-30;
                     bnd = (b.d2 + 2.0 * mg * s1 + mg * mg) * (1.0 + 1e-12) + 1e-300;
@@ -852,7 +861,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
             const bool fine_done = icp_fine_box(qx, qy, qz, fx, fy, fz);
             if (fine_done)
                 for (int r = 0; r <= ICP_FINE_RINGS && !settled; ++r) {
-                    icp_visit_shell<1, ICP_SG>(a.g[1], sl1, fx, fy, fz, r, qx, qy, qz, sub, bound, offer);
+                    icp_visit_shell<1, SG>(a.g[1], sl1, fx, fy, fz, r, qx, qy, qz, sub, bound, offer);
                     merged();
                     reach = r * IcpLevel<1>::cell;
                     settled = b.idx >= 0 && b.d2 <= reach * reach;
@@ -871,7 +880,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
                     int rx = 0;
                     if (b.idx < 0) rx = ICP_MATCH_RINGS;
                     else if (bnd > 4.0) { rx = (int)(sqrt(bnd) * (1.0 / IcpLevel<0>::cell)) + 1; rx = rx > ICP_MATCH_RINGS ? ICP_MATCH_RINGS : rx; }
-                    icp_visit_shell<0, ICP_SG>(a.g[0], sl0, cx, cy, cz, r, qx, qy, qz, sub, bound, offer, rx);
+                    icp_visit_shell<0, SG>(a.g[0], sl0, cx, cy, cz, r, qx, qy, qz, sub, bound, offer, rx);
                     merged();
                     reach = r * IcpLevel<0>::cell;
                     settled = b.idx >= 0 && b.d2 <= reach * reach;
@@ -923,7 +932,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
     __syncthreads();
     // accumulator k (the 21 products of J^T J row-wise, the 6 of J^T r, |q - t|^2, pairs, r^2) of four queries per thread
     {
-        const int k = threadIdx.x & 31, part = threadIdx.x >> 5;        // ICP_QPW / 4 = 8 parts of four queries
+        const int k = threadIdx.x & 31, part = threadIdx.x >> 5;        // 8 parts of ICP_QPW / 8 queries
         int i = 0, j = 0;                                   // k < 21: the pair (i, j), i <= j, row-wise
         {
             int kk = k;
@@ -932,8 +941,8 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
         }
         double acc = 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int q = part * 4 + u;
+        for (int u = 0; u < ICP_QPW / 8; ++u) {
+            const int q = part * (ICP_QPW / 8) + u;
             const uint32_t f = s_flag[q];
             double term = 0.0;
             if (k < 21) term = (f & 2u) ? s_row[q][i] * s_row[q][j] : 0.0;
@@ -949,7 +958,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
     if (threadIdx.x < ICP_NACC) {
         double v = 0.0;
 #pragma unroll
-        for (int part = 0; part < ICP_QPW / 4; ++part) v += s_part[part][threadIdx.x];
+        for (int part = 0; part < 8; ++part) v += s_part[part][threadIdx.x];
         a.partial[(size_t)threadIdx.x * a.grid + blockIdx.x] = v;   // [accumulator][workgroup]: icp_solve reads rows of it coalesced
     }
 }
@@ -1005,7 +1014,7 @@ __global__ __launch_bounds__(ICP_SOLVE_THREADS) void icp_solve(const IcpArgs a)
 extern "C" {
 
 static inline int64_t icp_align(int64_t v) { return (v + 255) & ~255ll; }
-static inline int icp_grid(int n) { return (n + ICP_QPW - 1) / ICP_QPW; }   // workgroups of icp_match = columns of partial sums
+static inline int icp_grid(int n, int sg = 16) { const int qpw = ICP_THREADS / sg; return (n + qpw - 1) / qpw; }   // workgroups of icp_match = columns of partial sums
 
 int64_t pca_icp_workspace_bytes(int32_t max_points)
 {
@@ -1077,7 +1086,8 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
     // convergence is a no-op, the check only saves launching the rest of the 31)
     for (int it = 0; it <= max_iter; ++it) {
         if (it == max_iter) a.rel_fitness = a.rel_rmse = 1e300;              // last pass only evaluates
-        PCA_LAUNCH(ctx, PCA_K_ICP, icp_match, dim3(a.grid), dim3(ICP_THREADS), s, a);
+        if (it == 0) { a.grid = icp_grid(n_src, 16); PCA_LAUNCH(ctx, PCA_K_ICP, icp_match<16>, dim3(a.grid), dim3(ICP_THREADS), s, a); }
+        else { a.grid = icp_grid(n_src, 8); PCA_LAUNCH(ctx, PCA_K_ICP, icp_match<8>, dim3(a.grid), dim3(ICP_THREADS), s, a); }
         PCA_LAUNCH(ctx, PCA_K_ICP, icp_solve, dim3(ICP_NACC), dim3(ICP_SOLVE_THREADS), s, a);
         if (it % ICP_CHECK_EVERY == ICP_CHECK_EVERY - 1 && it < max_iter) {
             PCA_CHECK(ctx, hipMemcpyAsync(st, a.state, sizeof st, hipMemcpyDeviceToHost, s));
