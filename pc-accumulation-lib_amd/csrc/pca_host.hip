@@ -27,6 +27,7 @@
 
 #include "../../include/pca.h"
 #include "pca_common.h"
+#include "pca_stage_pool.h"
 
 typedef void (*cblas_dgemv64_fn)(int order, int trans, int64_t m, int64_t n, double alpha, const double *A, int64_t lda,
                                  const double *x, int64_t incx, double beta, double *y, int64_t incy);
@@ -361,87 +362,13 @@ int64_t pca_host_track_trigger(pca_host_track *t, double bev_horizon, int64_t pr
 // Host arrays -> device, the way an unchanged driver hands observations over (numpy arrays in pageable memory): copy into
 // pinned staging blocks on a few threads at once, then one asynchronous H2D copy per array.  What this replaces on the
 // Python side (three np.copyto + three tensor.copy_ per KITTI observation) cost ~0.15 ms of a 0.34 ms step.
-// The pool's threads all take part in every job (slices dealt round-robin: no claiming, nothing to race on) and spin for
+// The pool (pca_stage_pool.h) claims slices one at a time, every claim tied to its job; its threads spin for
 // PCA_STAGING_SPIN_US (default 2000) after a job before they go to sleep: a driver stepping every 0.2-0.3 ms finds them
 // awake, an idle process does not burn cores.
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct StageSlice { char *dst; const char *src; size_t n; };
-struct StagePool {
-    int T = 0;                                            // worker threads (the caller takes part too)
-    long spin_us = 2000;
-    std::vector<std::thread> th;
-    std::atomic<uint64_t> job{0};
-    std::atomic<int> next{0}, done{0}, sleepers{0};
-    std::atomic<bool> stop{false};
-    std::mutex m;
-    std::condition_variable cv;
-    const StageSlice *slices = nullptr;
-    int total = 0;
-
-    // Slices are CLAIMED from a shared counter, one at a time: a worker that is descheduled (more runnable threads than
-    // cores: eight ranks with their pools, a cgroup-limited container) simply claims nothing, and whoever is running --
-    // the caller included -- finishes the job; nobody waits for a share that was dealt to a sleeping thread.
-    void drain()
-    {
-        for (;;) {
-            const int i = next.fetch_add(1, std::memory_order_acq_rel);   // (pairs with run()'s release store: slices / total are visible)
-            if (i >= total) return;
-            memcpy(slices[i].dst, slices[i].src, slices[i].n);
-            done.fetch_add(1, std::memory_order_release);
-        }
-    }
-    void worker()
-    {
-        uint64_t seen = 0;
-        for (;;) {
-            const auto t0 = std::chrono::steady_clock::now();
-            int polls = 0;
-            while (job.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_relaxed)) {
-                __builtin_ia32_pause();
-                if ((++polls & 255) == 0 &&
-                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) {
-                    std::unique_lock<std::mutex> lk(m);
-                    sleepers.fetch_add(1);
-                    cv.wait(lk, [&] { return job.load(std::memory_order_acquire) != seen || stop.load(); });
-                    sleepers.fetch_sub(1);
-                    break;
-                }
-            }
-            if (stop.load()) return;
-            seen = job.load(std::memory_order_acquire);
-            drain();
-        }
-    }
-    void start(int threads)
-    {
-        T = threads;
-        if (const char *e = getenv("PCA_STAGING_SPIN_US")) spin_us = atol(e);
-        for (int w = 0; w < T; ++w) th.emplace_back([this] { worker(); });
-    }
-    void run(const StageSlice *s, int n)
-    {
-        slices = s; total = n;
-        done.store(0, std::memory_order_relaxed);
-        next.store(0, std::memory_order_release);
-        { std::lock_guard<std::mutex> lk(m); job.fetch_add(1, std::memory_order_release); }
-        if (sleepers.load() > 0) cv.notify_all();
-        drain();
-        // every slice is claimed by now; the last few may still be in another thread's memcpy (<= 128 KB each): a short,
-        // bounded spin, then yield the core to whoever holds them
-        for (int spins = 0; done.load(std::memory_order_acquire) < n; ++spins) {
-            if (spins < 4096) __builtin_ia32_pause();
-            else std::this_thread::yield();
-        }
-        // (a worker that wakes up late finds next >= total and copies nothing; `slices` is not dereferenced then)
-    }
-    ~StagePool()
-    {
-        { std::lock_guard<std::mutex> lk(m); stop.store(true); }
-        cv.notify_all();
-        for (auto &t : th) t.join();
-    }
-};
+using StageSlice = pca_stage::Slice;
+using StagePool = pca_stage::Pool;
 static StagePool *stage_pool()
 {
     static std::mutex once;
@@ -480,7 +407,7 @@ int pca_stage_copy(const void *const *src, void *const *dst, const int64_t *byte
     static std::mutex serial;                               // one job at a time (callers on several threads take turns)
     std::lock_guard<std::mutex> lk(serial);
     StagePool *pool = stage_pool();
-    if (pool->T == 0 || slices.size() < 2) for (auto &sl : slices) memcpy(sl.dst, sl.src, sl.n);
+    if (slices.size() < 2) for (auto &sl : slices) memcpy(sl.dst, sl.src, sl.n);
     else pool->run(slices.data(), (int)slices.size());
     return 0;
 }
