@@ -698,10 +698,192 @@ def pcie_inclusive_pass(acc, pool, n_steps):
     return out
 
 
+def two_sequences_pass(steps, n_lanes=2, reps=9):
+    """TWO (n_lanes) independent sequences on the one GPU, each with its own pca_ctx and stream (pca_amd._lib.Lane), each
+    driven by its own host thread (ctypes releases the GIL inside a library call): the headline step, unchanged, on every
+    lane at once.  What it measures is the capacity a single sequence leaves idle -- its kernels fill the step's time but
+    end in tails (level 1: two rounds of one workgroup per CU; the tile kernel: as long as its densest tile) that another
+    sequence's workgroups can fill.  Independent sequences are what the reference's driver loops over
+    (run_kitti360_bev_gen.py:161-173).  Aggregate = all lanes' points over the time from a common start until the LAST lane
+    has finished (device included); median of `reps` repetitions of `steps` steps per lane."""
+    import threading
+    import torch
+    from pca_amd import _lib
+    lanes = [_lib.Lane() for _ in range(n_lanes)]
+    steppers, outs = [], []
+    for k, lane in enumerate(lanes):                          # set-up one lane after the other, on this thread
+        with lane:
+            acc, pool, _ = make_accumulator(synth_frame, 20 + k)
+            st = Stepper(acc, pool)
+            st.fill()
+            out = torch.empty((steps, 21, PX, PX), dtype=torch.float16, device='cuda')
+            for i in range(3):
+                st.step(out[i % steps])
+            lane.synchronize()
+            steppers.append(st)
+            outs.append(out)
+    torch.cuda.synchronize()
+    start = threading.Barrier(n_lanes + 1)
+    done = threading.Barrier(n_lanes + 1)
+    lane_s = [[0.0] * (reps + 1) for _ in range(n_lanes)]
+    errors = []
+
+    def run(k):
+        try:
+            with lanes[k]:
+                for r in range(reps + 1):
+                    start.wait()
+                    t0 = time.perf_counter()
+                    for i in range(steps):
+                        steppers[k].step(outs[k][i])
+                    lanes[k].synchronize()
+                    lane_s[k][r] = time.perf_counter() - t0
+                    done.wait()
+        except Exception as e:                                 # noqa: BLE001  (reported by the main thread)
+            errors.append(repr(e))
+            start.abort()
+            done.abort()
+    threads = [threading.Thread(target=run, args=(k, ), daemon=True) for k in range(n_lanes)]
+    for t in threads:
+        t.start()
+    wall = []
+    try:
+        for r in range(reps + 1):
+            start.wait()
+            t0 = time.perf_counter()
+            done.wait()
+            wall.append(time.perf_counter() - t0)
+    except threading.BrokenBarrierError:
+        pass
+    for t in threads:
+        t.join(timeout=60)
+    if errors:
+        return {'error': errors[0][:300]}
+    for k, lane in enumerate(lanes):
+        with lane:
+            steppers[k].acc.store.check_status()
+    wall = wall[1:]                                            # the first repetition warms up
+    dt = float(np.median(wall))
+    per_lane = [float(np.median(ls[1:])) for ls in lane_s]
+    # the same on ONE lane, measured the same way right here (same box, same thermal state): the ratio's denominator
+    with lanes[0]:
+        one = []
+        for r in range(reps + 1):
+            lanes[0].synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                steppers[0].step(outs[0][i])
+            lanes[0].synchronize()
+            one.append(time.perf_counter() - t0)
+        steppers[0].acc.store.check_status()
+    one_dt = float(np.median(one[1:]))
+    checks = [int(o.view(torch.int16).to(torch.int64).sum().item()) for o in outs]
+    return {'lanes': n_lanes, 'driven_by': 'one host thread per lane (own pca_ctx + stream each)', 'steps_per_lane': steps,
+            'repetitions': reps, 'Mpoints_per_s': n_lanes * N_PTS * steps / dt / 1e6, 'bev_frames_per_s': n_lanes * steps / dt,
+            'ms_per_step_per_sequence': [1e3 * t / steps for t in per_lane], 'ms_per_step_aggregate': 1e3 * dt / steps / n_lanes,
+            'one_lane_alone': {'Mpoints_per_s': N_PTS * steps / one_dt / 1e6, 'ms_per_step': 1e3 * one_dt / steps},
+            'aggregate_over_one_lane': one_dt * n_lanes / dt, 'plane_checksums': checks}
+
+
+def two_ranks_one_gpu_pass(steps, warmup):
+    """The same question answered with two PROCESSES (no GIL between the sequences): bench.py itself as two gloo ranks that
+    share the one GPU (the rehearsal path of tests/test_gpu_bench.py), each rank its own sequence; `value` of that run is the
+    aggregate over both.  This process sleeps meanwhile (its memory stays allocated, its streams are idle)."""
+    env = dict(os.environ, PCA_BENCH_BACKEND='gloo', PCA_BENCH_CHILD='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '2', '--steps', str(steps), '--warmup', str(warmup),
+           '--no-extras', '--no-cpu-baseline']
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    except subprocess.TimeoutExpired:
+        return {'error': 'timeout'}
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    if p.returncode != 0 or not line:
+        return {'error': (p.stderr or p.stdout)[-300:]}
+    d = json.loads(line[-1])
+    return {'ranks': 2, 'backend': 'gloo (two processes on ONE GPU; no data-path collective)', 'Mpoints_per_s': d['value'],
+            'bev_frames_per_s': d['bev_frames_per_s'], 'ms_per_step_per_sequence': d['ms_per_step'],
+            'repeats': d.get('repeats', {}).get('n'), 'wall_s_of_the_child_run': time.perf_counter() - t0}
+
+
+def kitti_icp_flow_pass(steps=30):
+    """The KITTI flow as the reference's own driver runs it (run_kitti360_bev_gen.py:146-155 passes no poses: every frame goes
+    through ICP, kitti360_sem_pc_accum.py:115-127): integrate() with the device ICP as pose source (PCA_POSE_PROVIDER=gpu_icp:
+    previous sweep -> new sweep, point-to-plane) on CONSECUTIVE ring-model frames from HOST arrays, one BEV per frame, planes
+    back on the host one step later (LazyBev).  The pose chain is sequential, so this flow cannot be chunk-sharded; its step
+    is bound by the registration.  The street of the ring model repeats every 25 m, so 25 frames cycle into a 1 m / frame drive."""
+    import torch
+    host_pool = [ring_frame(3, k) for k in range(25)]
+    cur = {'k': 0}
+
+    class HostSemSeg:
+        def pred(self, rgb):
+            return host_pool[cur['k'] % 25][2][None, None]
+    acc = new_accumulator(HostSemSeg())
+    icp_s = [0.0, 0]
+    provider = acc._gpu_icp_pose
+
+    def timed_pose(pc):
+        t0 = time.perf_counter()
+        T = provider(pc)
+        icp_s[0] += time.perf_counter() - t0
+        icp_s[1] += 1
+        return T
+    acc.pose_provider = timed_pose
+
+    def step(k):
+        pc, img, _ = host_pool[k % 25]
+        cur['k'] = k
+        acc.integrate([(img, pc, None)])
+        idx = present_index(acc)
+        return None if idx is None else acc.generate_bev(idx, 1, gen_future=True)[0]
+    k = 0
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')                        # (the 4 m search cap of the device ICP: said once per process)
+        while present_index(acc) is None or len(acc.poses) < 150:
+            step(k)
+            k += 1
+            if k > 400:
+                break
+        filled = k
+        for _ in range(3):
+            step(k)
+            k += 1
+        torch.cuda.synchronize()
+        icp_s[0], icp_s[1] = 0.0, 0
+        Ts = []
+        t0 = time.perf_counter()
+        parked = None
+        for _ in range(steps):
+            bev = step(k)
+            k += 1
+            bev, parked = parked, bev
+            if bev is not None:
+                assert bev['rgb_full'].shape == (3, PX, PX)
+            Ts.append(acc.T_prev_origin.copy())
+        if parked is not None:
+            assert parked['rgb_full'].shape == (3, PX, PX)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    acc.store.check_status()
+    # the drive the registrations recovered: the scene slides by 1 m per frame along x
+    adv = [float(np.linalg.norm((np.linalg.inv(Ts[i]) @ Ts[i + 1])[:3, 3])) for i in range(len(Ts) - 1)]
+    return {'workload': 'integrate() with PCA_POSE_PROVIDER=gpu_icp on consecutive ring-model frames (120 k points, host arrays) '
+                        '+ one 256^2 BEV per frame, planes to the host one step later; %d live frames' % acc.store.n_frames,
+            'steps': steps, 'frames_to_fill': filled, 'ms_per_step': 1e3 * dt / steps, 'Mpoints_per_s': N_PTS * steps / dt / 1e6,
+            'bev_frames_per_s': steps / dt, 'icp_ms_per_registration': 1e3 * icp_s[0] / max(icp_s[1], 1),
+            'icp_share_of_step': icp_s[0] / dt, 'metres_per_frame_recovered_mean': float(np.mean(adv)) if adv else None,
+            'metres_per_frame_recovered_minmax': [float(np.min(adv)), float(np.max(adv))] if adv else None,
+            'note': 'sequential pose chain: not chunk-shardable; whole sequences still shard over the GPUs'}
+
+
 # --------------------------------------------------------------------------------------------------------------------
 #  BASELINE configs[4]: the nine KITTI-360 sequences sharded over the ranks (strong scaling)
 # --------------------------------------------------------------------------------------------------------------------
-def config5_pass(rank, world, scale, barrier, allmax, coll_dev, dist):
+def config5_pass(rank, world, scale, barrier, allmax, coll_dev, dist, lanes_per_gpu=1):
     """Every rank plans the whole job (host replay of the sample trigger, identical everywhere), runs its own chunks --
     warm-up prefix through integrate_many, then integrate + BEV at the sample jobs -- and keeps its BEVs in HBM; the last
     GATHER_CHUNK samples of every rank go to rank 0 as a content check (checksums compared).  Timed: barrier .. barrier
@@ -724,23 +906,29 @@ def config5_pass(rank, world, scale, barrier, allmax, coll_dev, dist):
         return pools[seq]
     for j in jobs[rank]:
         pool_of(j.seq)
-    ring = torch.empty((GATHER_CHUNK, 21, PX, PX), dtype=torch.float16, device='cuda')
-    state = {'n': 0}
+    # (every lane keeps its last GATHER_CHUNK samples; lane 0's are what the content check sends to rank 0)
+    n_lanes = max(1, min(int(lanes_per_gpu), len(jobs[rank]))) if jobs[rank] else 1
+    rings = [torch.empty((GATHER_CHUNK, 21, PX, PX), dtype=torch.float16, device='cuda') for _ in range(n_lanes)]
+    ring = rings[0]
+    counts = [0] * n_lanes
+    torch.cuda.synchronize()
+
+    def run_job(job, lane):
+        acc = new_accumulator(model, T)
+        pool = pool_of(job.seq)
+
+        def get_obs(f):
+            rgb, pc, _ = pool[f % POOL]
+            return [(rgb, pc, None)]
+
+        def on_sample(f, present_idx):
+            acc.generate_bev_device(present_idx, out=rings[lane][counts[lane] % GATHER_CHUNK])
+            counts[lane] += 1
+        sr.run_chunk(acc, get_obs, job, on_sample, warm_batch=64)
+        acc.store.check_status()
 
     def run():
-        for job in jobs[rank]:
-            acc = new_accumulator(model, T)
-            pool = pool_of(job.seq)
-
-            def get_obs(f):
-                rgb, pc, _ = pool[f % POOL]
-                return [(rgb, pc, None)]
-
-            def on_sample(f, present_idx, acc=acc):
-                acc.generate_bev_device(present_idx, out=ring[state['n'] % GATHER_CHUNK])
-                state['n'] += 1
-            sr.run_chunk(acc, get_obs, job, on_sample, warm_batch=64)
-            acc.store.check_status()
+        sr.run_on_lanes(jobs[rank], run_job, n_lanes)
     import builtins
     real_print, builtins.print = builtins.print, (lambda *a, **k: None)
     try:
@@ -760,7 +948,7 @@ def config5_pass(rank, world, scale, barrier, allmax, coll_dev, dist):
            'scaling': 'strong', 'n_gpus': world, 'frames': total_frames, 'bev_samples': total_samples,
            'seconds': elapsed, 'Mpoints_per_s': total_frames * N_PTS / elapsed / 1e6,
            'bev_frames_per_s': total_samples / elapsed,
-           'frames_incl_warmup_per_rank': loads, 'plan_seconds_host': plan_s,
+           'frames_incl_warmup_per_rank': loads, 'plan_seconds_host': plan_s, 'lanes_per_gpu': n_lanes,
            'ideal_speedup_of_this_plan': float(total_frames) / max(loads)}
     # content check: the last chunk of every rank -> rank 0, checksums compared.  A failure of the check's own collectives
     # is reported in the block, it does not take the measurement above down with it.
@@ -939,6 +1127,8 @@ def main():
                     help='config2 = the per-frame step on one sequence per rank (headline, weak scaling); config5 = the nine '
                          'KITTI-360 sequences sharded over the ranks as the headline value (strong scaling)')
     ap.add_argument('--config5-scale', type=float, default=0.1, help='fraction of the nine sequence lengths (1 = 74 367 frames)')
+    ap.add_argument('--lanes', type=int, default=int(os.environ.get('PCA_LANES', '1')),
+                    help='config 5: chunks of a rank run on this many lanes (host thread + pca_ctx + stream each) at once')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--scene', choices=['uniform', 'ring'], default='uniform',
                     help='uniform = SURVEY 8d K-shape frame (headline); ring = 64-beam ring model')
@@ -1000,7 +1190,7 @@ def main():
     quiet = lambda *a, **k: None                      # the accumulator prints one line per frame, as the reference
 
     if args.workload == 'config5':
-        c5 = config5_pass(rank, world, args.config5_scale, barrier, allmax, coll_dev, dist)
+        c5 = config5_pass(rank, world, args.config5_scale, barrier, allmax, coll_dev, dist, args.lanes)
         if rank == 0:
             out = {'metric': 'Mpoints/s projected+accumulated and BEV frames/s @256x256; 1/2/4/8 GPU',
                    'value': c5['Mpoints_per_s'], 'unit': 'Mpoints/s', 'bev_frames_per_s': c5['bev_frames_per_s'],
@@ -1111,16 +1301,29 @@ def main():
 
     # ---- the step as an unchanged driver runs it (host arrays in, host dict out): right after the headline, on its
     #      accumulator, before the passes that churn through tens of GB ----
-    pcie = None
+    pcie = two_seq = None
     if rank == 0 and world == 1 and not args.no_extras:
         builtins.print = quiet
         pcie = pcie_inclusive_pass(acc, pool, min(args.steps, 30))
+        # two independent sequences on this GPU (threads with a lane each; then two processes): right after the headline,
+        # before the passes that churn through tens of GB
+        two_seq = two_sequences_pass(max(args.steps, 20))
+        two_seq['single_sequence_headline_Mpoints_per_s'] = N_PTS * args.steps / elapsed / 1e6
+        two_seq['aggregate_over_headline'] = two_seq.get('Mpoints_per_s', 0.0) / (N_PTS * args.steps / elapsed / 1e6)
         builtins.print = real_print
+        two_seq['two_processes'] = two_ranks_one_gpu_pass(max(args.steps, 20), args.warmup)
+        if 'Mpoints_per_s' in two_seq['two_processes']:
+            two_seq['two_processes']['aggregate_over_headline'] = two_seq['two_processes']['Mpoints_per_s'] / (N_PTS * args.steps / elapsed / 1e6)
 
     # ---- BASELINE configs[4] at this N: every rank takes part (strong-scaling job, reported beside `value`) ----
     c5 = None
     if not args.no_extras:
-        c5 = config5_pass(rank, world, args.config5_scale, barrier, allmax, coll_dev, dist)
+        c5 = config5_pass(rank, world, args.config5_scale, barrier, allmax, coll_dev, dist, args.lanes)
+        if args.lanes == 1 and world == 1 and rank == 0:
+            # the same job with two chunks at a time on the one GPU (two lanes): reported beside, adopted as the default if it pays
+            c5b = config5_pass(rank, world, args.config5_scale, barrier, allmax, coll_dev, dist, 2)
+            c5['two_lanes'] = {k: c5b[k] for k in ('seconds', 'Mpoints_per_s', 'bev_frames_per_s', 'lanes_per_gpu')}
+            c5['two_lanes']['speedup_over_one_lane'] = c5['seconds'] / c5b['seconds']
 
     if rank != 0:
         if use_dist:
@@ -1131,6 +1334,7 @@ def main():
     if world == 1 and not args.no_extras:
         builtins.print = quiet
         side['pcie_inclusive'] = pcie
+        side['two_sequences'] = two_seq
         side['k1_batched'] = k1_batched_pass(pool, POOL)
         side['k1_batched']['note'] = ('%d distinct frames repeated: the 32 MB of inputs stay in L2 / Infinity Cache between calls -- '
                                       'NOT an HBM figure; k1_batched_distinct is the one to compare with the 0.5 target' % POOL)
@@ -1149,6 +1353,7 @@ def main():
                                                              note='32 beams x 1085 azimuth steps in sweep order, pixels from '
                                                                   'azimuth / elevation: neighbours in the array are neighbours in the image')
         side['config4'] = config4_pass()
+        side['kitti_icp_flow'] = kitti_icp_flow_pass()
         if not args.no_ring and args.scene == 'uniform':
             side['ring_model'] = ring_model_pass(min(args.steps, 50))
         side['extras'] = extras_pass(acc)                  # mutates the store: last use of `acc`

@@ -4,6 +4,7 @@ There is no CPU fallback: if ``libpca_hip.so`` is missing or no GPU is visible t
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -196,9 +197,12 @@ def load():
 
 
 class Context:
-    """One pca_ctx per (process, GPU).  All calls are enqueued on torch's current stream."""
+    """One pca_ctx per (process, GPU) -- plus one per LANE (see `Lane`): a second independent sequence on the same GPU gets
+    its own context (look-back state, K1 / K1n staging, copy streams, status words are per context and assume one call
+    sequence at a time).  All calls are enqueued on torch's current stream."""
 
     _by_device = {}
+    _tls = threading.local()              # .lane: the Context this THREAD works on while inside `with Lane(...)`
 
     def __init__(self, device_index):
         import torch
@@ -221,9 +225,18 @@ class Context:
             raise RuntimeError('pca_amd needs an AMD GPU (torch.cuda.is_available() is False); '
                                'there is no CPU fallback')
         idx = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+        lane = getattr(cls._tls, 'lane', None)
+        if lane is not None and lane.device_index == idx:
+            return lane
         if idx not in cls._by_device:
             cls._by_device[idx] = Context(idx)
         return cls._by_device[idx]
+
+    def destroy(self):
+        """Frees the context's device / pinned blocks (lanes; the per-device context lives as long as the process)."""
+        if self.h is not None:
+            self.lib.pca_ctx_destroy(self.h)
+            self.h = None
 
     def stream(self):
         """Raw handle of torch's current stream on this device (every call targets it)."""
@@ -282,3 +295,42 @@ class Context:
         st = C.c_uint32(0)
         self.check(self.lib.pca_status(self.h, self.stream(), C.byref(st)))
         return st.value
+
+
+class Lane:
+    """An independent call sequence on one GPU: its own pca_ctx and its own torch stream.  Inside `with lane:` the calling
+    THREAD's Context.get() is the lane's context and torch's current stream is the lane's stream, so that accumulators
+    created and driven there neither share workspaces with, nor queue behind, another lane's.  What this is for: two
+    independent sequences (scene shards: run_kitti360_bev_gen.py:161-173 of the reference loops over them) on one GPU, each
+    driven from its own host thread -- the kernels of one fill the CUs the other's tails leave idle.  ctypes releases the GIL
+    for the duration of a library call; the host-side staging pool and the constant-memory argument array of
+    pca_bev_generate_many are shared by all lanes and take turns (mutex)."""
+
+    def __init__(self, device=None, priority=0):
+        import torch
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+        self.ctx = Context(idx)
+        self.stream = torch.cuda.Stream(device=idx, priority=priority)
+        self._guard = None
+        self._outer = None
+
+    def __enter__(self):
+        import torch
+        self._outer = getattr(Context._tls, 'lane', None)
+        Context._tls.lane = self.ctx
+        self._guard = torch.cuda.stream(self.stream)
+        self._guard.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self._guard.__exit__(*exc)
+        Context._tls.lane = self._outer
+        self._guard = None
+        return False
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def close(self):
+        self.stream.synchronize()
+        self.ctx.destroy()

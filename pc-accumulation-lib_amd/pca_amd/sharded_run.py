@@ -144,14 +144,49 @@ def run_chunk(acc, get_obs, job, on_sample, warm_batch=64):
     return taken
 
 
-def run_rank(rank_jobs, make_accumulator, get_obs_for, on_bev, warm_batch=64, bev_num=1):
+def run_on_lanes(jobs, run_job, n_lanes=1, device=None):
+    """run_job(job, lane_index) for every job of this rank.  n_lanes > 1: the jobs are dealt to that many LANES (longest
+    first onto the least loaded lane) -- a lane is a host thread with its own pca_ctx and stream (pca_amd._lib.Lane), so that
+    the chunks of two lanes run on the GPU at the same time and one's kernels fill the CUs the other's tails leave idle.
+    Chunks are independent (fresh accumulator each), so which lane runs which chunk changes no result.  Returns per lane the
+    list of run_job's return values, in the order that lane ran its jobs."""
+    jobs = list(jobs)
+    if n_lanes <= 1 or len(jobs) <= 1:
+        return [[run_job(j, 0) for j in jobs]]
+    import threading
+
+    from . import _lib
+    n_lanes = min(n_lanes, len(jobs))
+    items, _ = shard.lpt_assign([j.cost for j in jobs], n_lanes)
+    lanes = [_lib.Lane(device) for _ in range(n_lanes)]
+    out, errors = [[] for _ in range(n_lanes)], []
+
+    def work(k):
+        try:
+            with lanes[k]:
+                for i in sorted(items[k], key=lambda i: (jobs[i].seq, jobs[i].start)):
+                    out[k].append(run_job(jobs[i], k))
+                lanes[k].synchronize()
+        except BaseException as e:                             # noqa: BLE001  (re-raised on the caller's thread)
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(k, )) for k in range(n_lanes)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
+def run_rank(rank_jobs, make_accumulator, get_obs_for, on_bev, warm_batch=64, bev_num=1, lanes=1):
     """All chunks of one rank.  make_accumulator(seq) -> fresh accumulator; get_obs_for(seq) -> get_obs callable;
-    on_bev(seq, frame, bevs) receives generate_bev's list.  Returns the number of samples."""
-    n = 0
-    for job in rank_jobs:
+    on_bev(seq, frame, bevs) receives generate_bev's list (lanes > 1: from that many threads -- see run_on_lanes).
+    Returns the number of samples."""
+    def run_job(job, lane):
         acc = make_accumulator(job.seq)
 
-        def on_sample(f, present_idx, acc=acc, job=job):
+        def on_sample(f, present_idx):
             on_bev(job.seq, f, acc.generate_bev(present_idx, bev_num, gen_future=True))
-        n += run_chunk(acc, get_obs_for(job.seq), job, on_sample, warm_batch)
-    return n
+        return run_chunk(acc, get_obs_for(job.seq), job, on_sample, warm_batch)
+    return sum(sum(per_lane) for per_lane in run_on_lanes(rank_jobs, run_job, lanes))

@@ -47,6 +47,49 @@ def test_two_chunks_with_warm_up_equal_the_sequential_run():
         assert np.array_equal(got[f].view(np.uint16), ref[f].view(np.uint16)), f
 
 
+def test_two_chunks_on_two_concurrent_lanes_equal_the_sequential_run():
+    """Two chunks at the SAME time on one GPU -- a lane each: own pca_ctx, own stream, own host thread (sharded_run.run_on_lanes)
+    -- give, BEV for BEV, the bits of the sequential single-lane run; so do two whole sequences side by side."""
+    import threading
+
+    from pca_amd import _lib
+    from pca_amd import sharded_run as sr
+    Ts = sc.transforms(330)
+    jobs, _, samples = sr.plan([Ts], 2, sc.ACCUM_H, sc.BEV_H, sc.SPACING)
+    chunks = sorted((j for r in jobs for j in r), key=lambda j: j.start)
+    assert len(chunks) == 2
+    ref = sc.run_job(sr.ChunkJob(0, 0, 0, 330, samples[0]), Ts)
+    seen_ctx = set()
+
+    def run_job(job, lane):
+        seen_ctx.add((threading.get_ident(), _lib.Context.get().h.value))
+        return sc.run_job(job, Ts)
+    per_lane = sr.run_on_lanes(chunks, run_job, n_lanes=2)
+    assert len(per_lane) == 2 and len(seen_ctx) == 2                  # two threads, two contexts
+    assert len({c for _, c in seen_ctx} | {_lib.Context.get().h.value}) == 3   # neither is the process-wide one
+    got = {}
+    for outs in per_lane:
+        for o in outs:
+            got.update(o)
+    assert sorted(got) == sorted(ref) == [f for f, _ in samples[0]]
+    for f in ref:
+        assert np.array_equal(got[f].view(np.uint16), ref[f].view(np.uint16)), f
+    # two whole, DIFFERENT sequences side by side against each one alone
+    Tb = sc.transforms(200, seed=11)
+    _, _, sb = sr.plan([Tb], 1, sc.ACCUM_H, sc.BEV_H, sc.SPACING)
+    ja, jb = sr.ChunkJob(0, 0, 0, 330, samples[0]), sr.ChunkJob(1, 0, 0, 200, sb[0])
+    alone_b = sc.run_job(jb, Tb, seq=1)
+    side = sr.run_on_lanes([ja, jb], lambda job, lane: sc.run_job(job, Ts if job.seq == 0 else Tb, seq=job.seq), n_lanes=2)
+    both = {}
+    for outs in side:
+        for o in outs:
+            both[len(o)] = o
+    a2, b2 = both[len(ref)], both[len(alone_b)]
+    assert len(ref) != len(alone_b) and len(alone_b) > 50
+    assert all(np.array_equal(a2[f].view(np.uint16), ref[f].view(np.uint16)) for f in ref)
+    assert all(np.array_equal(b2[f].view(np.uint16), alone_b[f].view(np.uint16)) for f in alone_b)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
