@@ -1,4 +1,5 @@
 // pca_api.hip -- context, error reporting and look-back workspace management (C ABI, include/pca.h).
+#include <stdio.h>
 #include "pca_common.h"
 
 __global__ __launch_bounds__(256) void pca_fetch_block_kernel(const uint4 *src, uint4 *dst, int64_t n16)
@@ -147,24 +148,30 @@ int pca_ctx_create(int device, pca_ctx **out)
     *out = nullptr;
     pca_ctx *ctx = new pca_ctx();
     ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->ticket, 4 * sizeof(uint32_t)) != hipSuccess ||
-        hipMemset(ctx->ticket, 0, 4 * sizeof(uint32_t)) != hipSuccess ||
-        hipHostMalloc(&ctx->status_host, sizeof(uint32_t)) != hipSuccess ||
-        hipHostMalloc(&ctx->status_mirror, PCA_STATUS_BITS * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
-        hipHostMalloc(&ctx->heavy_hint, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) {
-        delete ctx;
-        return -1;
-    }
+    // (a failure here has no context to carry its message: it goes to stderr, naming the call)
+#define PCA_CREATE_STEP(expr)                                                                                          \
+    do {                                                                                                               \
+        const hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                        \
+            fprintf(stderr, "pca_ctx_create(device %d): %s failed: %s\n", device, #expr, hipGetErrorString(e_));       \
+            delete ctx;                                                                                                \
+            return -1;                                                                                                 \
+        }                                                                                                              \
+    } while (0)
+    PCA_CREATE_STEP(hipSetDevice(device));
+    PCA_CREATE_STEP(hipMalloc(&ctx->ticket, 4 * sizeof(uint32_t)));
+    PCA_CREATE_STEP(hipMemset(ctx->ticket, 0, 4 * sizeof(uint32_t)));
+    PCA_CREATE_STEP(hipHostMalloc(&ctx->status_host, sizeof(uint32_t)));
+    PCA_CREATE_STEP(hipHostMalloc(&ctx->status_mirror, PCA_STATUS_BITS * sizeof(uint32_t), hipHostMallocMapped));
+    PCA_CREATE_STEP(hipHostMalloc(&ctx->heavy_hint, sizeof(uint32_t), hipHostMallocMapped));
     int n_cu = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) ctx->n_cu = n_cu;
     *ctx->heavy_hint = 1;            // first call: assume heavy tiles exist
     for (int b = 0; b < PCA_STATUS_BITS; ++b) ctx->status_mirror[b] = 0;
-    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->heavy_hint_dev), ctx->heavy_hint, 0) != hipSuccess ||
-        hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->status_mirror_dev), ctx->status_mirror, 0) != hipSuccess ||
-        hipMemcpy(ctx->ticket + 2, &ctx->status_mirror_dev, sizeof(void *), hipMemcpyHostToDevice) != hipSuccess) {
-        delete ctx;
-        return -1;
-    }
+    PCA_CREATE_STEP(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->heavy_hint_dev), ctx->heavy_hint, 0));
+    PCA_CREATE_STEP(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->status_mirror_dev), ctx->status_mirror, 0));
+    PCA_CREATE_STEP(hipMemcpy(ctx->ticket + 2, &ctx->status_mirror_dev, sizeof(void *), hipMemcpyHostToDevice));
+#undef PCA_CREATE_STEP
     *out = ctx;
     return 0;
 }
@@ -198,6 +205,8 @@ void pca_ctx_destroy(pca_ctx *ctx)
     if (ctx->k1n_desc_dev) (void)hipFree(ctx->k1n_desc_dev);
     if (ctx->k1n_pin) (void)hipHostFree(ctx->k1n_pin);
     if (ctx->k1n_ev) (void)hipEventDestroy(ctx->k1n_ev);
+    if (ctx->icp_cnt) (void)hipFree(ctx->icp_cnt);
+    if (ctx->icp_host) (void)hipHostFree(ctx->icp_host);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     if (ctx->status_mirror) (void)hipHostFree(ctx->status_mirror);
     if (ctx->heavy_hint) (void)hipHostFree(ctx->heavy_hint);

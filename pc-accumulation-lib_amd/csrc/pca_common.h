@@ -75,6 +75,14 @@ struct pca_ctx {
     unsigned long long *dbg = nullptr; // diagnostic stamps of the last K1 launch (PCA_K1_STAMPS)
     int dbg_blocks = 0;
     int heavy_cooldown = 0;           // calls for which bev_tile_cells_heavy is still launched after the last heavy tile
+    // device ICP (pca_icp.hip): the per-cell count tables of its grids, owned by the context because they are all zero again
+    // after every registration (no 134 MB of memsets per call), and the registration's state as the host sees it --
+    // mapped host memory the solve kernel stores into: the host polls it instead of copying and waiting
+    uint32_t *icp_cnt = nullptr;      // dev [levels][cells]
+    bool icp_cnt_dirty = true;        // not known to be all zero (first use, or a call that failed half way)
+    double *icp_host = nullptr;       // pinned + mapped [32]: T, fitness, rmse, iterations, flag; [31] = (call << 8 | pass) tag
+    double *icp_host_dev = nullptr;
+    uint32_t icp_call = 0;
     uint32_t *status_host = nullptr;  // pinned
     uint32_t *heavy_hint = nullptr;   // pinned, device-visible: heavy-tile count of the latest rasteriser call
     uint32_t *heavy_hint_dev = nullptr;

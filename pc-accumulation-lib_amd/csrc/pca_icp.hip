@@ -29,6 +29,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 
 // Two uniform grids of 512 x 512 x 64 cells around the sensor: level 0 = 0.5 m cells (256 m x 256 m x 32 m), level 1 =
 // 0.25 m cells (128 m x 128 m x 16 m).  Next to the sensor a 0.5 m cell holds ~300 returns: a query settles in the fine
@@ -46,6 +47,13 @@ template <int LV> struct IcpLevel {
 #define ICP_NORMAL_RINGS 6       // search cap of the normals: 3 m (coarse rings)
 #define ICP_MATCH_RINGS 8        // search cap of a correspondence: 4 m (the reference passes 1e3 m = everything)
 #define ICP_THREADS 256
+// Waves per SIMD the compiler is asked for on the search kernels (their 104-108 VGPRs allow four; five costs 6-16 spilled
+// registers and measured 1.47 against 1.50 ms per registration, six 1.59: profiles/r05_experiments/icp_round5.txt).
+// -DICP_WAVES_PER_EU=<n>: A/B builds (tools/experiments/icp_ab.sh)
+#ifndef ICP_WAVES_PER_EU
+#define ICP_WAVES_PER_EU 5
+#endif
+#define ICP_OCC __attribute__((amdgpu_waves_per_eu(ICP_WAVES_PER_EU)))
 #define ICP_NACC 30              // 21 (J^T J upper) + 6 (J^T r) + sum d^2 + inliers + sum r^2
 #define ICP_CHECK_EVERY 12        // the host looks at the convergence flag after every 12th pass (a look = a copy + a wait: 45 us of idle
                                   // GPU; a pass after convergence = two early-exit launches: 9 us.  Registrations take 5-15 updates)
@@ -66,7 +74,8 @@ struct IcpArgs {
     int32_t *nn_cell;            // [n_src] coarse cell the query lay in when it was searched last, -1 = outside the grid
     float *nn_slack;             // [n_src] how far the query may still move before its partner has to be searched again (icp_match)
     int no_skip;                 // PCA_ICP_NO_SKIP=1: every pass searches every query (A/B)
-    int dbg;                     // PCA_ICP_DBG=1: searched queries per pass counted in state[48 + pass] and printed by the host
+    int dbg;                     // PCA_ICP_DBG bit 0: searched queries per pass counted in state[48 + pass] and printed by the host;
+                                 // bits 1, 2: ablations of icp_normals (no eigen decomposition / no covariance pass), timing only
     uint64_t *lb_state;          // decoupled look-back of the cell scan
     uint32_t epoch;
     double *partial;             // [ICP_NACC][grid] partial sums, one column per workgroup of icp_match
@@ -81,6 +90,9 @@ struct IcpArgs {
     double max_dist2;
     double rel_fitness, rel_rmse;
     int grid;
+    double *host;                // mapped host memory [32]: what icp_solve_step stores into state[0..21], and [31] = the tag
+    uint64_t tag;                // (call << 16) of this registration; icp_solve publishes tag | ended << 8 | passes done
+    int pass;                    // number of this pass (0 = first)
 };
 
 template <int LV>
@@ -375,9 +387,13 @@ __device__ __forceinline__ bool icp_in_fine_box(const float4 w, int cx, int cy, 
 __device__ __forceinline__ void icp_smallest_eigvec(double A[3][3], double n[3])
 {
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    // (a rotation changes nothing once the off-diagonal part is below 2^-60 of the diagonal: cyclic Jacobi converges
+    // quadratically, so that is one sweep after 1e-9 -- round 4 ran until 1e-300, three to four sweeps of pure rounding noise
+    // on ONE lane of eight while the group waits: 100 of the kernel's 423 us)
+    const double tiny = (fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2])) * 8.7e-19;
     for (int sweep = 0; sweep < 12; ++sweep) {
         const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
-        if (off < 1e-300) break;
+        if (off <= tiny) break;
 #pragma unroll
         for (int pq = 0; pq < 3; ++pq) {
             const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
@@ -440,7 +456,7 @@ __device__ __forceinline__ double icp_group_sum(double v)
 // the eight lists exactly (bisection on the bit patterns), which is the cull bound of the next shell and decides whether
 // the search has settled.  The covariance pass deals the records out the same way and adds the
 // eight partial sums up in a fixed butterfly.
-__global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
+__global__ __launch_bounds__(ICP_THREADS) ICP_OCC void icp_normals(const IcpArgs a)
 {
     __shared__ float s_d[ICP_K][ICP_THREADS];               // per lane: the K smallest squared distances it saw (unsorted)
     const int p = (blockIdx.x * ICP_THREADS + threadIdx.x) / ICP_SG;   // original index
@@ -555,7 +571,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
         }
     const uint32_t total = icp_group_sum((uint32_t)found);
     if (kth < __builtin_huge_valf()) merge_kth();           // the exact K-th distance (at most the bound)
-    if (total >= 3) {
+    if (total >= 3 && !(a.dbg & 4)) {                       // (PCA_ICP_DBG=4: ablation, no covariance pass)
         // the search radius of pass B: the K-th distance, or -- fewer than K points inside the search cap -- the largest
         float lim = kth;
         if (!(lim < __builtin_huge_valf())) {
@@ -595,8 +611,8 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_normals(const IcpArgs a)
             A[0][0] = sxx * inv - mx * mx; A[0][1] = sxy * inv - mx * my; A[0][2] = sxz * inv - mx * mz;
             A[1][1] = syy * inv - my * my; A[1][2] = syz * inv - my * mz; A[2][2] = szz * inv - mz * mz;
             A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
-            double n[3];
-            icp_smallest_eigvec(A, n);
+            double n[3] = {0.0, 0.0, 1.0};
+            if (!(a.dbg & 2)) icp_smallest_eigvec(A, n);    // (PCA_ICP_DBG=2: ablation, no eigen decomposition)
             const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
             if (len > 0) out = make_float4((float)(n[0] / len), (float)(n[1] / len), (float)(n[2] / len), 1.f);
         }
@@ -619,20 +635,23 @@ __device__ __forceinline__ double icp_from_lane(double v, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-__device__ void icp_solve_step(const IcpArgs &a, const double *sum, const IcpPrev &pv)
+// (returns true when this evaluation ended the registration: converged, too few pairs, singular system)
+__device__ bool icp_solve_body(const IcpArgs &a, const double *sum, const IcpPrev &pv)
 {
-    double *S = a.state;
+    // every store goes to the device state AND to its host-visible mirror (mapped memory; lane 0 only)
+    struct Both { double *s, *h; __device__ __forceinline__ void put(int k, double v) const { s[k] = v; h[k] = v; } };
+    const Both S{a.state, a.host};
     const int lane = threadIdx.x & 63;
     const double inl = sum[28];
     const double fitness = a.n_src > 0 ? inl / a.n_src : 0.0;
     const double rmse = inl > 0 ? sqrt(sum[27] / inl) : 0.0;
     // Open3D evaluates fitness / rmse of the CURRENT transform, then updates; convergence compares successive evaluations
     const bool first = pv.iters == 0.0;
-    if (lane == 0) { S[16] = fitness; S[17] = rmse; }
+    if (lane == 0) { S.put(16, fitness); S.put(17, rmse); }
     const bool conv = !first && fabs(pv.fit - fitness) < a.rel_fitness && fabs(pv.rmse - rmse) < a.rel_rmse;
-    if (icp_lane0(conv ? 1.0 : 0.0) != 0.0) { if (lane == 0) S[20] = 1.0; return; }
-    if (lane == 0) { S[18] = fitness; S[19] = rmse; }
-    if (inl < 6) { if (lane == 0) S[20] = 1.0; return; }    // (uniform: sum[] is shared)
+    if (icp_lane0(conv ? 1.0 : 0.0) != 0.0) { if (lane == 0) S.put(20, 1.0); return true; }
+    if (lane == 0) { S.put(18, fitness); S.put(19, rmse); }
+    if (inl < 6) { if (lane == 0) S.put(20, 1.0); return true; }    // (uniform: sum[] is shared)
     // solve (J^T J) x = -J^T r  (Cholesky, upper triangle stored row-wise in sum[0..20]).  Every loop has a constant trip
     // count and no early exit, so the 6x6 system lives in registers (indexed dynamically it sat in scratch memory: ~100
     // dependent scratch round trips, most of the kernel's 55 us)
@@ -658,7 +677,7 @@ __device__ void icp_solve_step(const IcpArgs &a, const double *sum, const IcpPre
             else A[i][j] = s * inv[j];
         }
     }
-    if (!ok) { if (lane == 0) S[20] = 1.0; return; }        // (uniform)
+    if (!ok) { if (lane == 0) S.put(20, 1.0); return true; }        // (uniform)
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double s = b[i];
@@ -683,15 +702,29 @@ __device__ void icp_solve_step(const IcpArgs &a, const double *sum, const IcpPre
                           -sb, cb * sa, cb * ca, x[5]};
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) S[32 + i] = pv.T[i];   // (icp_match: how far has a point moved since the last pass?)
+        for (int i = 0; i < 12; ++i) a.state[32 + i] = pv.T[i];   // (icp_match: how far has a point moved since the last pass?)
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                S[4 * i + j] = U[4 * i] * pv.T[j] + U[4 * i + 1] * pv.T[4 + j] + U[4 * i + 2] * pv.T[8 + j] + (j == 3 ? U[4 * i + 3] : 0.0);
-        S[21] = pv.iters + 1.0;
+                S.put(4 * i + j, U[4 * i] * pv.T[j] + U[4 * i + 1] * pv.T[4 + j] + U[4 * i + 2] * pv.T[8 + j] + (j == 3 ? U[4 * i + 3] : 0.0));
+        S.put(21, pv.iters + 1.0);
+    }
+    return false;
+}
+// the step, then the news for the host: tag | ended << 8 | passes done, released at system scope behind the stores above --
+// pca_icp_register polls that word in mapped memory instead of copying the state back and waiting for the stream
+__device__ void icp_solve_step(const IcpArgs &a, const double *sum, const IcpPrev &pv)
+{
+    const bool ended = icp_solve_body(a, sum, pv);
+    if ((threadIdx.x & 63) == 0) {
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<uint64_t *>(a.host + 31), a.tag | (ended ? 0x100ull : 0ull) | (uint64_t)(a.pass + 1),
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+
+
 
 // icp_match: ICP_SG neighbouring lanes share one source point.  The own cell's records and the rows of every further
 // shell are dealt out over the lanes, each lane keeps its own best partner, and at the end of every shell the lanes agree
@@ -766,7 +799,7 @@ __device__ __forceinline__ void icp_group_merge(IcpBest &b, double &other)
 #define ICP_QPW_MAX (ICP_THREADS / 8)     // queries per workgroup of icp_match, at most
 #define ICP_MARGIN 0.02                  // [m]
 template <int SG>
-__global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
+__global__ __launch_bounds__(ICP_THREADS) ICP_OCC void icp_match(const IcpArgs a)
 {
     constexpr int ICP_QPW = ICP_THREADS / SG;
     __shared__ double s_row[ICP_QPW][8];                    // per query: J[0..5], r, |q - t|^2
@@ -806,7 +839,10 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
                 if (prev >= 0) {
                     const double dx = t.x - qx, dy = t.y - qy, dz = t.z - qz;
                     const double d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 < a.max_dist2) { need = false; b.d2 = d2; b.idx = prev; b.x = t.x; b.y = t.y; b.z = t.z; }   // (else the search decides)
+                    // (the query's cell is compared as in the branch below: the search box is a function of that cell, and a step
+                    // across a cell border -- however short -- moves the box by half a metre: a partner 3.5-4 m away could leave it
+                    // or a nearer target enter it.  The comparison is free: the cell is known)
+                    if (d2 < a.max_dist2 && (in_coarse ? icp_cell_index(cx, cy, cz) : -1) == cell_ref) { need = false; b.d2 = d2; b.idx = prev; b.x = t.x; b.y = t.y; b.z = t.z; }   // (else the search decides)
                 } else if ((in_coarse ? icp_cell_index(cx, cy, cz) : -1) == cell_ref) {
                     need = false;                           // still nothing within the cap in the same box
                 }
@@ -908,7 +944,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_match(const IcpArgs a)
             }
         }
     }
-    if (a.dbg) { const uint64_t m = __ballot(need && sub == 0); if ((threadIdx.x & 63) == 0 && m) { const int it = (int)a.state[21]; atomicAdd(&a.state[48 + (it < 15 ? it : 15)], (double)__popcll(m)); } }
+    if (a.dbg & 1) { const uint64_t m = __ballot(need && sub == 0); if ((threadIdx.x & 63) == 0 && m) { const int it = (int)a.state[21]; atomicAdd(&a.state[48 + (it < 15 ? it : 15)], (double)__popcll(m)); } }
     // the query's row (one lane of its group)
     if (sub == 0) {
         uint32_t flag = 0u;
@@ -1011,6 +1047,15 @@ __global__ __launch_bounds__(ICP_SOLVE_THREADS) void icp_solve(const IcpArgs a)
     if (threadIdx.x < 64) icp_solve_step(a, s_sum, pv);
 }
 
+// state block and "first pass" marks in one launch (a 512-byte copy from pageable memory and a memset before)
+struct IcpInit { double st[32]; };
+__global__ __launch_bounds__(ICP_THREADS) void icp_init(const IcpArgs a, const IcpInit in)
+{
+    const int p = blockIdx.x * ICP_THREADS + threadIdx.x;
+    if (p < a.n_src) a.nn_prev[p] = (int)0xfefefefe;        // "first pass" (see icp_match)
+    if (blockIdx.x == 0 && threadIdx.x < 64) a.state[threadIdx.x] = threadIdx.x < 32 ? in.st[threadIdx.x] : 0.0;
+}
+
 extern "C" {
 
 static inline int64_t icp_align(int64_t v) { return (v + 255) & ~255ll; }
@@ -1040,8 +1085,21 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
     a.src = src_pts; a.tgt = tgt_pts; a.n_src = n_src; a.n_tgt = n_tgt;
     char *w = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     const int64_t cells = (int64_t)ICP_NX * ICP_NY * ICP_NZ;
+    // the count tables belong to the context: the fill pass leaves them all zero, so only a first use (or a call that
+    // failed half way) clears them -- 2 x 67 MB of memset per registration otherwise
+    if (!ctx->icp_cnt) {
+        PCA_CHECK(ctx, hipMalloc(&ctx->icp_cnt, (size_t)(2 * cells * 4)));
+        ctx->icp_cnt_dirty = true;
+    }
+    if (!ctx->icp_host) {
+        PCA_CHECK(ctx, hipHostMalloc(&ctx->icp_host, 32 * sizeof(double), hipHostMallocMapped));
+        memset(ctx->icp_host, 0, 32 * sizeof(double));
+        PCA_CHECK(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->icp_host_dev), ctx->icp_host, 0));
+    }
+    if (ctx->icp_cnt_dirty) PCA_CHECK(ctx, hipMemsetAsync(ctx->icp_cnt, 0, (size_t)(2 * cells * 4), s));
+    ctx->icp_cnt_dirty = true;                              // until this call has come through
     for (int lv = 0; lv < 2; ++lv) {
-        a.g[lv].cnt = reinterpret_cast<uint32_t *>(w); w += icp_align(cells * 4);
+        a.g[lv].cnt = ctx->icp_cnt + (size_t)lv * cells; w += icp_align(cells * 4);      // (the workspace's own slot stays unused)
         a.g[lv].start = reinterpret_cast<uint32_t *>(w); w += icp_align((cells + 1) * 4);
         a.g[lv].spts = reinterpret_cast<float4 *>(w); w += icp_align((int64_t)n_tgt * 16);
     }
@@ -1061,48 +1119,86 @@ int pca_icp_register(pca_ctx *ctx, const float *src_pts, int32_t n_src, const fl
     a.max_dist2 = max_corr_dist * max_corr_dist;
     a.rel_fitness = rel_fitness; a.rel_rmse = rel_rmse;
     a.grid = icp_grid(n_src);
-    double st[64] = {0};
+    a.host = ctx->icp_host_dev;
+    a.pass = 0;
+    // the word the host polls: tag of THIS call, nothing done yet.  (A kernel of an earlier registration that could still
+    // store into the mirror does not exist: the passes behind the one that ended a registration leave at their first line.)
+    ctx->icp_call = (ctx->icp_call + 1) & 0xffffffu;
+    a.tag = (uint64_t)ctx->icp_call << 16;
+    uint64_t *const tag_word = reinterpret_cast<uint64_t *>(ctx->icp_host + 31);
+    __atomic_store_n(tag_word, a.tag, __ATOMIC_RELEASE);
+    IcpInit in;
+    memset(&in, 0, sizeof in);
     static const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    for (int i = 0; i < 16; ++i) st[i] = init ? init[i] : eye[i];
+    for (int i = 0; i < 16; ++i) in.st[i] = init ? init[i] : eye[i];
     {
         const uint32_t zr0[4] = {0xffffffffu, 0u, 0xffffffffu, 0u};       // zmin, zmax + 1 of both grids: nothing seen yet
-        memcpy(&st[24], zr0, sizeof zr0);
+        memcpy(&in.st[24], zr0, sizeof zr0);
     }
-    PCA_CHECK(ctx, hipMemsetAsync(a.g[0].cnt, 0, (size_t)cells * 4, s));
-    PCA_CHECK(ctx, hipMemsetAsync(a.g[1].cnt, 0, (size_t)cells * 4, s));
-    PCA_CHECK(ctx, hipMemsetAsync(a.nn_prev, 0xfe, (size_t)n_src * 4, s));        // 0xfefefefe: "first pass" (see icp_match)
-    PCA_CHECK(ctx, hipMemcpyAsync(a.state, st, sizeof st, hipMemcpyHostToDevice, s));
+    for (int i = 0; i < 22; ++i) ctx->icp_host[i] = in.st[i];            // (a registration that ends before any update returns init)
     const int scan_tiles = (int)(cells / ICP_SCAN_TILE);
     if (pca_ctx_reserve_tiles(ctx, 2 * scan_tiles, s)) return -1;
     a.lb_state = ctx->tile_state;
     const dim3 per_point((n_tgt + ICP_THREADS - 1) / ICP_THREADS);
+    PCA_LAUNCH(ctx, PCA_K_ICP, icp_init, dim3((n_src + ICP_THREADS - 1) / ICP_THREADS), dim3(ICP_THREADS), s, a, in);
     PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_count, per_point, dim3(ICP_THREADS), s, a);
     a.epoch = pca_ctx_next_epoch(ctx, s);
     PCA_LAUNCH(ctx, PCA_K_ICP, icp_cell_scan, dim3(2 * scan_tiles), dim3(ICP_SCAN_THREADS), s, a);
     PCA_LAUNCH(ctx, PCA_K_ICP, icp_grid_fill, per_point, dim3(ICP_THREADS), s, a);
     PCA_LAUNCH(ctx, PCA_K_ICP, icp_normals, dim3(((int64_t)n_tgt * ICP_SG + ICP_THREADS - 1) / ICP_THREADS), dim3(ICP_THREADS), s, a);
-    // one more evaluation than updates: Open3D reports fitness / rmse of the final transform.  The loop never leaves the
-    // device inside a group of ICP_CHECK_EVERY passes; between groups the host reads the convergence flag (a pass after
-    // convergence is a no-op, the check only saves launching the rest of the 31)
-    for (int it = 0; it <= max_iter; ++it) {
+    // One more evaluation than updates: Open3D reports fitness / rmse of the final transform.  The host stays ICP_AHEAD passes
+    // ahead of the device -- pass k is launched once pass k - ICP_AHEAD has reported in through the mapped word -- so the queue
+    // never runs dry (a pass lasts 50-250 us, its two launches 10) and at most ICP_AHEAD no-op passes are in flight when the
+    // flag comes up.  Round 4 copied the state back and waited every twelfth pass: three no-op passes per registration (30 us),
+    // 45 us of idle GPU per look, and a copy + wait at the end.
+    constexpr int ICP_AHEAD = 2;
+    constexpr double ICP_POLL_TIMEOUT_S = 2.0;
+    auto news = [&]() -> uint64_t {                         // low 16 bits of the word if it carries this call's tag, else 0
+        const uint64_t t = __atomic_load_n(tag_word, __ATOMIC_ACQUIRE);
+        return (t >> 16) == (a.tag >> 16) ? (t & 0xffffu) : 0u;
+    };
+    bool ended = false, timed_out = false;
+    auto wait_for = [&](int passes_done) {                  // until that many passes have reported in, or the registration has ended
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0;; ++spins) {
+            const uint64_t v = news();
+            if (v & 0x100u) { ended = true; return; }
+            if ((int)(v & 0xffu) >= passes_done) return;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+            if ((spins & 1023u) == 1023u &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > ICP_POLL_TIMEOUT_S) { timed_out = true; return; }
+        }
+    };
+    int launched = 0;
+    for (int it = 0; it <= max_iter && !ended && !timed_out; ++it) {
+        if (it >= ICP_AHEAD) wait_for(it - ICP_AHEAD + 1);
+        if (ended || timed_out) break;
         if (it == max_iter) a.rel_fitness = a.rel_rmse = 1e300;              // last pass only evaluates
+        a.pass = it;
         if (it == 0) { a.grid = icp_grid(n_src, 16); PCA_LAUNCH(ctx, PCA_K_ICP, icp_match<16>, dim3(a.grid), dim3(ICP_THREADS), s, a); }
         else { a.grid = icp_grid(n_src, 8); PCA_LAUNCH(ctx, PCA_K_ICP, icp_match<8>, dim3(a.grid), dim3(ICP_THREADS), s, a); }
         PCA_LAUNCH(ctx, PCA_K_ICP, icp_solve, dim3(ICP_NACC), dim3(ICP_SOLVE_THREADS), s, a);
-        if (it % ICP_CHECK_EVERY == ICP_CHECK_EVERY - 1 && it < max_iter) {
-            PCA_CHECK(ctx, hipMemcpyAsync(st, a.state, sizeof st, hipMemcpyDeviceToHost, s));
-            PCA_CHECK(ctx, hipStreamSynchronize(s));
-            if (st[20] != 0.0) break;
-        }
+        ++launched;
     }
-    PCA_CHECK(ctx, hipMemcpyAsync(st, a.state, sizeof st, hipMemcpyDeviceToHost, s));
-    PCA_CHECK(ctx, hipStreamSynchronize(s));
+    while (!ended && !timed_out) wait_for(launched + 1);    // (the last pass launched ends the registration: it only evaluates)
+    double st[64] = {0};
+    if (timed_out || (a.dbg & 1)) {
+        // nothing heard for seconds (a launch that failed, a device in trouble), or the diagnostics' counters are wanted: the
+        // plain way -- copy the state back behind everything on the stream and wait
+        PCA_CHECK(ctx, hipMemcpyAsync(st, a.state, sizeof st, hipMemcpyDeviceToHost, s));
+        PCA_CHECK(ctx, hipStreamSynchronize(s));
+    } else {
+        for (int i = 0; i < 22; ++i) st[i] = ctx->icp_host[i];           // (behind the acquire of the word that said "ended")
+    }
     for (int i = 0; i < 12; ++i) T_out[i] = st[i];
-    if (a.dbg) { fprintf(stderr, "icp: searched queries per pass:"); for (int i = 0; i < 16; ++i) fprintf(stderr, " %.0f", st[48 + i]); fprintf(stderr, "\n"); }
+    if (a.dbg & 1) { fprintf(stderr, "icp: searched queries per pass:"); for (int i = 0; i < 16; ++i) fprintf(stderr, " %.0f", st[48 + i]); fprintf(stderr, "\n"); }
     T_out[12] = T_out[13] = T_out[14] = 0.0; T_out[15] = 1.0;
     if (fitness) *fitness = st[16];
     if (rmse) *rmse = st[17];
     if (iterations) *iterations = (int)st[21];
+    ctx->icp_cnt_dirty = timed_out;                         // the fill pass has run: every count is zero again
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }

@@ -94,6 +94,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; '
                            f'g.build()"` or `make -C pc-accumulation-lib_amd/csrc` (no CPU fallback exists)')
+    # torch FIRST: it brings its own bundled HIP runtime (SONAME libamdhip64.so.7, the one this library needs too).  Loaded
+    # before this library, the library binds to it and the process has ONE runtime; loaded after (a module that binds the host
+    # helpers at import time, before anything imported torch), the process would hold the system's runtime AND torch's, and
+    # the second of them to open the device finds "no ROCm-capable device" on the GPU boxes.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     lib.pca_version.restype = C.c_int
