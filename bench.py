@@ -1134,9 +1134,14 @@ def main():
                     help='uniform = SURVEY 8d K-shape frame (headline); ring = 64-beam ring model')
     ap.add_argument('--no-ring', action='store_true', help='skip the additional ring-model pass')
     ap.add_argument('--no-extras', action='store_true', help='skip the side measurements (K1 batches, NuScenes, config 4/5, ...)')
+    ap.add_argument('--extras', choices=['all', 'config5', 'none'], default='all',
+                    help='config5 = of the side measurements only the sharded nine-sequence job (same process group as the headline)')
     ap.add_argument('--gather', action='store_true',
                     help='multi-GPU: also stream every finished BEV tensor to rank 0 inside the timed region')
     args = ap.parse_args()
+    if args.extras == 'none':
+        args.no_extras = True
+    only_c5 = args.extras == 'config5' and not args.no_extras
     if args.gpus > 1 and 'RANK' not in os.environ:
         self_launch(args)
 
@@ -1148,7 +1153,14 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (no CPU fallback)'
     # PCA_BENCH_BACKEND=gloo + fewer GPUs than ranks: rehearsal of the multi-rank control flow on a one-GPU box
     backend = os.environ.get('PCA_BENCH_BACKEND', 'nccl')
-    dev_index = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if backend == 'nccl' and world > 1 and int(os.environ.get('LOCAL_WORLD_SIZE', world)) > n_dev:
+        # RCCL wants one device per rank; two ranks on one card die inside the first collective with a duplicate-device error.
+        # Said here, in one line, before anything is initialised (the gloo rehearsal shares cards on purpose: modulo below)
+        sys.stderr.write(f'bench.py: {os.environ.get("LOCAL_WORLD_SIZE", world)} local ranks but {n_dev} visible GPU(s): the nccl (RCCL) '
+                         f'backend needs one GPU per rank (rehearse the control flow on fewer cards with PCA_BENCH_BACKEND=gloo)\n')
+        sys.exit(2)
+    dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     # under a launcher (RANK set) the process group is initialised even for ONE rank: `torchrun --nproc-per-node 1 bench.py`
     # takes RCCL, the gathers of device tensors and the checksum check through the real transport on a one-GPU box (the
@@ -1302,7 +1314,7 @@ def main():
     # ---- the step as an unchanged driver runs it (host arrays in, host dict out): right after the headline, on its
     #      accumulator, before the passes that churn through tens of GB ----
     pcie = two_seq = None
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not only_c5:
         builtins.print = quiet
         pcie = pcie_inclusive_pass(acc, pool, min(args.steps, 30))
         # two independent sequences on this GPU (threads with a lane each; then two processes): right after the headline,
@@ -1319,7 +1331,7 @@ def main():
     c5 = None
     if not args.no_extras:
         c5 = config5_pass(rank, world, args.config5_scale, barrier, allmax, coll_dev, dist, args.lanes)
-        if args.lanes == 1 and world == 1 and rank == 0:
+        if args.lanes == 1 and world == 1 and rank == 0 and not only_c5:
             # the same job with two chunks at a time on the one GPU (two lanes): reported beside, adopted as the default if it pays
             c5b = config5_pass(rank, world, args.config5_scale, barrier, allmax, coll_dev, dist, 2)
             c5['two_lanes'] = {k: c5b[k] for k in ('seconds', 'Mpoints_per_s', 'bev_frames_per_s', 'lanes_per_gpu')}
@@ -1331,7 +1343,7 @@ def main():
         return
 
     side = {}
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and not only_c5:
         builtins.print = quiet
         side['pcie_inclusive'] = pcie
         side['two_sequences'] = two_seq

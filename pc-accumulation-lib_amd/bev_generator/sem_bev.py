@@ -50,6 +50,7 @@ class LazyBev(dict):
     def __init__(self, host, index, event, trajs, gt_lanes=None):
         super().__init__()
         self._pending = (host, index, event, trajs, gt_lanes)
+        self._error = None
         self._zero_copy = LazyBev._live[0] < LazyBev.MAX_PINNED_LIVE
         if self._zero_copy:
             import weakref
@@ -62,13 +63,19 @@ class LazyBev(dict):
 
     def _fill(self):
         if self._pending is not None:
+            if self._error is not None:          # the copy's wait raised (a device error): every later access says so again,
+                raise self._error                # instead of handing out an empty dict or a bare KeyError
             host, index, event, trajs, gt_lanes = self._pending
-            self._pending = None
-            event.synchronize()
+            try:
+                event.synchronize()
+            except Exception as e:               # noqa: BLE001
+                self._error = e
+                raise
             planes = host[index].numpy()
             if not self._zero_copy:
                 planes = np.array(planes)
             dict.update(self, SemBEVGenerator.pack_bev(planes, trajs[0], trajs[1], trajs[2], gt_lanes))
+            self._pending = None                 # only now: the sample is complete
         return self
 
     def __getitem__(self, k):

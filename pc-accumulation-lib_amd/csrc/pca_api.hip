@@ -159,8 +159,8 @@ int pca_ctx_create(int device, pca_ctx **out)
         }                                                                                                              \
     } while (0)
     PCA_CREATE_STEP(hipSetDevice(device));
-    PCA_CREATE_STEP(hipMalloc(&ctx->ticket, 4 * sizeof(uint32_t)));
-    PCA_CREATE_STEP(hipMemset(ctx->ticket, 0, 4 * sizeof(uint32_t)));
+    PCA_CREATE_STEP(hipMalloc(&ctx->ticket, sizeof(PcaStatusBlock)));
+    PCA_CREATE_STEP(hipMemset(ctx->ticket, 0, sizeof(PcaStatusBlock)));
     PCA_CREATE_STEP(hipHostMalloc(&ctx->status_host, sizeof(uint32_t)));
     PCA_CREATE_STEP(hipHostMalloc(&ctx->status_mirror, PCA_STATUS_BITS * sizeof(uint32_t), hipHostMallocMapped));
     PCA_CREATE_STEP(hipHostMalloc(&ctx->heavy_hint, sizeof(uint32_t), hipHostMallocMapped));
@@ -170,7 +170,7 @@ int pca_ctx_create(int device, pca_ctx **out)
     for (int b = 0; b < PCA_STATUS_BITS; ++b) ctx->status_mirror[b] = 0;
     PCA_CREATE_STEP(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->heavy_hint_dev), ctx->heavy_hint, 0));
     PCA_CREATE_STEP(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->status_mirror_dev), ctx->status_mirror, 0));
-    PCA_CREATE_STEP(hipMemcpy(ctx->ticket + 2, &ctx->status_mirror_dev, sizeof(void *), hipMemcpyHostToDevice));
+    PCA_CREATE_STEP(hipMemcpy(reinterpret_cast<char *>(ctx->ticket) + offsetof(PcaStatusBlock, mirror), &ctx->status_mirror_dev, sizeof(void *), hipMemcpyHostToDevice));
 #undef PCA_CREATE_STEP
     *out = ctx;
     return 0;

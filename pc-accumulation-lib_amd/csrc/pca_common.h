@@ -4,6 +4,7 @@
 // fma(); everything else is un-fused -> this library is compiled with -ffp-contract=off.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -30,7 +31,7 @@ struct pca_ctx {
     // decoupled look-back workspace (stable compaction / scans)
     uint64_t *tile_state = nullptr;   // dev [tile_cap]
     int64_t tile_cap = 0;
-    uint32_t *ticket = nullptr;       // dev [4]: [0] ticket counter, [1] status bits, [2..3] device address of the mirror
+    uint32_t *ticket = nullptr;       // dev: one PcaStatusBlock (below) -- [0] ticket counter, [1] status bits, [2..3] device address of the mirror
     uint32_t *status_mirror = nullptr;     // pinned, device-visible [PCA_STATUS_BITS]: word b != 0 <=> bit b was raised
     uint32_t *status_mirror_dev = nullptr;
     uint32_t epoch = 0;               // 22-bit launch tag of tile_state entries
@@ -232,10 +233,20 @@ __device__ __forceinline__ uint16_t f64_to_f16_bits_reference(double d)
 // mirror -- a plain store into mapped host memory, whose address sits next to the status word -- that pca_status_peek
 // reads without touching the stream.  Only ever executed on the error paths.
 #define PCA_STATUS_BITS 8
+// The 16-byte device block behind pca_ctx::ticket.  Kernels are handed `&block->status` (ctx->ticket + 1) as their status
+// word; pca_raise finds the mirror's device address in the SAME block.  Whoever hands a kernel a status word must hand it this
+// one; pca_status clears `status` alone (4 bytes) and nothing may write `mirror` after pca_ctx_create.
+struct PcaStatusBlock {
+    uint32_t ticket;       // ticket counter of the look-back users
+    uint32_t status;       // PCA_STATUS_* bits (read and cleared by pca_status)
+    uint32_t *mirror;      // device address of the host-visible mirror words [PCA_STATUS_BITS] (mapped host memory), or null
+};
+static_assert(sizeof(PcaStatusBlock) == 16 && offsetof(PcaStatusBlock, status) == 4 && offsetof(PcaStatusBlock, mirror) == 8,
+              "pca_ctx::ticket is four u32: [0] ticket, [1] status, [2..3] the mirror's address");
 __device__ __forceinline__ void pca_raise(uint32_t *status, uint32_t bit)
 {
     atomicOr(status, bit);
-    uint32_t *mirror = *reinterpret_cast<uint32_t *const *>(status + 1);
+    uint32_t *mirror = reinterpret_cast<const PcaStatusBlock *>(status - 1)->mirror;
     if (mirror) __hip_atomic_store(mirror + (__ffs((int)bit) - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

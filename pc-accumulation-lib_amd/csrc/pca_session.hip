@@ -85,7 +85,14 @@ int pca_kitti_integrate(pca_ctx *ctx, const pca_kitti_obs *obs, const double P[1
     fr.sem_gt = (const uint8_t *)dev[3]; fr.n = obs->n; fr.reserved = 0;
     const int rc = pca_kitti_project_sample_filter_ex(ctx, &fr, 1, P, H, W, filter_mask, store, frame_off, slot, sample_mode, stream);
     if (slot_st) {                                         // the blocks are free again once K1 has read them
-        if (hipEventRecord(slot_st->done, s) == hipSuccess) slot_st->busy = true;
+        const hipError_t e = hipEventRecord(slot_st->done, s);
+        if (e == hipSuccess) slot_st->busy = true;
+        else {
+            // no event to wait for: the block must not be staged into again while K1 may still read it -- wait here, once,
+            // and say what happened
+            (void)hipStreamSynchronize(s);
+            if (rc == 0) { ctx->err = std::string("kitti_integrate: hipEventRecord(stage done): ") + hipGetErrorString(e); return -1; }
+        }
     }
     if (rc != 0) return rc;
     if (track) *evicted = pca_host_track_step(track, T_new_prev, horizon, path_length);

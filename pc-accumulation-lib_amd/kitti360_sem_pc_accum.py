@@ -31,6 +31,7 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         import os
         self._fast = os.environ.get('PCA_FAST_CALLS', '1') != '0'      # one library call per driver call (0: the general path)
         self._prev_sweep = None
+        self._sweep_dev = None           # (host sweep, its device copy) of the frame the device ICP has just registered
         self.pose_provider = self._default_pose_provider()
 
     # ---- pose input ----------------------------------------------------------------------------
@@ -56,10 +57,17 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
 
     def _gpu_icp_pose(self, pc):
         """kitti360_sem_pc_accum.py:115-127 on the device: previous sweep -> new sweep, point-to-plane."""
+        import torch
         from pca_amd.icp import GpuIcp
         if self._gpu_icp is None:
             self._gpu_icp = GpuIcp()
-        new = GpuIcp.to_device(pc)
+        # ONE upload serves the registration and K1: an (N,4) f32 host sweep goes through the pinned staging (asynchronous copy,
+        # no pageable .to(device) the host would sit in) and integrate() hands the device tensor on to K1
+        if not isinstance(pc, torch.Tensor) and getattr(pc, 'dtype', None) == np.float32 and pc.ndim == 2 and pc.shape[1] == 4:
+            new = self._upload([('icp_pts', pc)])[0]
+            self._sweep_dev = (pc, new)
+        else:
+            new = GpuIcp.to_device(pc)
         if self._prev_sweep is None:
             self._prev_sweep = new
         reg = self._gpu_icp.register(self._prev_sweep, new, self.icp_threshold, self.icp_trans_init)
@@ -151,10 +159,16 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         def put(a, np_dtype, t_dtype, bit):
             nonlocal mask
             if not isinstance(a, torch.Tensor):
-                d = getattr(a, '__dict__', {}).get('_dev')      # pca_amd.ingest.DeviceImage with its copy already there
-                if d is not None:
+                # device wrappers, WITHOUT running their lazy properties: a device tensor found in the object's own
+                # attributes is used as it is -- utils.onnx_utils.DeviceMap keeps its class map under 'dev' (going through
+                # np.asarray would copy it to the host and stage it back up, frame after frame), pca_amd.ingest.DeviceImage
+                # its upload under '_dev'; a DeviceImage whose copy is not there yet ('_dev' is None: asking for `.dev` would
+                # start a synchronous pageable upload only to be thrown away) hands over its host array with the others
+                own = getattr(a, '__dict__', {})
+                d = own.get('dev') if isinstance(own.get('dev'), torch.Tensor) else own.get('_dev')
+                if isinstance(d, torch.Tensor):
                     a = d
-                elif hasattr(a, 'host') and hasattr(a, 'dev'):  # ... or not yet: its host array goes with the others
+                elif '_host' in own and '_dev' in own:
                     a = a.host
             if isinstance(a, torch.Tensor):
                 if a.device != dev or a.dtype != t_dtype or not a.is_contiguous():
@@ -200,6 +214,11 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
             sem_gt = None
         T_new_prev = np.asarray(self.pose_provider(pc), dtype=np.float64)
         self.T_prev_origin = np.matmul(self.T_prev_origin, T_new_prev)
+        if self._sweep_dev is not None:    # the device ICP uploaded this very sweep: K1 reads that copy
+            host, dev = self._sweep_dev
+            self._sweep_dev = None
+            if host is pc:
+                pc = dev
         fast = self._obs_pointers(rgb, pc, sem_gt) if self._fast else None
         general = self._frame_tensors(rgb, pc, sem_gt) if fast is None else None
         if len(self._track) > 0:           # move everything stored so far into the new ego frame (K2, owed to the next reader)
@@ -254,6 +273,11 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
                 sem_gt = None
             T_new_prev = np.asarray(self.pose_provider(pc), dtype=np.float64)
             self.T_prev_origin = np.matmul(self.T_prev_origin, T_new_prev)
+            if self._sweep_dev is not None:
+                host, dev = self._sweep_dev
+                self._sweep_dev = None
+                if host is pc:
+                    pc = dev
             frame, semseg, H, W = self._frame_tensors(rgb, pc, sem_gt)
             if shape not in (None, (H, W)):
                 raise ValueError('integrate_many: all images of a batch must have one size')

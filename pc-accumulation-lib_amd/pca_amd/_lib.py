@@ -280,14 +280,20 @@ class Context:
         """Synchronises, reads and clears the device status word and raises what the reference would have raised on the
         spot (AssertionError of datasets/nuscenes_utils.py:191-195) or a RuntimeError naming what went wrong."""
         st = self.status()
-        if st & STATUS_UV_OUT_OF_IMAGE:
-            raise AssertionError('pts_uv must be all inside image')
-        if st & STATUS_STORE_OVERFLOW:
-            raise RuntimeError('pca: device point store overflow (points were dropped)')
-        if st & STATUS_LOOKBACK_TIMEOUT:
-            raise RuntimeError('pca: a compaction workgroup timed out waiting for its predecessor (output invalid)')
-        if st & STATUS_NEGATIVE_INTENSITY:
-            raise ValueError('pca: negative lidar intensity on the f32 path (pass intensity64 to bev())')
+        if not st:
+            return
+        # every raised bit goes into ONE message (the word has been cleared: what is not said now is lost); the exception's
+        # type is that of the first bit in the reference's own order of failure
+        said = [(STATUS_UV_OUT_OF_IMAGE, AssertionError, 'pts_uv must be all inside image'),
+                (STATUS_STORE_OVERFLOW, RuntimeError, 'pca: device point store overflow (points were dropped)'),
+                (STATUS_LOOKBACK_TIMEOUT, RuntimeError,
+                 'pca: a compaction workgroup timed out waiting for its predecessor (output invalid)'),
+                (STATUS_NEGATIVE_INTENSITY, ValueError, 'pca: negative lidar intensity on the f32 path (pass intensity64 to bev())')]
+        hit = [(exc, msg) for bit, exc, msg in said if st & bit]
+        rest = st & ~(STATUS_UV_OUT_OF_IMAGE | STATUS_STORE_OVERFLOW | STATUS_LOOKBACK_TIMEOUT | STATUS_NEGATIVE_INTENSITY)
+        if rest:
+            hit.append((RuntimeError, 'pca: unknown device status bits 0x%x' % rest))
+        raise hit[0][0]('; '.join(msg for _, msg in hit))
 
     def poll_status(self):
         """check_status() without the wait: only when the host-visible mirror shows a raised bit (a kernel that has

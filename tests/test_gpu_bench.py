@@ -125,3 +125,33 @@ def test_bench_one_rank_over_rccl():
     d = last_json(r.stdout)
     gc = d['gather_check']
     assert d['n_gpus'] == 1 and gc['backend'] == 'nccl' and gc['in_timed_region'] is True and gc['checksums_match'] is True
+
+
+def test_bench_gather_in_the_timed_region_and_config5_in_one_rccl_process_group():
+    """ONE process group over RCCL (world 1 on the one-GPU box) carries both: the headline with every finished BEV chunk
+    streamed to rank 0 INSIDE the timed region (async gathers overlapping the next chunk's compute) and, afterwards, the
+    sharded nine-sequence job with its own gather check -- the two runs of test_bench_one_rank_over_rccl as one."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('PCA_BENCH_BACKEND', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29549', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '1', '--gather',
+           '--extras', 'config5', '--config5-scale', '0.01', '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = last_json(r.stdout)
+    assert d['n_gpus'] == 1 and d['gather_check']['backend'] == 'nccl' and d['gather_check']['in_timed_region'] is True
+    assert d['gather_check']['checksums_match'] is True
+    c5 = d['config5']
+    assert c5['gather_check']['backend'] == 'nccl' and c5['gather_check']['on_device_tensors'] is True
+    assert c5['gather_check']['checksums_match'] is True and c5['bev_samples'] > 0
+    assert 'two_sequences' not in d and 'nuscenes' not in d                 # only the sharded job rode along
+
+
+def test_bench_refuses_more_nccl_ranks_than_gpus_in_one_line():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('PCA_BENCH_BACKEND', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29551', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-extras']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert 'needs one GPU per rank' in r.stderr and 'Traceback' not in r.stderr.split('needs one GPU per rank')[0][-400:]

@@ -807,6 +807,26 @@ def test_semseg_wrapper_keeps_the_class_map_on_the_device(monkeypatch):
     orc.kitti_project_sample_filter(ost, pc, P, img, want[0, 0].astype(np.uint8), None, 64, 96, KITTI_FILTERS)
     assert np.array_equal(rows, ost.rows()) and rows.shape[0] > 100
     assert isinstance(acc.get_semseg(0)[0], onnx_utils.DeviceMap)
+    # the ONE-CALL path (a device image in: pca_kitti_integrate) takes the DeviceMap's cuda tensor as it is -- no copy of the
+    # class map to the host and back up (counted: DeviceMap.__array__ is the only way down) -- and a DeviceImage whose upload
+    # has not happened hands over its host array without its lazy `dev` property starting a pageable upload
+    from pca_amd.ingest import DeviceImage
+    downs, lazy_ups = [], []
+    real_array = onnx_utils.DeviceMap.__array__
+    monkeypatch.setattr(onnx_utils.DeviceMap, '__array__', lambda self, *a, **k: (downs.append(1), real_array(self, *a, **k))[1])
+    real_dev = DeviceImage.dev.fget
+    monkeypatch.setattr(DeviceImage, 'dev', property(lambda self: (lazy_ups.append(self._dev is None), real_dev(self))[1]))
+    assert acc._fast
+    acc.integrate([(torch.from_numpy(img).cuda(), pc, None)])                       # cuda tensor in
+    acc.integrate([(DeviceImage(img, torch.from_numpy(img).cuda()), pc, None)])     # DeviceImage, copy already there
+    assert downs == [] and lazy_ups == []
+    rows2 = acc.sem_pcs
+    assert np.array_equal(rows2[1], ost.rows()) and np.array_equal(rows2[2], ost.rows())
+    host_only = DeviceImage(img, None)                                              # DeviceImage without a device copy
+    acc.semseg_model = type('HostModel', (), {'pred': lambda self, rgb: want})()    # (a host model: the image stays a host array)
+    acc.integrate([(host_only, pc, None)])
+    assert lazy_ups == [] and host_only._dev is None
+    assert np.array_equal(acc.sem_pcs[3], ost.rows())
 
 
 def test_bev_num_batch_equals_single_calls_and_lazy_dicts(golden, monkeypatch, tmp_path):

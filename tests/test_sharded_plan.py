@@ -65,6 +65,19 @@ def test_plan_of_the_nine_kitti360_sequences_on_eight_ranks():
         assert edges[0][0] == 0 and edges[-1][1] == n and all(a[1] == b[0] for a, b in zip(edges[:-1], edges[1:]))
 
 
+def test_full_length_plan_of_the_nine_sequences_on_eight_ranks():
+    """The same at FULL length (74 367 frames, the job BASELINE configs[4] names): one warm-up horizon (~200 frames) per cut
+    against ~9 300 frames per rank -- the plan's ideal speed-up is 7.8; at least 6.5 is asserted (the target is 6 x measured)."""
+    lengths = [11270, 14384, 730, 11440, 6610, 9578, 2960, 13855, 3540]
+    c, s = np.cos(-0.002), np.sin(-0.002)
+    T = np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.]]) @ np.array(
+        [[1, 0, 0, -1.0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.]])
+    jobs, loads, samples = sr.plan([np.tile(T, (n, 1, 1)) for n in lengths], 8, 200., 80., 1.0)
+    assert sum(lengths) / max(loads) >= 6.5, loads
+    assert sum(len(x) for x in samples) == sum(len(j.samples) for r in jobs for j in r) > 70_000
+    assert max(loads) / min(loads) < 1.02                                   # the lanes are cut to equal cost
+
+
 def test_frame_exactly_at_the_horizon_is_held_by_the_chunk_too():
     """A frame whose path distance from the newest is EXACTLY one horizon (unit steps, horizon 50.0: the eviction test is a
     strict '> 0' on sums that are exact here) is kept by the sequential run; a chunk's warm-up starts one frame before the
