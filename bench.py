@@ -262,28 +262,42 @@ def ring_model_pass(steps):
 def k1_batched_pass(pool_frames, n_distinct, batch=64, reps=20):
     """K1 alone on `batch` frames per call (7.68 M points): the shape in which the fused project+sample+filter kernel is
     throughput- rather than launch-latency-bound.  Wall clock over `reps` back-to-back C calls on prebuilt descriptors
-    (the GPU stays busy: launch gaps of the unit are included, host preparation is not), HIP events beside it."""
+    (the GPU stays busy: launch gaps of the unit are included, host preparation is not), HIP events beside it.
+    n_distinct > batch: the calls ALTERNATE between n_distinct / batch different batches, so that no call finds its inputs where
+    the call before left them (two batches of 64 frames = 514 MB of inputs: more than the 256 MB Infinity Cache holds)."""
     import torch
     from pca_amd import _lib
     from pca_amd.device_store import DeviceStore
     ctx = _lib.Context.get()
     tmp = DeviceStore(capacity=batch * N_PTS, max_frames=batch + 1)
-    frames = [dict(pts=pool_frames[k % n_distinct][1], rgb=pool_frames[k % n_distinct][0], sem=pool_frames[k % n_distinct][2])
-              for k in range(batch)]
-    descs = DeviceStore.kitti_descs(frames)
+    n_sets = max(n_distinct // batch, 1)
+    sets = []
+    for i in range(n_sets):
+        fr = [dict(pts=pool_frames[(i * batch + k) % n_distinct][1], rgb=pool_frames[(i * batch + k) % n_distinct][0],
+                   sem=pool_frames[(i * batch + k) % n_distinct][2]) for k in range(batch)]
+        sets.append((fr, DeviceStore.kitti_descs(fr)))
+    frames, descs = sets[0]
+    calls = [0]
 
     def call():
+        fr, ds = sets[calls[0] % n_sets]
+        calls[0] += 1
         tmp.clear()
-        tmp.append_kitti(frames, P_VELO_FRAME, IMG_H, IMG_W, FILTERS, descs=descs)
-    tmp.clear()
-    tmp.append_kitti(frames, P_VELO_FRAME, IMG_H, IMG_W, [], descs=descs)      # no class filter: the in-frustum count M_proj
-    m_proj = int(tmp.offsets()[-1])
-    for _ in range(3):
+        tmp.append_kitti(fr, P_VELO_FRAME, IMG_H, IMG_W, FILTERS, descs=ds)
+    m_proj = kept = 0
+    for fr, ds in sets:
+        tmp.clear()
+        tmp.append_kitti(fr, P_VELO_FRAME, IMG_H, IMG_W, [], descs=ds)      # no class filter: the in-frustum count M_proj
+        m_proj += int(tmp.offsets()[-1])
+        tmp.clear()
+        tmp.append_kitti(fr, P_VELO_FRAME, IMG_H, IMG_W, FILTERS, descs=ds)
+        kept += int(tmp.offsets()[-1])
+    m_proj, kept = m_proj / n_sets, kept / n_sets              # per call (mean over the alternating batches)
+    for _ in range(3 * n_sets):
         call()
-    kept = int(tmp.offsets()[-1])
     torch.cuda.synchronize()
     ctx.profile(True)
-    for _ in range(5):
+    for _ in range(5 * n_sets):
         call()
     ev = ctx.profile_read()['kitti_project_sample_filter']
     ctx.profile(False)
@@ -294,24 +308,29 @@ def k1_batched_pass(pool_frames, n_distinct, batch=64, reps=20):
     Pc, fm = _lib.f64_array(P_VELO_FRAME, 12), _lib.class_mask(FILTERS)
     tmp.clear()
     torch.cuda.synchronize()
+    reps = reps * n_sets
     t0 = time.perf_counter()
-    for _ in range(reps):
-        ctx.check(lib.pca_kitti_project_sample_filter(ctx.h, descs, batch, Pc, IMG_H, IMG_W, fm, C.byref(st),
+    for r in range(reps):
+        ctx.check(lib.pca_kitti_project_sample_filter(ctx.h, sets[r % n_sets][1], batch, Pc, IMG_H, IMG_W, fm, C.byref(st),
                                                       tmp.frame_off.data_ptr(), 0, ctx.stream()))
     torch.cuda.synchronize()
     us = 1e6 * (time.perf_counter() - t0) / reps
     tmp.check_status()
     alg = 16.0 * N_PTS * batch + 4.0 * m_proj + 40.0 * kept
-    return {'frames_per_call': batch, 'distinct_frames': n_distinct, 'points_per_call': N_PTS * batch, 'kept': kept,
-            'in_frustum': m_proj,
+    in_mb = n_distinct * (N_PTS * 16 + IMG_H * IMG_W * 4) / 1e6
+    return {'frames_per_call': batch, 'distinct_frames': n_distinct, 'alternating_batches': n_sets, 'points_per_call': N_PTS * batch,
+            'kept': kept, 'in_frustum': m_proj,
             'us_per_call_wall_back_to_back': us, 'us_per_call_hip_events': 1e3 * ev[0] / ev[1],
             'alg_bytes': alg, 'GBps': alg / us / 1e3, 'frac': alg / us / 1e3 / HBM_PEAK_GBS,
             'frac_on_hip_event_time': alg / (1e3 * ev[0] / ev[1]) / 1e3 / HBM_PEAK_GBS,
             'frac_note': '`frac` is on the back-to-back wall time (launch gaps in, per-kernel events out); the HIP-event pair '
                          'around the two kernels of one call gives frac_on_hip_event_time',
             'Mpoints_per_s': N_PTS * batch / us,
-            'input_MB': n_distinct * (N_PTS * 16 + IMG_H * IMG_W * 4) / 1e6,
-            'inputs_cache_resident': bool(n_distinct * (N_PTS * 16 + IMG_H * IMG_W * 4) < 64e6)}
+            'input_MB': in_mb,
+            'inputs_cache_resident': bool(in_mb < 64e6 / 1e6),
+            'inputs_fit_infinity_cache': bool(in_mb + 100.0 < 256 * 1.048576),
+            'cache_note': 'the calls cycle through %.0f MB of inputs and write ~95 MB (staging + store) per call; the Infinity Cache '
+                          'holds 256 MiB: below ~170 MB of inputs a call finds part of them on-die' % in_mb}
 
 
 def nuscenes_pass(frames=40, reps=10):
@@ -1350,8 +1369,10 @@ def main():
         side['k1_batched'] = k1_batched_pass(pool, POOL)
         side['k1_batched']['note'] = ('%d distinct frames repeated: the 32 MB of inputs stay in L2 / Infinity Cache between calls -- '
                                       'NOT an HBM figure; k1_batched_distinct is the one to compare with the 0.5 target' % POOL)
-        big = device_pool(synth_frame, 7, 64)
-        side['k1_batched_distinct'] = k1_batched_pass(big, 64)
+        big = device_pool(synth_frame, 7, 128)
+        side['k1_batched_distinct'] = k1_batched_pass(big[:64], 64)
+        # two alternating batches of 64 different frames: no call finds its inputs where the call before left them
+        side['k1_batched_distinct128'] = k1_batched_pass(big, 128)
         del big
         ringpool = device_pool(ring_frame, 7, 64)          # 64 distinct ring-model frames: a real sweep's point ORDER
         side['k1_batched_ring'] = k1_batched_pass(ringpool, 64)
@@ -1408,7 +1429,8 @@ def main():
         roofline['frac_physical'] = traffic / (units[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS
     k1_pmc_path = os.path.join(ROOT, 'profiles', PROFILE_TAG + '_k1_batched_summary.json')
     k1_pmc = json.load(open(k1_pmc_path)) if os.path.exists(k1_pmc_path) else {}
-    for k, pool in (('k1_batched', 'pool8'), ('k1_batched_distinct', 'pool64'), ('k1_batched_ring', None)):
+    for k, pool in (('k1_batched', 'pool8'), ('k1_batched_distinct', 'pool64'), ('k1_batched_distinct128', None),
+                    ('k1_batched_ring', None)):
         if k in side:
             roofline[k] = side.pop(k)
             phys = k1_pmc.get(pool, {}).get('physical_MB') if pool else None

@@ -67,6 +67,53 @@ __device__ __forceinline__ uint32_t k1_mbcnt(uint64_t m)      // set bits of m b
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// ---- cache-policy knobs of the batched front kernel (compile time; tools/experiments/k1_variants.sh builds and times them) ----
+// K1_STREAM_NT: bit 0 = the point stream is loaded non-temporally, bit 1 = the staging records are stored non-temporally
+//               (both are touched once by this kernel: they should not push the frame's image lines out of its L2)
+// K1_GATHER_MODE: how the class byte and the colour dword are gathered: 0 plain, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1
+#ifndef K1_STREAM_NT
+#define K1_STREAM_NT 0
+#endif
+#ifndef K1_GATHER_MODE
+#define K1_GATHER_MODE 0
+#endif
+template <typename T>
+__device__ __forceinline__ T k1_gather(const T *p)
+{
+    typedef const __attribute__((address_space(1))) T *G;           // (global_load_*, not flat_load_*)
+    G g = reinterpret_cast<G>(reinterpret_cast<uintptr_t>(p));
+#if K1_GATHER_MODE == 1
+    return __builtin_nontemporal_load(g);
+#elif K1_GATHER_MODE == 2
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#elif K1_GATHER_MODE == 3
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif K1_GATHER_MODE == 4
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    return *g;
+#endif
+}
+__device__ __forceinline__ uint32_t k1_gather_u32_unaligned(const uint8_t *p)
+{
+#if K1_GATHER_MODE == 0
+    return k1_ldg_u32_unaligned(p);
+#else
+    return k1_gather(reinterpret_cast<const uint32_t *>(p));      // (experiment builds only: the hardware takes the unaligned address)
+#endif
+}
+__device__ __forceinline__ float4 k1_load_point(const float *p, bool split)
+{
+#if K1_STREAM_NT & 1
+    if (split) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) f4 *>(reinterpret_cast<uintptr_t>(p)));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+#endif
+    return k1_ldg4(p);
+}
+
 #define K1_MAXQ 8
 #define K1_APPEND_BLK 256
 #define K1_SCAN_BLK 1024
@@ -265,7 +312,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a)
 #pragma unroll                                             // a lane past the end re-reads the tile's last point
         for (int k = 0; k < PPT; ++k) {
             const int idx = k * BLK + (int)threadIdx.x;
-            v[k] = k1_ldg4(pts + 4 * (idx < n_here ? idx : n_here - 1));   // 16 B / lane, fully coalesced
+            v[k] = k1_load_point(pts + 4 * (idx < n_here ? idx : n_here - 1), SPLIT);   // 16 B / lane, fully coalesced
         }
     } else {
 #pragma unroll
@@ -358,7 +405,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a)
         auto rgb_raw = [&](int pix, unsigned &sh) -> uint32_t {
             const int off = pix * 3;
             sh = off > last ? (unsigned)(off - last) * 8u : 0u;
-            return k1_ldg_u32_unaligned(fr.rgb + (off > last ? last : off));
+            return SPLIT ? k1_gather_u32_unaligned(fr.rgb + (off > last ? last : off)) : k1_ldg_u32_unaligned(fr.rgb + (off > last ? last : off));
         };
         auto rgb_at = [&](int pix) -> uint32_t { unsigned sh; const uint32_t w = rgb_raw(pix, sh); return (w >> sh) & 0xffffffu; };
 #pragma unroll
@@ -372,7 +419,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a)
                 ok[r] = j < ncand && px >= 0;
                 const int pix = ok[r] ? px : 0;                           // pixel 0 is always a valid address
                 // two gathers per point: the class byte and ONE unaligned dword holding r,g,b
-                cls[r] = k1_ldg(fr.sem + pix);
+                cls[r] = SPLIT ? k1_gather(fr.sem + pix) : k1_ldg(fr.sem + pix);
                 pixr[r] = pix;
                 if (!BILIN) {
                     if (!dep) rgb[r] = rgb_raw(pix, rsh[r]);
@@ -428,8 +475,15 @@ __device__ __forceinline__ void k1_body(const K1Args &a)
         for (int r = 0; r < PPT; ++r)
             if ((km[r] >> lane) & 1ull) {
                 const uint32_t o = koff[r] + k1_mbcnt(km[r]);
+#if K1_STREAM_NT & 2
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 w; w.x = p[r].x; w.y = p[r].y; w.z = p[r].z; w.w = p[r].w;
+                __builtin_nontemporal_store(w, reinterpret_cast<__attribute__((address_space(1))) f4 *>(reinterpret_cast<uintptr_t>(rp + o)));
+                __builtin_nontemporal_store(packed[r], reinterpret_cast<__attribute__((address_space(1))) uint32_t *>(reinterpret_cast<uintptr_t>(rc + o)));
+#else
                 rp[o] = p[r];
                 rc[o] = packed[r];
+#endif
             }
         if (threadIdx.x == 0) { a.counts[tile] = total; a.lastf[tile] = tin == ftiles - 1 ? fr.f : -1; }
         K1_STAMP(5);
@@ -493,48 +547,80 @@ struct K1AppendArgs {
     const uint32_t *counts;
     const int32_t *lastf;
     int tile_points;
+    int tiles;                 // tiles of the (sub-)batch
+    int group;                 // consecutive tiles per workgroup
     pca_store st;
     int64_t *frame_off;
     int first_slot;
     uint32_t *status;
 };
 
-__global__ __launch_bounds__(K1_APPEND_BLK) void k1_append(const K1AppendArgs a)
+// A workgroup takes `group` consecutive tiles (round 5; one before): the sum over the counts in front of it is taken once per
+// group -- tile 15 000 of a 64-frame batch reads 60 KB of counts before its first store, and 15 000 workgroups did that --
+// and the staging records, written once by the front kernel and read once here, are read with the non-temporal hint, the SoA
+// stores (nobody re-reads them before the raster's next pass over the whole store) likewise when `nt` says so.
+template <bool NT>
+__device__ __forceinline__ void k1_append_body(const K1AppendArgs &a)
 {
     constexpr int BLK = K1_APPEND_BLK;
-    const int tile = blockIdx.x;
+    const int tile0 = (int)blockIdx.x * a.group;
+    const int tile1 = tile0 + a.group < a.tiles ? tile0 + a.group : a.tiles;
     __shared__ uint32_t s_w[BLK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t sum = 0;
-    for (int t = threadIdx.x; t < tile; t += BLK) sum += k1_ldg(a.counts + t);
+    for (int t = threadIdx.x; t < tile0; t += BLK) sum += k1_ldg(a.counts + t);
     sum = wave_reduce_add(sum);
     if (lane == 0) s_w[wave] = sum;
-    const uint32_t c = a.counts[tile];
-    const int32_t lf = a.lastf[tile];
     __syncthreads();
     uint32_t before = 0;
 #pragma unroll
     for (int w = 0; w < BLK / 64; ++w) before += s_w[w];
-    const int64_t base = a.frame_off[a.first_slot] + before;
-    if (threadIdx.x == 0 && lf >= 0) a.frame_off[a.first_slot + lf + 1] = base + c;
-    const float4 *rp = a.rec_p + (size_t)tile * a.tile_points;
-    const uint32_t *rc = a.rec_c + (size_t)tile * a.tile_points;
     bool overflow = false;
-    for (uint32_t j = threadIdx.x; j < c; j += BLK) {
-        const float4 p = k1_ldg4(reinterpret_cast<const float *>(rp + j));
-        const uint32_t col = k1_ldg(rc + j);
-        const int64_t o = base + j;
-        if (o >= a.st.capacity) { overflow = true; continue; }
-        a.st.x[o] = (double)p.x;
-        a.st.y[o] = (double)p.y;
-        a.st.z[o] = (double)p.z;
-        a.st.intensity[o] = p.w;
-        a.st.rgbs[o] = col;
-        a.st.inst[o] = 0;
-        a.st.dyn[o] = 0;
+    for (int tile = tile0; tile < tile1; ++tile) {          // (uniform)
+        const uint32_t c = a.counts[tile];
+        const int32_t lf = a.lastf[tile];
+        const int64_t base = a.frame_off[a.first_slot] + before;
+        if (threadIdx.x == 0 && lf >= 0) a.frame_off[a.first_slot + lf + 1] = base + c;
+        const float4 *rp = a.rec_p + (size_t)tile * a.tile_points;
+        const uint32_t *rc = a.rec_c + (size_t)tile * a.tile_points;
+        for (uint32_t j = threadIdx.x; j < c; j += BLK) {
+            float4 p;
+            uint32_t col;
+            if (NT) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(rp + j));
+                p = make_float4(v.x, v.y, v.z, v.w);
+                col = __builtin_nontemporal_load(rc + j);
+            } else {
+                p = k1_ldg4(reinterpret_cast<const float *>(rp + j));
+                col = k1_ldg(rc + j);
+            }
+            const int64_t o = base + j;
+            if (o >= a.st.capacity) { overflow = true; continue; }
+            if (NT) {
+                __builtin_nontemporal_store((double)p.x, a.st.x + o);
+                __builtin_nontemporal_store((double)p.y, a.st.y + o);
+                __builtin_nontemporal_store((double)p.z, a.st.z + o);
+                __builtin_nontemporal_store(p.w, a.st.intensity + o);
+                __builtin_nontemporal_store(col, a.st.rgbs + o);
+                __builtin_nontemporal_store((int32_t)0, a.st.inst + o);
+                __builtin_nontemporal_store((uint8_t)0, a.st.dyn + o);
+            } else {
+                a.st.x[o] = (double)p.x;
+                a.st.y[o] = (double)p.y;
+                a.st.z[o] = (double)p.z;
+                a.st.intensity[o] = p.w;
+                a.st.rgbs[o] = col;
+                a.st.inst[o] = 0;
+                a.st.dyn[o] = 0;
+            }
+        }
+        before += c;
     }
     if (overflow) pca_raise(a.status, PCA_STATUS_STORE_OVERFLOW);
 }
+__global__ __launch_bounds__(K1_APPEND_BLK) void k1_append(const K1AppendArgs a) { k1_append_body<false>(a); }
+__global__ __launch_bounds__(K1_APPEND_BLK) void k1_append_nt(const K1AppendArgs a) { k1_append_body<true>(a); }
 
 // =============================================================================================
 // C ABI
@@ -589,6 +675,7 @@ struct K1Plan {
     K1AppendArgs pa;
     dim3 grid_front;     // FUSED: (tiles); SPLIT: see k1_kitti
     int tiles;
+    bool append_nt;
     const K1Frame *host_frames;   // the plan's descriptors on the host
     bool inline_frames;           // they fit the kernel arguments: no device copy needed
 };
@@ -695,6 +782,21 @@ static int k1_prepare(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames,
     a.rec_p = reinterpret_cast<float4 *>(ws + o_p);
     K1AppendArgs &pa = plan->pa;
     pa.rec_p = a.rec_p; pa.rec_c = a.rec_c; pa.counts = a.counts; pa.lastf = a.lastf; pa.tile_points = tile_pts;
+    pa.tiles = total;
+    {   // tiles per workgroup of k1_append and the non-temporal hint: PCA_K1_APPEND="<group>[,nt|,plain]" (A/B; results are
+        // identical).  Default: one tile per workgroup (4 and 8 measured the same), non-temporal: the 61 MB the append kernel
+        // stores and the 33 MB it reads are not pushed through the caches in front of HBM, where they evicted the NEXT launch's
+        // inputs -- 64 uniform frames per call 69.9 -> 60.0 us, ring-model frames unchanged (profiles/r05_experiments/k1_round5.txt)
+        static int group = -1, nt = 1;
+        if (group < 0) {
+            group = 1;
+            if (const char *e = getenv("PCA_K1_APPEND")) { group = atoi(e); nt = strstr(e, "plain") == nullptr; }
+            if (group < 1) group = 1;
+            if (group > 64) group = 64;
+        }
+        pa.group = total / group >= 4 * ctx->n_cu ? group : 1;     // (small batches: as many workgroups as there are tiles)
+        plan->append_nt = nt != 0;
+    }
     pa.st = *store; pa.frame_off = frame_off; pa.first_slot = first_slot; pa.status = a.status;
     return 0;
 }
@@ -714,7 +816,9 @@ static int k1_launch_split(pca_ctx *ctx, int blk, int ppt, const K1Plan *plan, h
     K1_CASE(256, 4) K1_CASE(512, 4) K1_CASE(1024, 4)
 #undef K1_CASE
     if (!launched) { ctx->err = "k1: unsupported PCA_K1_CFG"; return -1; }
-    hipLaunchKernelGGL(k1_append, dim3(plan->tiles), dim3(K1_APPEND_BLK), 0, s, plan->pa);
+    const dim3 agrid((plan->tiles + plan->pa.group - 1) / plan->pa.group);
+    if (plan->append_nt) hipLaunchKernelGGL(k1_append_nt, agrid, dim3(K1_APPEND_BLK), 0, s, plan->pa);
+    else hipLaunchKernelGGL(k1_append, agrid, dim3(K1_APPEND_BLK), 0, s, plan->pa);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
 }

@@ -17,7 +17,7 @@ elif what == 'ring':
 elif what == 'k1':
     n = int(sys.argv[2])
     frame_fn = bench.ring_frame if len(sys.argv) > 3 and sys.argv[3] == 'ring' else bench.synth_frame
-    out = bench.k1_batched_pass(bench.device_pool(frame_fn, 7, n), n)
+    out = bench.k1_batched_pass(bench.device_pool(frame_fn, 7, n), n)          # n = 128: two alternating batches of 64
 else:
     raise SystemExit('unknown pass')
 builtins.print = rp
