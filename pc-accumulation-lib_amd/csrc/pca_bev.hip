@@ -81,6 +81,9 @@ struct alignas(16) BevArgs {                             // (16: pca_fetch_block
     uint32_t *key;        // [max_points]
     uint32_t *bh;         // [T][G] kept records per (tile, workgroup)
     uint32_t *boff;       // [T][G] exclusive scan of bh in that order
+    uint32_t *bh0;        // [T][G] with `split`: how many of a (tile, workgroup) piece's records belong to the tile's cells 0..31
+    int split;            // level 1 orders every piece by HALF of the tile (cells 0..31, then 32..63), so that an item (tile, half)
+                          // of bev_tile_cells_heavy walks its own records only -- set when a heavy launch follows
     uint32_t *heavy_hint; // host-visible word: the heavy count of this call, read by the host before the next one
     uint32_t heavy_hint_known;   // its value when this call was made
     int heavy_launched;   // a bev_tile_cells_heavy launch follows (else the light kernel's last workgroup drains the queue)
@@ -304,7 +307,10 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     extern __shared__ uint32_t s_lds[];                     // [T] histogram, [T] cursors
     __shared__ uint32_t s_wsum[AB_THREADS / 64];
     __shared__ uint32_t s_dyn[8];                           // prm.dynobj_mask as dwords (see bin_store)
-    uint32_t *s_h = s_lds, *s_cur = s_lds + a.T;
+    // split: one histogram entry and one cursor per (tile, half of its cells): key >> 6 = tile << 1 | cell >> 5
+    const int hs = a.split ? 6 : 7;
+    const int n_hist = a.split ? 2 * a.T : a.T;
+    uint32_t *s_h = s_lds, *s_cur = s_lds + n_hist;
     if (threadIdx.x < 8) {                                  // (a select chain over scalar registers, no indexed read)
         uint32_t w = (uint32_t)a.prm.dynobj_mask[0];
 #pragma unroll
@@ -319,7 +325,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
         if (threadIdx.x == 0 && a.frame_off[a.slot_end] - w.lo > a.max_points) pca_raise(a.status, PCA_STATUS_STORE_OVERFLOW);
         if (threadIdx.x < HQ_IDS) a.heavy[threadIdx.x] = 0;  // the heavy queue of this call starts empty
     }
-    for (int t = threadIdx.x; t < a.T; t += AB_THREADS) s_h[t] = 0;
+    for (int t = threadIdx.x; t < n_hist; t += AB_THREADS) s_h[t] = 0;
     __syncthreads();
     PendHi pend_hi;
 #pragma unroll
@@ -411,7 +417,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
                 const uint32_t i = (uint32_t)(j0 + u) * AB_THREADS + threadIdx.x;
                 rkey[j0 + u] = view_key_lean(vc, X[u], Y[u], Z[u], i < n_reg && D[u] != 1u, i >= sp_rel ? 1u : 0u);
                 rz[j0 + u] = Z[u];
-                if (rkey[j0 + u] != KEY_INVALID) atomicAdd(&s_h[rkey[j0 + u] >> 7], 1u);
+                if (rkey[j0 + u] != KEY_INVALID) atomicAdd(&s_h[rkey[j0 + u] >> hs], 1u);
             }
         };
 #pragma unroll
@@ -444,7 +450,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
             const int64_t p = base + u * AB_THREADS;
             if (p >= w.c_hi) continue;
             const BinPoint b = bin_point(a, vcm, w, pend_hi, p, X[u], Y[u], Z[u], D[u]);
-            if (b.key != KEY_INVALID) atomicAdd(&s_h[b.key >> 7], 1u);
+            if (b.key != KEY_INVALID) atomicAdd(&s_h[b.key >> hs], 1u);
             a.key[p - w.lo] = b.key;
         }
     }
@@ -456,7 +462,8 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
         const int t0 = threadIdx.x * per;
         const int gp = table_pos(a, g);
         uint32_t sum = 0;
-        for (int k = 0; k < per; ++k) sum += t0 + k < a.T ? s_h[t0 + k] : 0u;
+        if (a.split) { for (int k = 0; k < per; ++k) sum += t0 + k < a.T ? s_h[2 * (t0 + k)] + s_h[2 * (t0 + k) + 1] : 0u; }
+        else { for (int k = 0; k < per; ++k) sum += t0 + k < a.T ? s_h[t0 + k] : 0u; }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const uint32_t inc = wave_incl_scan_add(sum);
         if (lane == 63) s_wsum[wave] = inc;
@@ -467,12 +474,22 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
         for (int k = 0; k < per; ++k) {
             const int t = t0 + k;
             if (t >= a.T) break;
-            const uint32_t c = s_h[t];
-            s_cur[t] = run;
             // tile-major tables [tile][place of the workgroup]: a tile's workgroup of level 2 reads its counters as one range
-            a.bh[(int64_t)t * a.Gr + gp] = c;
-            a.boff[(int64_t)t * a.Gr + gp] = run;
-            run += c;
+            if (a.split) {                                  // the piece = the tile's first half, then its second
+                const uint32_t c0 = s_h[2 * t], c1 = s_h[2 * t + 1];
+                s_cur[2 * t] = run;
+                s_cur[2 * t + 1] = run + c0;
+                a.bh[(int64_t)t * a.Gr + gp] = c0 + c1;
+                a.boff[(int64_t)t * a.Gr + gp] = run;
+                a.bh0[(int64_t)t * a.Gr + gp] = c0;
+                run += c0 + c1;
+            } else {
+                const uint32_t c = s_h[t];
+                s_cur[t] = run;
+                a.bh[(int64_t)t * a.Gr + gp] = c;
+                a.boff[(int64_t)t * a.Gr + gp] = run;
+                run += c;
+            }
         }
     }
     __syncthreads();
@@ -508,7 +525,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
 #pragma unroll
         for (int j = 0; j < REG_P; ++j) {
             if (rkey[j] == KEY_INVALID) continue;
-            const uint32_t pos = seg + atomicAdd(&s_cur[rkey[j] >> 7], 1u);
+            const uint32_t pos = seg + atomicAdd(&s_cur[rkey[j] >> hs], 1u);
             bin_store<I64>(a, s_dyn, pos, rkey[j], rrgb[j], rz[j], 0.0, rinten[j]);
         }
     }
@@ -540,7 +557,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
             const int64_t p = base + u * AB_THREADS;
             const bool ok = key[u] != KEY_INVALID;
             if (ok && stale) apply_owed(a, pend_hi, p, xs[u], ys[u], zz[u]);
-            pos[u] = ok ? seg + atomicAdd(&s_cur[key[u] >> 7], 1u) : 0u;
+            pos[u] = ok ? seg + atomicAdd(&s_cur[key[u] >> hs], 1u) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < MUNR; ++u)
@@ -559,7 +576,9 @@ struct RecMap {
 };
 // builds the map of `tile` (all `nthreads` threads of the workgroup, G <= 1024); returns the tile's record count.
 // Ends with a barrier.
-__device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, int tile, int nthreads, uint16_t *owner = nullptr)
+// half = 0 / 1 (only with a.split): the map of the records of the tile's cells 0..31 / 32..63 alone -- level 1 laid every piece
+// out as [first half][second half] and left the first half's count in bh0.
+__device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, int tile, int nthreads, uint16_t *owner = nullptr, int half = -1)
 {
     // (places of the row, not workgroups: see table_pos; a place beyond the last workgroup counts as an empty piece)
     const int per = (a.Gr + nthreads - 1) / nthreads;
@@ -572,7 +591,13 @@ __device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, in
     for (int k = 0; k < 4; ++k)
         if (k < per && g0 + k < a.Gr) {
             grp[k] = table_group(a, g0 + k);
-            if (grp[k] < a.G) { c[k] = cnt[g0 + k]; o[k] = off[g0 + k]; }
+            if (grp[k] < a.G) {
+                c[k] = cnt[g0 + k]; o[k] = off[g0 + k];
+                if (half >= 0) {                            // (uniform)
+                    const uint32_t c0 = a.bh0[(int64_t)tile * a.Gr + g0 + k];
+                    if (half == 0) c[k] = c0; else { o[k] += c0; c[k] -= c0; }
+                }
+            }
         }
     const int64_t lo = a.frame_off[a.slot_begin], hi0 = a.frame_off[a.slot_end];
     const int64_t n = hi0 - lo > a.max_points ? a.max_points : hi0 - lo;
@@ -1393,7 +1418,9 @@ __device__ __forceinline__ void tile_cell_medians32(TileStats &S, uint32_t (*his
     }
 }
 
-template <bool I64>
+// EXTRA (the opt-in reducers) and OWN (an item walks its own half's records: a.split) are template parameters: the kernel
+// sits at the 128-VGPR limit of a 1024-thread workgroup and spilled 4-9 registers with them as run-time flags.
+template <bool I64, bool EXTRA, bool OWN>
 __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
 {
     unsigned long long t_begin = wall_clock64();
@@ -1402,7 +1429,7 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
     HeavyLds &L = *reinterpret_cast<HeavyLds *>(smem + (size_t)H_HIST_DWORDS * 4);
     __shared__ uint32_t s_next;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool extra = a.extra != nullptr;
+    constexpr bool extra = EXTRA;
     const bool div255 = !I64 && a.prm.intensity_div255;
     // the queue: HQ_CLASSES lists of tile ids, larger tiles first; item -> (class, place) by the classes' running counts
     __shared__ uint32_t s_cls[HQ_CLASSES + 1];
@@ -1435,7 +1462,10 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
     const int half = (int)(item % HALVES);
     if (item >= (uint32_t)gridDim.x) t_begin = wall_clock64();
     stats_init(L.S, H_THREADS);
-    const uint32_t r_lo = 0, r_hi = recmap_build(L.M, a, tile, H_THREADS);
+    // (split: the item's own records only -- round 4 let both items of a tile stream ALL its records and drop the other half's:
+    // 2 x 16 B read per record of a heavy tile, 3.2 GB for 1.6 GB of records on BASELINE config 4)
+    constexpr bool own = OWN;
+    const uint32_t r_lo = 0, r_hi = recmap_build(L.M, a, tile, H_THREADS, nullptr, own ? half : -1);
     if (threadIdx.x == 0) L.overflow = 0;
     {
         for (int k = threadIdx.x; k < H_HIST_DWORDS / 4; k += H_THREADS) reinterpret_cast<uint4 *>(hist)[k] = make_uint4(0, 0, 0, 0);
@@ -1473,7 +1503,7 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                if (k[u] == RUN_NONE || (int)(k[u] >> 1) / H_CELLS != half) continue;
+                if (k[u] == RUN_NONE || (!own && (int)(k[u] >> 1) / H_CELLS != half)) continue;
                 if (k[u] != run.key) {
                     if (run.key != RUN_NONE) run_flush(L.S, extra, run);
                     run_reset(run, k[u]);
@@ -1525,8 +1555,8 @@ __global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(BIN_
 #endif
 template <bool I64>
 __global__ __launch_bounds__(C_THREADS) C_OCC void bev_tile_cells(const BevArgs a) { bev_tile_cells_body<I64>(a); }
-template <bool I64>
-__global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs a) { bev_tile_cells_heavy_body<I64>(a); }
+template <bool I64, bool EXTRA, bool OWN>
+__global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy(const BevArgs a) { bev_tile_cells_heavy_body<I64, EXTRA, OWN>(a); }
 // (the samples' argument blocks live in CONSTANT memory: the kernels read them through the scalar cache exactly as they read
 // kernel arguments.  Copies out of a global array ended up in scratch -- the blocks are indexed dynamically -- and made
 // level 1 three times slower than a launch per sample.)
@@ -1546,7 +1576,7 @@ __global__ __launch_bounds__(C_THREADS) C_OCC void bev_tile_cells_many()
 template <bool I64>
 __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy_many()
 {
-    bev_tile_cells_heavy_body<I64>(g_bev_many[blockIdx.y]);
+    bev_tile_cells_heavy_body<I64, false, false>(g_bev_many[blockIdx.y]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1572,7 +1602,7 @@ int64_t pca_bev_workspace_bytes(int64_t max_points, int px)
 {
     if (max_points < 1) max_points = 1;
     const int64_t T = (int64_t)tiles_x(px) * tiles_x(px), G = n_groups(max_points);
-    return align256(max_points * 4) + 2 * align256((G + 8) * T * 4) + align256((HQ_IDS + HQ_CLASSES * T) * 4) +
+    return align256(max_points * 4) + 3 * align256((G + 8) * T * 4) + align256((HQ_IDS + HQ_CLASSES * T) * 4) +
            align256((max_points + G) * 24) + 512;
 }
 
@@ -1647,6 +1677,8 @@ static int bev_prepare(pca_ctx *ctx, const pca_store *store, const double *inten
     a.key = reinterpret_cast<uint32_t *>(w); w += align256(max_points * 4);
     a.bh = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.G + 8) * a.T * 4);
     a.boff = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.G + 8) * a.T * 4);
+    a.bh0 = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.G + 8) * a.T * 4);
+    a.split = 0;
     a.heavy = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(HQ_IDS + HQ_CLASSES * (int64_t)a.T) * 4);
     a.recs = w;
     a.planes = planes;
@@ -1671,9 +1703,12 @@ static int bev_set_lds_attributes(pca_ctx *ctx)
 {
     static bool lds_set = false;                            // > 64 KiB of dynamic LDS has to be asked for once
     if (lds_set) return 0;
-#define PCA_BEV_LDS_ATTR(k, bytes) PCA_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
-    PCA_BEV_LDS_ATTR(bev_tile_cells_heavy<false>, HEAVY_LDS_BYTES);
-    PCA_BEV_LDS_ATTR(bev_tile_cells_heavy<true>, HEAVY_LDS_BYTES);
+#define PCA_BEV_LDS_ATTR(k, bytes) PCA_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&(k)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
+#define PCA_BEV_HEAVY_ATTR(I) PCA_BEV_LDS_ATTR((bev_tile_cells_heavy<I, false, false>), HEAVY_LDS_BYTES); PCA_BEV_LDS_ATTR((bev_tile_cells_heavy<I, false, true>), HEAVY_LDS_BYTES); \
+    PCA_BEV_LDS_ATTR((bev_tile_cells_heavy<I, true, false>), HEAVY_LDS_BYTES); PCA_BEV_LDS_ATTR((bev_tile_cells_heavy<I, true, true>), HEAVY_LDS_BYTES)
+    PCA_BEV_HEAVY_ATTR(false);
+    PCA_BEV_HEAVY_ATTR(true);
+#undef PCA_BEV_HEAVY_ATTR
     PCA_BEV_LDS_ATTR(bev_tile_cells_heavy_many<false>, HEAVY_LDS_BYTES);
     PCA_BEV_LDS_ATTR(bev_tile_cells_heavy_many<true>, HEAVY_LDS_BYTES);
     PCA_BEV_LDS_ATTR(bev_tile_bin<false>, 128 * 1024);
@@ -1699,7 +1734,6 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
     if (bev_prepare(ctx, store, intensity64, frame_off, slot_begin, slot_split, slot_end, max_points, prm, pending_Ts,
                     pending_slot_ends, n_pending, write_back, workspace, workspace_bytes, planes, planes_f16, extra_planes, a))
         return -1;
-    const size_t lds = (size_t)a.T * 8;                     // bev_tile_bin: histogram + cursors
     if (bev_set_lds_attributes(ctx)) return -1;
     // one resident workgroup per CU draws from the queue -- when the previous call had no heavy tile (uniform data)
     // only a few are launched: any number of them drains the queue, and 256 idle 110-KiB workgroups cost ~5 us
@@ -1712,18 +1746,36 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
     else if (ctx->heavy_cooldown > 0) --ctx->heavy_cooldown;
     a.heavy_launched = a.heavy_hint_known != 0 || ctx->heavy_cooldown > 0;
     { static int always = -1; if (always < 0) { const char *e = getenv("PCA_BEV_HEAVY_ALWAYS"); always = e ? atoi(e) : 0; } if (always) a.heavy_launched = 1; }
+    // Pieces ordered by half of the tile when the heavy kernel follows (its items are halves), level 1's LDS holds 2 T histogram
+    // entries + 2 T cursors (px <= 720) AND the window stays on level 1's register path.  On the memory path of giant windows
+    // (BASELINE config 4: 1e8 points, 512^2) it was measured and LOSES: the heavy kernel 1485 -> 1261 us, but level 1 2980 ->
+    // 3420 us -- its scattered 16-byte record stores then feed 8192 open ranges per workgroup instead of 4096, a 128-byte line
+    // takes twice as many iterations to fill and is evicted half-written more often (profiles/r05_experiments/bev_split_halves.txt).
+    // Ring model (register path): heavy kernel 44.3 -> 40.9 us, level 1 +0.7.  PCA_BEV_SPLIT=0 / 2: off / also on the memory path (A/B).
+    { static int sp = -1; if (sp < 0) { const char *e = getenv("PCA_BEV_SPLIT"); sp = e ? atoi(e) : 1; }
+      const bool reg_path = !intensity64 && max_points <= (int64_t)a.G * BIN_REG_P * AB_THREADS;
+      a.split = (sp && a.heavy_launched && (size_t)a.T * 16 <= 128 * 1024 && (reg_path || sp == 2)) ? 1 : 0; }
+    const size_t lds = (size_t)a.T * 8 * (a.split ? 2 : 1);  // bev_tile_bin: histogram + cursors
     if (ctx->profiling == 2) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
     // (Running the two tile kernels side by side was tried: a second stream with fork / join events costs ~20 us per
     // call, and hipExtAnyOrderLaunch is not honoured on gfx9 -- see DESIGN.md.)
+#define PCA_BEV_HEAVY_LAUNCH(I, E, O) PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, (bev_tile_cells_heavy<I, E, O>), dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a)
+#define PCA_BEV_HEAVY_PICK(I)                                                                                          \
+    do {                                                                                                               \
+        if (a.extra) { if (a.split) PCA_BEV_HEAVY_LAUNCH(I, true, true); else PCA_BEV_HEAVY_LAUNCH(I, true, false); }  \
+        else { if (a.split) PCA_BEV_HEAVY_LAUNCH(I, false, true); else PCA_BEV_HEAVY_LAUNCH(I, false, false); }        \
+    } while (0)
     if (intensity64) {
         PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_bin<true>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
         PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_tile_cells<true>, dim3(a.T), dim3(C_THREADS), s, a);
-        if (a.heavy_launched) PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, bev_tile_cells_heavy<true>, dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a);
+        if (a.heavy_launched) PCA_BEV_HEAVY_PICK(true);
     } else {
         PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_bin<false>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
         PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_tile_cells<false>, dim3(a.T), dim3(C_THREADS), s, a);
-        if (a.heavy_launched) PCA_LAUNCH_SHM(ctx, PCA_K_BEV_CELLS_HEAVY, bev_tile_cells_heavy<false>, dim3(heavy_grid), dim3(H_THREADS), HEAVY_LDS_BYTES, s, a);
+        if (a.heavy_launched) PCA_BEV_HEAVY_PICK(false);
     }
+#undef PCA_BEV_HEAVY_PICK
+#undef PCA_BEV_HEAVY_LAUNCH
     if (ctx->profiling == 2) pca_prof_end(ctx, s);
     PCA_CHECK(ctx, hipGetLastError());
     return 0;
