@@ -407,7 +407,7 @@ int pca_stage_copy(const void *const *src, void *const *dst, const int64_t *byte
     static std::mutex serial;                               // one job at a time (callers on several threads take turns)
     std::lock_guard<std::mutex> lk(serial);
     StagePool *pool = stage_pool();
-    if (slices.size() < 2) for (auto &sl : slices) memcpy(sl.dst, sl.src, sl.n);
+    if (slices.size() < 2) { for (auto &sl : slices) pca_stage::copy_slice(sl.dst, sl.src, sl.n); pca_stage::stream_fence(); }
     else pool->run(slices.data(), (int)slices.size());
     return 0;
 }

@@ -23,9 +23,59 @@
 #include <thread>
 #include <vector>
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
 namespace pca_stage {
 
 struct Slice { char *dst; const char *src; size_t n; };
+
+// One slice, pageable source -> pinned staging block.  The destination is written ONCE and read next by the DMA engine, never
+// by this CPU: streaming (non-temporal) stores skip the read-for-ownership of every destination line that a plain memcpy of
+// 128 KB pays (glibc switches to them only for copies beyond the cache size), i.e. a third less memory traffic per byte staged.
+// PCA_STAGING_NT=0: plain memcpy (A/B).  The caller fences (stream_fence) before it publishes the slice as done.
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline void copy_nt_avx2(char *dst, const char *src, size_t n)
+{
+    const size_t head = (32 - (reinterpret_cast<uintptr_t>(dst) & 31)) & 31;
+    if (head) { const size_t h = head < n ? head : n; memcpy(dst, src, h); dst += h; src += h; n -= h; }
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 64));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 96), d);
+    }
+    if (i < n) memcpy(dst + i, src + i, n - i);
+}
+#endif
+inline bool use_nt()
+{
+#if defined(__x86_64__)
+    static const bool on = [] { const char *e = getenv("PCA_STAGING_NT"); return (!e || atoi(e) != 0) && __builtin_cpu_supports("avx2"); }();
+    return on;
+#else
+    return false;
+#endif
+}
+inline void copy_slice(char *dst, const char *src, size_t n)
+{
+#if defined(__x86_64__)
+    if (n >= 4096 && use_nt()) { copy_nt_avx2(dst, src, n); return; }
+#endif
+    memcpy(dst, src, n);
+}
+inline void stream_fence()                                  // streaming stores are weakly ordered: drained before "done" is said
+{
+#if defined(__x86_64__)
+    _mm_sfence();
+#endif
+}
 
 struct Pool {
     static constexpr int IDX_BITS = 20;
@@ -55,7 +105,8 @@ struct Pool {
             if (i >= total) return gen_of(c);
             if (!claim.compare_exchange_weak(c, c + 1, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
             const Slice *s = slices.load(std::memory_order_relaxed);      // published before the claim word (release / acquire)
-            memcpy(s[i].dst, s[i].src, s[i].n);
+            copy_slice(s[i].dst, s[i].src, s[i].n);
+            stream_fence();
             done.fetch_add(1, std::memory_order_release);
             c = claim.load(std::memory_order_acquire);
         }
@@ -93,7 +144,7 @@ struct Pool {
     void run(const Slice *s, int n)
     {
         if (n <= 0) return;
-        if (T == 0 || n > MAX_SLICES) { for (int i = 0; i < n; ++i) memcpy(s[i].dst, s[i].src, s[i].n); return; }
+        if (T == 0 || n > MAX_SLICES) { for (int i = 0; i < n; ++i) copy_slice(s[i].dst, s[i].src, s[i].n); stream_fence(); return; }
         gen = (gen + 1) & ((1ull << (64 - 2 * IDX_BITS)) - 1);
         if (gen == 0) gen = 1;                                // (0 = "no job yet" for a fresh helper)
         slices.store(s, std::memory_order_relaxed);
