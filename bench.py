@@ -49,7 +49,7 @@ MIN_TIMED_S = 0.25                        # ... and as many as it takes to have 
 MAX_REPEATS = 2000
 GATHER_CHUNK = 16                         # multi-GPU: BEV samples per asynchronous gather to rank 0
 HBM_PEAK_GBS = 8000.0                     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_TAG = 'r04'                       # profiles/<tag>_pmc_traffic*.json: rocprofv3 PMC passes of THESE kernels
+PROFILE_TAG = 'r05'                       # profiles/<tag>_pmc_traffic*.json: rocprofv3 PMC passes of THESE kernels
 KITTI360_LENGTHS = [11270, 14384, 730, 11440, 6610, 9578, 2960, 13855, 3540]   # run_kitti360_bev_gen.py:172-173, end - start
 
 CAM_TO_VELO = np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418],
@@ -968,7 +968,8 @@ def config5_pass(rank, world, scale, barrier, allmax, coll_dev, dist, lanes_per_
            'seconds': elapsed, 'Mpoints_per_s': total_frames * N_PTS / elapsed / 1e6,
            'bev_frames_per_s': total_samples / elapsed,
            'frames_incl_warmup_per_rank': loads, 'plan_seconds_host': plan_s, 'lanes_per_gpu': n_lanes,
-           'ideal_speedup_of_this_plan': float(total_frames) / max(loads)}
+           'ideal_speedup_of_this_plan': float(total_frames) / max(loads),
+           'peak_hbm_GB_torch_allocator': torch.cuda.max_memory_allocated() / 1e9}
     # content check: the last chunk of every rank -> rank 0, checksums compared.  A failure of the check's own collectives
     # is reported in the block, it does not take the measurement above down with it.
     mine = ring.view(torch.int16).to(torch.int64).sum().reshape(1)
@@ -1399,7 +1400,12 @@ def main():
     # In steady state the owed re-transform of a step is applied by the BEV's first pass (it reads every
     # coordinate anyway): the BEV unit then also does K2's work, so its algorithmic bytes include K2's.
     m_kept = float(np.mean(sizes))
-    m_proj = m_kept * 19.0 / 14.0 / 0.99               # 14 of 19 uniform classes survive, 1 % 'ignore'
+    # in-frustum points per frame, COUNTED: the pool's frames through K1 without a class filter
+    from pca_amd.device_store import DeviceStore
+    cnt = DeviceStore(capacity=len(pool) * N_PTS, max_frames=len(pool) + 1)
+    cnt.append_kitti([dict(pts=f[1], rgb=f[0], sem=f[2]) for f in pool], P_VELO_FRAME, IMG_H, IMG_W, [])
+    m_proj = float(np.mean(cnt.sizes()))
+    del cnt
     k2_fused = 'retransform' not in kern
     alg = {
         'kitti_project_sample_filter': 16.0 * N_PTS + 4.0 * m_proj + 40.0 * m_kept,

@@ -83,7 +83,8 @@ struct alignas(16) BevArgs {                             // (16: pca_fetch_block
     uint32_t *boff;       // [T][G] exclusive scan of bh in that order
     uint32_t *bh0;        // [T][G] with `split`: how many of a (tile, workgroup) piece's records belong to the tile's cells 0..31
     int split;            // level 1 orders every piece by HALF of the tile (cells 0..31, then 32..63), so that an item (tile, half)
-                          // of bev_tile_cells_heavy walks its own records only -- set when a heavy launch follows
+                          // of bev_tile_cells_heavy walks its own records only: 0 never, 1 if the window is small enough for
+                          // level 1's register path (bev_split: decided by the kernels, which know the window), 2 always
     uint32_t *heavy_hint; // host-visible word: the heavy count of this call, read by the host before the next one
     uint32_t heavy_hint_known;   // its value when this call was made
     int heavy_launched;   // a bev_tile_cells_heavy launch follows (else the light kernel's last workgroup drains the queue)
@@ -132,6 +133,12 @@ __host__ __device__ __forceinline__ int64_t seg_stride(int64_t n, int G) { retur
 // ONE XCD -- the 32 of a round fill a whole 128-byte line in that XCD's L2, which then leaves it as one full-line write.
 // In plain [tile][g] order a line held the 4-byte stores of eight different L2s: 1 M partial-line writes per call, 100 MB
 // of write traffic for 75 MB of payload.  Level 2 reads a tile's row as one range either way.  Gp = 0: plain order.
+// Are the pieces of THIS call ordered by half of the tile (a.split: 1 = if the window stays on level 1's register path -- the
+// host only knows an upper bound of the window, the kernels read its size --, 2 = always)?  The same answer in every kernel.
+__device__ __forceinline__ bool bev_split(const BevArgs &a, int64_t window_points)
+{
+    return a.split == 2 || (a.split == 1 && window_points <= (int64_t)a.G * BIN_REG_P * AB_THREADS);
+}
 __device__ __forceinline__ int table_pos(const BevArgs &a, int g) { return a.Gp ? (g & 7) * a.Gp + (g >> 3) : g; }
 __device__ __forceinline__ int table_group(const BevArgs &a, int p)
 {
@@ -307,10 +314,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     extern __shared__ uint32_t s_lds[];                     // [T] histogram, [T] cursors
     __shared__ uint32_t s_wsum[AB_THREADS / 64];
     __shared__ uint32_t s_dyn[8];                           // prm.dynobj_mask as dwords (see bin_store)
-    // split: one histogram entry and one cursor per (tile, half of its cells): key >> 6 = tile << 1 | cell >> 5
-    const int hs = a.split ? 6 : 7;
-    const int n_hist = a.split ? 2 * a.T : a.T;
-    uint32_t *s_h = s_lds, *s_cur = s_lds + n_hist;
+    uint32_t *s_h = s_lds;
     if (threadIdx.x < 8) {                                  // (a select chain over scalar registers, no indexed read)
         uint32_t w = (uint32_t)a.prm.dynobj_mask[0];
 #pragma unroll
@@ -321,6 +325,11 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     int g;                                                  // this workgroup's chunk
     const Window w = chunk_of(a, g);
     const int64_t chunk = seg_stride(w.hi - w.lo, a.G);
+    // split: one histogram entry and one cursor per (tile, half of its cells): key >> 6 = tile << 1 | cell >> 5
+    const bool split = bev_split(a, w.hi - w.lo);
+    const int hs = split ? 6 : 7;
+    const int n_hist = split ? 2 * a.T : a.T;
+    uint32_t *s_cur = s_lds + n_hist;
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0 && a.frame_off[a.slot_end] - w.lo > a.max_points) pca_raise(a.status, PCA_STATUS_STORE_OVERFLOW);
         if (threadIdx.x < HQ_IDS) a.heavy[threadIdx.x] = 0;  // the heavy queue of this call starts empty
@@ -462,7 +471,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
         const int t0 = threadIdx.x * per;
         const int gp = table_pos(a, g);
         uint32_t sum = 0;
-        if (a.split) { for (int k = 0; k < per; ++k) sum += t0 + k < a.T ? s_h[2 * (t0 + k)] + s_h[2 * (t0 + k) + 1] : 0u; }
+        if (split) { for (int k = 0; k < per; ++k) sum += t0 + k < a.T ? s_h[2 * (t0 + k)] + s_h[2 * (t0 + k) + 1] : 0u; }
         else { for (int k = 0; k < per; ++k) sum += t0 + k < a.T ? s_h[t0 + k] : 0u; }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const uint32_t inc = wave_incl_scan_add(sum);
@@ -475,7 +484,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
             const int t = t0 + k;
             if (t >= a.T) break;
             // tile-major tables [tile][place of the workgroup]: a tile's workgroup of level 2 reads its counters as one range
-            if (a.split) {                                  // the piece = the tile's first half, then its second
+            if (split) {                                    // the piece = the tile's first half, then its second
                 const uint32_t c0 = s_h[2 * t], c1 = s_h[2 * t + 1];
                 s_cur[2 * t] = run;
                 s_cur[2 * t + 1] = run + c0;
@@ -584,7 +593,7 @@ __device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, in
     const int per = (a.Gr + nthreads - 1) / nthreads;
     const int g0 = threadIdx.x * per;
     const uint32_t *cnt = a.bh + (int64_t)tile * a.Gr, *off = a.boff + (int64_t)tile * a.Gr;
-    uint32_t c[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0}, sum = 0;  // per <= 4: Gr <= 1024, nthreads >= 256
+    uint32_t c[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0}, c0[4] = {0, 0, 0, 0}, sum = 0;  // per <= 4: Gr <= 1024, nthreads >= 256
     int grp[4] = {0, 0, 0, 0};
     // (the counters' loads are issued before the window's size is waited for: two memory round trips side by side)
 #pragma unroll
@@ -593,14 +602,15 @@ __device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, in
             grp[k] = table_group(a, g0 + k);
             if (grp[k] < a.G) {
                 c[k] = cnt[g0 + k]; o[k] = off[g0 + k];
-                if (half >= 0) {                            // (uniform)
-                    const uint32_t c0 = a.bh0[(int64_t)tile * a.Gr + g0 + k];
-                    if (half == 0) c[k] = c0; else { o[k] += c0; c[k] -= c0; }
-                }
+                if (half >= 0) c0[k] = a.bh0[(int64_t)tile * a.Gr + g0 + k];     // (uniform; read before it is known to be valid: never used then)
             }
         }
     const int64_t lo = a.frame_off[a.slot_begin], hi0 = a.frame_off[a.slot_end];
     const int64_t n = hi0 - lo > a.max_points ? a.max_points : hi0 - lo;
+    if (half >= 0 && bev_split(a, n)) {                     // (uniform) the item's own half of every piece
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (half == 0) c[k] = c0[k]; else { o[k] += c0[k]; c[k] -= c0[k]; } }
+    }
     const uint32_t chunk = (uint32_t)seg_stride(n, a.G);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -1464,8 +1474,12 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
     stats_init(L.S, H_THREADS);
     // (split: the item's own records only -- round 4 let both items of a tile stream ALL its records and drop the other half's:
     // 2 x 16 B read per record of a heavy tile, 3.2 GB for 1.6 GB of records on BASELINE config 4)
-    constexpr bool own = OWN;
-    const uint32_t r_lo = 0, r_hi = recmap_build(L.M, a, tile, H_THREADS, nullptr, own ? half : -1);
+    bool own = false;                                       // (uniform) OWN: compiled for it; in effect if this window's pieces are ordered
+    if (OWN) {
+        const int64_t wn = a.frame_off[a.slot_end] - a.frame_off[a.slot_begin];
+        own = bev_split(a, wn > a.max_points ? a.max_points : wn);
+    }
+    const uint32_t r_lo = 0, r_hi = recmap_build(L.M, a, tile, H_THREADS, nullptr, OWN ? half : -1);
     if (threadIdx.x == 0) L.overflow = 0;
     {
         for (int k = threadIdx.x; k < H_HIST_DWORDS / 4; k += H_THREADS) reinterpret_cast<uint4 *>(hist)[k] = make_uint4(0, 0, 0, 0);
@@ -1752,9 +1766,10 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
     // 3420 us -- its scattered 16-byte record stores then feed 8192 open ranges per workgroup instead of 4096, a 128-byte line
     // takes twice as many iterations to fill and is evicted half-written more often (profiles/r05_experiments/bev_split_halves.txt).
     // Ring model (register path): heavy kernel 44.3 -> 40.9 us, level 1 +0.7.  PCA_BEV_SPLIT=0 / 2: off / also on the memory path (A/B).
+    // (the host knows only an upper bound of the window: it allows the split -- and sizes level 1's LDS for it -- and the
+    // kernels decide on the window's real size, all of them alike: bev_split)
     { static int sp = -1; if (sp < 0) { const char *e = getenv("PCA_BEV_SPLIT"); sp = e ? atoi(e) : 1; }
-      const bool reg_path = !intensity64 && max_points <= (int64_t)a.G * BIN_REG_P * AB_THREADS;
-      a.split = (sp && a.heavy_launched && (size_t)a.T * 16 <= 128 * 1024 && (reg_path || sp == 2)) ? 1 : 0; }
+      a.split = (sp && a.heavy_launched && !intensity64 && (size_t)a.T * 16 <= 128 * 1024) ? (sp == 2 ? 2 : 1) : 0; }
     const size_t lds = (size_t)a.T * 8 * (a.split ? 2 : 1);  // bev_tile_bin: histogram + cursors
     if (ctx->profiling == 2) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
     // (Running the two tile kernels side by side was tried: a second stream with fork / join events costs ~20 us per

@@ -135,7 +135,7 @@ def test_bench_gather_in_the_timed_region_and_config5_in_one_rccl_process_group(
     env.pop('PCA_BENCH_BACKEND', None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', '29549', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '1', '--gather',
-           '--extras', 'config5', '--config5-scale', '0.01', '--no-cpu-baseline']
+           '--extras', 'config5', '--config5-scale', '0.03', '--no-cpu-baseline']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = last_json(r.stdout)
