@@ -783,14 +783,15 @@ static int k1_prepare(pca_ctx *ctx, const pca_kitti_frame *frames, int n_frames,
     K1AppendArgs &pa = plan->pa;
     pa.rec_p = a.rec_p; pa.rec_c = a.rec_c; pa.counts = a.counts; pa.lastf = a.lastf; pa.tile_points = tile_pts;
     pa.tiles = total;
-    {   // tiles per workgroup of k1_append and the non-temporal hint: PCA_K1_APPEND="<group>[,nt|,plain]" (A/B; results are
-        // identical).  Default: one tile per workgroup (4 and 8 measured the same), non-temporal: the 61 MB the append kernel
-        // stores and the 33 MB it reads are not pushed through the caches in front of HBM, where they evicted the NEXT launch's
-        // inputs -- 64 uniform frames per call 69.9 -> 60.0 us, ring-model frames unchanged (profiles/r05_experiments/k1_round5.txt)
-        static int group = -1, nt = 1;
+    {   // tiles per workgroup of k1_append and the non-temporal hint: PCA_K1_APPEND="<group>[,nt]" (A/B; results are identical).
+        // Default: one tile per workgroup (4 and 8 measured the same), plain loads and stores.  Non-temporal: the kernel itself
+        // takes 23 instead of 17 us; it wins only where the NEXT call's inputs would otherwise be pushed out of the Infinity Cache
+        // (64 frames cycled: 69.9 -> 60-64 us), loses on cached inputs (8 frames: 49.7 -> 54.1) and changes nothing when the
+        // inputs come from HBM (two alternating batches: 75.3 / 75.4): profiles/r05_experiments/k1_round5.txt
+        static int group = -1, nt = 0;
         if (group < 0) {
             group = 1;
-            if (const char *e = getenv("PCA_K1_APPEND")) { group = atoi(e); nt = strstr(e, "plain") == nullptr; }
+            if (const char *e = getenv("PCA_K1_APPEND")) { group = atoi(e); nt = strstr(e, "nt") != nullptr; }
             if (group < 1) group = 1;
             if (group > 64) group = 64;
         }
