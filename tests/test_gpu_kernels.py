@@ -974,3 +974,50 @@ def test_light_tile_kernel_thread_contiguous_mode_in_a_subprocess():
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_kernels.py'), '-x', '-q', '-m', 'gpu', '-k',
                         'ring_like_skew or dense_tile_goes or randomised_configs'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def _ab_switches_child():
+    """(run in a child process by the test below) hashes of a skewed raster's planes and of a batched K1's stored rows."""
+    import hashlib
+    import torch as T_
+    rng = np.random.default_rng(123)
+    rows = _skewed_rows(rng, 150000, 0.9, 4)
+    p16, p64, _ = run_dev_bev(T_, rows[:60000], rows[60000:], 32, 64, None, (1., 30., 0.12), True, 0.2)
+    p16b, _, _ = run_dev_bev(T_, rows[:60000], rows[60000:], 32, 64, None, (1., 30., 0.12), True, 0.2)      # (second call: heavy kernel)
+    h_bev = hashlib.sha256(p16.cpu().numpy().tobytes() + p16b.cpu().numpy().tobytes() + p64.cpu().numpy().tobytes()).hexdigest()
+    from pca_amd.device_store import DeviceStore
+    H, W, n = 94, 352, 30000
+    frames = []
+    for k in range(6):
+        pc = np.stack([rng.uniform(-40, 40, n), rng.uniform(-40, 40, n), rng.uniform(-2, 3, n), rng.uniform(0, 1, n)], 1).astype(np.float32)
+        frames.append(dict(pts=T_.from_numpy(pc).cuda(), rgb=T_.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).cuda(),
+                           sem=T_.from_numpy(rng.integers(0, 19, (H, W)).astype(np.uint8)).cuda()))
+    cam_to_velo = np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418], [-0.999004371, 0.007784614041, 0.04392796942, 0.2993489574],
+                            [-0.01162548558, -0.9960641394, -0.08786966659, -0.1770225824], [0, 0, 0, 1]])
+    P = np.array([[138., 0, 176, 0], [0, 138., 47, 0], [0, 0, 1, 0]]) @ np.linalg.inv(cam_to_velo)
+    st = DeviceStore(capacity=6 * n, max_frames=8)
+    os.environ['PCA_K1_MODE'] = 'split'
+    st.append_kitti(frames, P, H, W, [10, 11, 12, 16, 18, 255])
+    st.check_status()
+    h_k1 = hashlib.sha256(st.rows().tobytes()).hexdigest()
+    print('ABHASH', h_bev, h_k1, int(st.offsets()[-1]))
+
+
+def test_ab_switches_of_round5_change_no_result():
+    """PCA_BEV_SPLIT (pieces ordered by half of the tile: off / register path / always) and PCA_K1_APPEND (tiles per
+    k1_append workgroup, non-temporal accesses) are speed switches read once per process: every setting gives the bits of the
+    default (a raster with heavy and light tiles, f16 and f64 planes; the stored rows of a six-frame split-form K1 batch)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ('import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_kernels as t; '
+            't._ab_switches_child()' % (here, os.path.join(os.path.dirname(here), 'pc-accumulation-lib_amd'), os.path.dirname(here)))
+    got = {}
+    for name, env in (('default', {}), ('split0', {'PCA_BEV_SPLIT': '0'}), ('split2', {'PCA_BEV_SPLIT': '2'}),
+                      ('append4nt', {'PCA_K1_APPEND': '4,nt'}), ('staging_plain', {'PCA_STAGING_NT': '0'})):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stdout[-1500:] + r.stderr[-1500:])
+        got[name] = [ln for ln in r.stdout.splitlines() if ln.startswith('ABHASH ')][-1].split()[1:]
+    assert int(got['default'][2]) > 20000
+    for name, v in got.items():
+        assert v == got['default'], name
