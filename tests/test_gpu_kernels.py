@@ -984,7 +984,7 @@ def _ab_switches_child():
     rows = _skewed_rows(rng, 150000, 0.9, 4)
     p16, p64, _ = run_dev_bev(T_, rows[:60000], rows[60000:], 32, 64, None, (1., 30., 0.12), True, 0.2)
     p16b, _, _ = run_dev_bev(T_, rows[:60000], rows[60000:], 32, 64, None, (1., 30., 0.12), True, 0.2)      # (second call: heavy kernel)
-    h_bev = hashlib.sha256(p16.cpu().numpy().tobytes() + p16b.cpu().numpy().tobytes() + p64.cpu().numpy().tobytes()).hexdigest()
+    h_bev = hashlib.sha256(np.asarray(p16).tobytes() + np.asarray(p16b).tobytes() + np.asarray(p64).tobytes()).hexdigest()
     from pca_amd.device_store import DeviceStore
     H, W, n = 94, 352, 30000
     frames = []
