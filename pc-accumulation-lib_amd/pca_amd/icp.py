@@ -7,9 +7,12 @@ The reference calls (kitti360_sem_pc_accum.py:115-127, sem_pc_accum.py:310-315)
 
 and uses ``.transformation`` as T_new_prev.  `GpuIcp.register` runs a point-to-plane ICP of the same shape (defaults of
 Open3D: at most 30 iterations, relative fitness / rmse 1e-6) in HIP kernels (csrc/pca_icp.hip), with two deliberate
-differences: a correspondence is the nearest target point within min(`threshold`, MAX_CORR_DIST = 4 m) -- exact inside that
-ball, nothing beyond it, where the reference (it passes 1e3: "every point has a partner") would take the nearest point of
-the whole cloud -- and target points outside +-128 m / +-16 m of the sensor are ignored.  So fitness / rmse
+differences: a correspondence is the nearest target point closer than `threshold` inside a box of +-8 half-metre cells
+around the query's cell -- exact for every partner within MAX_CORR_DIST = 4 m, whatever the threshold; a partner farther
+than that is found only if it lies in the box, where the reference (it passes 1e3: "every point has a partner") would
+take the nearest point of the whole cloud -- and target points outside +-128 m / +-16 m of the sensor are ignored.
+(A strict 4 m ball was tried in round 5: it moves the poses AWAY from the uncapped model -- the 2 m-step case of
+test_icp_search_cap_against_the_uncapped_model leaves its 1e-3 -- and is no faster.)  So fitness / rmse
 and, within ICP's own tolerance, the pose differ from Open3D's; Open3D is a third-party, unpinned dependency of the
 reference, there is no golden vector: parity is UNPINNED and the tests check known motions and a k-d-tree CPU model.
 It is opt-in (PCA_POSE_PROVIDER=gpu_icp), never a silent fallback.
