@@ -896,7 +896,11 @@ def kitti_icp_flow_pass(steps=30):
             'bev_frames_per_s': steps / dt, 'icp_ms_per_registration': 1e3 * icp_s[0] / max(icp_s[1], 1),
             'icp_share_of_step': icp_s[0] / dt, 'metres_per_frame_recovered_mean': float(np.mean(adv)) if adv else None,
             'metres_per_frame_recovered_minmax': [float(np.min(adv)), float(np.max(adv))] if adv else None,
-            'note': 'sequential pose chain: not chunk-shardable; whole sequences still shard over the GPUs'}
+            'note': 'sequential pose chain: not chunk-shardable; whole sequences still shard over the GPUs',
+            'note_recovered_motion': 'the scene slides 1 m per frame; point-to-plane ICP recovers ~0.85 m of it on THIS synthetic scene, device '
+                                     'and CPU alike (the same algorithm with exact, uncapped k-d-tree neighbours -- tests/test_gpu_icp.py:icp_model -- '
+                                     'gives 0.838 m on frames 3 -> 4): the ground rings travel with the sensor and pull towards zero motion.  '
+                                     'Known motions on a ray-cast scene with world-fixed structure are recovered to 3 cm (tests/test_gpu_icp.py)'}
 
 
 # --------------------------------------------------------------------------------------------------------------------
