@@ -349,6 +349,18 @@ int pca_kitti_integrate(pca_ctx *ctx, const pca_kitti_obs *obs, const double P[1
                         const uint64_t filter_mask[4], const pca_store *store, int64_t *frame_off /*dev*/, int slot,
                         int sample_mode, pca_host_track *track, const double *T_new_prev, double horizon, int64_t *evicted,
                         double *path_length, void *stream);
+/* K1 of pca_kitti_integrate left for the raster that follows it.  The reference's driver integrates a frame and, when its
+ * trigger fires, rasterises the window that ends with that frame (run_kitti360_bev_gen.py:186-273): with on = 1, a
+ * pca_kitti_integrate whose inputs are the plain kind (nearest sampling, rgb + class map) does the pose bookkeeping and the
+ * staging as before but only NOTES its K1; the next pca_bev_generate_chain / pca_kitti_generate_bev of the context whose
+ * window ends with that slot (same store, frame_off and stream, 5 planes x int32 layout) runs it as the first workgroups
+ * of its own first kernel -- the frame's kept points go into the store AND, straight from registers, into the raster's
+ * tile lists, so they are not read back.  Every other entry point that reads or writes a store runs a noted K1 first, on
+ * its own (the order of effects on `stream` is the order of the calls, as without deferral); so does pca_status.  Until
+ * then the DEVICE pointers of the observation must stay valid (host arrays are held in the context's staging block).
+ * pca_k1_defer(ctx, 0) turns it off and runs what is noted; pca_k1_flush runs what is noted.  0 / -1. */
+int pca_k1_defer(pca_ctx *ctx, int on);
+int pca_k1_flush(pca_ctx *ctx);
 int pca_kitti_generate_bev(pca_ctx *ctx, const pca_store *store, const int64_t *frame_off /*dev*/, int slot_begin,
                            int slot_split, int slot_end, int64_t max_points, const pca_bev_params *prm,
                            const double *pending_Ts, const int *pending_slot_ends, int n_pending, int write_back,

@@ -735,6 +735,7 @@ int pca_nusc_sample_filter_transform_ex(pca_ctx *ctx, const double *pc, const in
                                         int64_t *frame_off, int slot, int sample_mode, void *stream)
 {
     if (!ctx) return -1;
+    if (pca_k1_flush_pending(ctx)) return -1;               // a deferred K1 of this context comes first
     if (sample_mode != PCA_SAMPLE_NEAREST && sample_mode != PCA_SAMPLE_BILINEAR) { ctx->err = "k1n: unknown sample_mode"; return -1; }
     if (ncam < 1 || H < 1 || W < 1 || (int64_t)ncam * H * W * 3 < 4) { ctx->err = "k1n: bad image stack"; return -1; }
     if (n < 0 || (n > 0 && (!pc || !cam_idx || !imgs || !sems)) || !store || !frame_off) { ctx->err = "k1n: bad arguments"; return -1; }
@@ -775,6 +776,7 @@ int pca_nusc_sample_filter_transform_batch(pca_ctx *ctx, const pca_nusc_frame *f
                                            int first_slot, int sample_mode, void *stream)
 {
     if (!ctx) return -1;
+    if (pca_k1_flush_pending(ctx)) return -1;               // a deferred K1 of this context comes first
     if (sample_mode != PCA_SAMPLE_NEAREST && sample_mode != PCA_SAMPLE_BILINEAR) { ctx->err = "k1n: unknown sample_mode"; return -1; }
     if (ncam < 1 || H < 1 || W < 1 || (int64_t)ncam * H * W * 3 < 4) { ctx->err = "k1n: bad image stack"; return -1; }
     if (!frames || n_frames < 1 || !store || !frame_off) { ctx->err = "k1n: bad arguments"; return -1; }
@@ -879,6 +881,7 @@ int pca_retransform(pca_ctx *ctx, const pca_store *store, const int64_t *frame_o
                     const double *Ts, int n_T, void *stream)
 {
     if (!ctx) return -1;
+    if (pca_k1_flush_pending(ctx)) return -1;               // a deferred K1 of this context comes first
     if (!store || !frame_off || !Ts || n_T < 0 || slot_end < slot_begin) { ctx->err = "k2: bad arguments"; return -1; }
     if (n_T == 0 || slot_end == slot_begin) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -900,6 +903,7 @@ int pca_retransform_batch_tail(pca_ctx *ctx, const pca_store *store, const int64
                                const double *Ts, void *stream)
 {
     if (!ctx) return -1;
+    if (pca_k1_flush_pending(ctx)) return -1;               // a deferred K1 of this context comes first
     if (!store || !frame_off || !Ts || n_frames < 0 || n_frames > 65535) { ctx->err = "k2 tail: bad arguments"; return -1; }
     if (n_frames < 2) return 0;                  // a single frame owes nothing
     hipStream_t s = (hipStream_t)stream;
@@ -958,6 +962,7 @@ int pca_mark_dynamic(pca_ctx *ctx, const pca_store *store, const int64_t *frame_
                      const int32_t *inst_idx, int n_pairs, void *stream)
 {
     if (!ctx) return -1;
+    if (pca_k1_flush_pending(ctx)) return -1;               // a deferred K1 of this context comes first
     if (!store || !frame_off || n_pairs < 0 || (n_pairs > 0 && (!slots || !inst_idx))) { ctx->err = "k3: bad arguments"; return -1; }
     hipStream_t s = (hipStream_t)stream;
     PCA_CHECK(ctx, hipSetDevice(ctx->device));
@@ -992,6 +997,7 @@ int pca_voxel_dedup(pca_ctx *ctx, const pca_store *store, int64_t *frame_off, in
                     double voxel_size, int64_t max_points, void *workspace, int64_t workspace_bytes, void *stream)
 {
     if (!ctx) return -1;
+    if (pca_k1_flush_pending(ctx)) return -1;               // a deferred K1 of this context comes first
     if (!store || !frame_off || !workspace || slot_end < slot_begin) { ctx->err = "dedup: bad arguments"; return -1; }
     if (!(voxel_size > 0.0)) { ctx->err = "dedup: voxel_size must be positive"; return -1; }
     if (slot_end == slot_begin) return 0;

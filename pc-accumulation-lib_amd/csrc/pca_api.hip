@@ -220,6 +220,7 @@ const char *pca_last_error(pca_ctx *ctx) { return ctx ? ctx->err.c_str() : "null
 int pca_status(pca_ctx *ctx, void *stream, uint32_t *status_out)
 {
     if (!ctx || !status_out) return -1;
+    if (pca_k1_flush_pending(ctx)) return -1;               // a deferred K1 of this context comes first
     hipStream_t s = (hipStream_t)stream;
     PCA_CHECK(ctx, hipSetDevice(ctx->device));
     PCA_CHECK(ctx, hipMemcpyAsync(ctx->status_host, ctx->ticket + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

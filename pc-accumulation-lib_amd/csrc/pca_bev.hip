@@ -19,6 +19,7 @@
 //                       of 32 cells at a time filled straight from the record stream (two passes, no sort).
 // 'full' = present (+) future is formed per cell (counts add, min of mins, median of the union).
 #include "pca_bev_common.h"
+#include "pca_k1_body.h"
 #include <cstdlib>
 #include <mutex>
 
@@ -81,6 +82,8 @@ struct alignas(16) BevArgs {                             // (16: pca_fetch_block
     uint32_t *key;        // [max_points]
     uint32_t *bh;         // [T][G] kept records per (tile, workgroup)
     uint32_t *boff;       // [T][G] exclusive scan of bh in that order
+    int Gk;               // the first Gk of the G pieces are the tiles of a K1 that rides in level 1's launch (0: none), see bev_tile_bin_k1
+    int k1_slot, k1_n;    // its slot (the window's last: the pieces behind Gk cover the window up to it) and its input points
     uint32_t *bh0;        // [T][G] with `split`: how many of a (tile, workgroup) piece's records belong to the tile's cells 0..31
     int split;            // level 1 orders every piece by HALF of the tile (cells 0..31, then 32..63), so that an item (tile, half)
                           // of bev_tile_cells_heavy walks its own records only: 0 never, 1 if the window is small enough for
@@ -113,16 +116,24 @@ __device__ __forceinline__ int chunk_index(const BevArgs &a, int64_t lo, int64_t
     (void)a; (void)lo; (void)sp; (void)chunk;
     return (int)blockIdx.x;
 }
+#define K1_SEG 4096               // record slots of a K1 piece (one 1024 x 4 tile of k1_body keeps at most that many points)
+#define K1_RIDE 32                // K1 tiles that may ride in a level-1 launch (frames of up to 131 072 points): they come ON TOP of
+                                  // the window's G pieces, so the counter tables and the record buffer are sized for G + K1_RIDE
+// the window level 1 reads from the store: up to the frame whose K1 rides along (its points come out of K1's registers), else all
+__device__ __forceinline__ int64_t window_end(const BevArgs &a) { return a.frame_off[a.Gk ? a.k1_slot : a.slot_end]; }
 __device__ __forceinline__ Window chunk_of(const BevArgs &a, int &g)
 {
     Window w;
     w.lo = a.frame_off[a.slot_begin];
-    const int64_t hi0 = a.frame_off[a.slot_end];
-    w.sp = a.frame_off[a.slot_split];
+    const int64_t hi0 = window_end(a);
+    // (with a K1 in the launch frame_off[k1_slot + 1] is not written yet: a split behind that frame = everything the store holds)
+    w.sp = (a.Gk && a.slot_split > a.k1_slot) ? hi0 : a.frame_off[a.slot_split];
     w.hi = (hi0 - w.lo > a.max_points) ? w.lo + a.max_points : hi0;
-    const int64_t chunk = (w.hi - w.lo + a.G - 1) / a.G;
-    g = chunk_index(a, w.lo, w.sp, chunk);
-    w.c_lo = w.lo + (int64_t)g * chunk;
+    const int G = a.G - a.Gk;                               // chunks of the store's part of the window
+    const int64_t chunk = (w.hi - w.lo + G - 1) / G;
+    g = chunk_index(a, w.lo, w.sp, chunk);                  // the piece: K1's tiles come first
+    const int c = g - a.Gk;
+    w.c_lo = w.lo + (int64_t)c * chunk;
     w.c_hi = w.c_lo + chunk < w.hi ? w.c_lo + chunk : w.hi;
     if (w.c_lo > w.hi) w.c_lo = w.c_hi = w.hi;
     return w;
@@ -137,7 +148,7 @@ __host__ __device__ __forceinline__ int64_t seg_stride(int64_t n, int G) { retur
 // host only knows an upper bound of the window, the kernels read its size --, 2 = always)?  The same answer in every kernel.
 __device__ __forceinline__ bool bev_split(const BevArgs &a, int64_t window_points)
 {
-    return a.split == 2 || (a.split == 1 && window_points <= (int64_t)a.G * BIN_REG_P * AB_THREADS);
+    return a.split == 2 || (a.split == 1 && window_points <= (int64_t)(a.G - a.Gk) * BIN_REG_P * AB_THREADS);
 }
 __device__ __forceinline__ int table_pos(const BevArgs &a, int g) { return a.Gp ? (g & 7) * a.Gp + (g >> 3) : g; }
 __device__ __forceinline__ int table_group(const BevArgs &a, int p)
@@ -306,6 +317,47 @@ __device__ __forceinline__ uint32_t view_key_lean(const ViewConst &c, double X, 
 // (giant windows) takes the memory path: keys to the key buffer, re-read with z / intensity / colour in pass B.
 __device__ unsigned long long g_dbg_stamps[1024][8];   // PCA_BEV_DBG=8|16|32: per-tile / per-chunk phase stamps (diagnostics)
 #define BIN_STAMP(slot) do { if ((a.dbg & 32) && threadIdx.x == 0 && blockIdx.x < 1024) g_dbg_stamps[blockIdx.x][slot] = wall_clock64(); } while (0)
+// exclusive scan of a level-1 workgroup's histogram over the tiles (thread t owns `per` consecutive tiles): LDS cursors and the
+// workgroup's column of the tile-major tables.  All AB_THREADS threads; one barrier inside.
+__device__ __forceinline__ void bin_scan_tables(const BevArgs &a, const uint32_t *s_h, uint32_t *s_cur, uint32_t *s_wsum, bool split, int g)
+{
+{
+    const int per = (a.T + AB_THREADS - 1) / AB_THREADS;
+    const int t0 = threadIdx.x * per;
+    const int gp = table_pos(a, g);
+    uint32_t sum = 0;
+    if (split) { for (int k = 0; k < per; ++k) sum += t0 + k < a.T ? s_h[2 * (t0 + k)] + s_h[2 * (t0 + k) + 1] : 0u; }
+    else { for (int k = 0; k < per; ++k) sum += t0 + k < a.T ? s_h[t0 + k] : 0u; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan_add(sum);
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int k = 0; k < wave; ++k) before += s_wsum[k];
+    uint32_t run = before + inc - sum;
+    for (int k = 0; k < per; ++k) {
+        const int t = t0 + k;
+        if (t >= a.T) break;
+        // tile-major tables [tile][place of the workgroup]: a tile's workgroup of level 2 reads its counters as one range
+        if (split) {                                    // the piece = the tile's first half, then its second
+            const uint32_t c0 = s_h[2 * t], c1 = s_h[2 * t + 1];
+            s_cur[2 * t] = run;
+            s_cur[2 * t + 1] = run + c0;
+            a.bh[(int64_t)t * a.Gr + gp] = c0 + c1;
+            a.boff[(int64_t)t * a.Gr + gp] = run;
+            a.bh0[(int64_t)t * a.Gr + gp] = c0;
+            run += c0 + c1;
+        } else {
+            const uint32_t c = s_h[t];
+            s_cur[t] = run;
+            a.bh[(int64_t)t * a.Gr + gp] = c;
+            a.boff[(int64_t)t * a.Gr + gp] = run;
+            run += c;
+        }
+    }
+}
+}
+
 template <bool I64>
 __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
 {
@@ -324,14 +376,16 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     BIN_STAMP(0);
     int g;                                                  // this workgroup's chunk
     const Window w = chunk_of(a, g);
-    const int64_t chunk = seg_stride(w.hi - w.lo, a.G);
+    const int64_t chunk = seg_stride(w.hi - w.lo, a.G - a.Gk);
     // split: one histogram entry and one cursor per (tile, half of its cells): key >> 6 = tile << 1 | cell >> 5
     const bool split = bev_split(a, w.hi - w.lo);
     const int hs = split ? 6 : 7;
     const int n_hist = split ? 2 * a.T : a.T;
     uint32_t *s_cur = s_lds + n_hist;
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0 && a.frame_off[a.slot_end] - w.lo > a.max_points) pca_raise(a.status, PCA_STATUS_STORE_OVERFLOW);
+    if ((int)blockIdx.x == a.Gk) {                          // (the first workgroup that reads the store)
+        // (with a K1 in the launch the window's end is not written yet: its input points bound it)
+        const int64_t end_ub = a.Gk ? a.frame_off[a.k1_slot] + a.k1_n : a.frame_off[a.slot_end];
+        if (threadIdx.x == 0 && end_ub - w.lo > a.max_points) pca_raise(a.status, PCA_STATUS_STORE_OVERFLOW);
         if (threadIdx.x < HQ_IDS) a.heavy[threadIdx.x] = 0;  // the heavy queue of this call starts empty
     }
     for (int t = threadIdx.x; t < n_hist; t += AB_THREADS) s_h[t] = 0;
@@ -465,46 +519,11 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     }
     __syncthreads();
     BIN_STAMP(2);
-    // ---- exclusive scan of the histogram: thread t owns `per` consecutive tiles ----
-    {
-        const int per = (a.T + AB_THREADS - 1) / AB_THREADS;
-        const int t0 = threadIdx.x * per;
-        const int gp = table_pos(a, g);
-        uint32_t sum = 0;
-        if (split) { for (int k = 0; k < per; ++k) sum += t0 + k < a.T ? s_h[2 * (t0 + k)] + s_h[2 * (t0 + k) + 1] : 0u; }
-        else { for (int k = 0; k < per; ++k) sum += t0 + k < a.T ? s_h[t0 + k] : 0u; }
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const uint32_t inc = wave_incl_scan_add(sum);
-        if (lane == 63) s_wsum[wave] = inc;
-        __syncthreads();
-        uint32_t before = 0;
-        for (int k = 0; k < wave; ++k) before += s_wsum[k];
-        uint32_t run = before + inc - sum;
-        for (int k = 0; k < per; ++k) {
-            const int t = t0 + k;
-            if (t >= a.T) break;
-            // tile-major tables [tile][place of the workgroup]: a tile's workgroup of level 2 reads its counters as one range
-            if (split) {                                    // the piece = the tile's first half, then its second
-                const uint32_t c0 = s_h[2 * t], c1 = s_h[2 * t + 1];
-                s_cur[2 * t] = run;
-                s_cur[2 * t + 1] = run + c0;
-                a.bh[(int64_t)t * a.Gr + gp] = c0 + c1;
-                a.boff[(int64_t)t * a.Gr + gp] = run;
-                a.bh0[(int64_t)t * a.Gr + gp] = c0;
-                run += c0 + c1;
-            } else {
-                const uint32_t c = s_h[t];
-                s_cur[t] = run;
-                a.bh[(int64_t)t * a.Gr + gp] = c;
-                a.boff[(int64_t)t * a.Gr + gp] = run;
-                run += c;
-            }
-        }
-    }
+    bin_scan_tables(a, s_h, s_cur, s_wsum, split, g);
     __syncthreads();
     BIN_STAMP(3);
     // ---- pass B: the chunk's records into its segment, tile by tile ----
-    const uint32_t seg = (uint32_t)((int64_t)g * chunk);
+    const uint32_t seg = (uint32_t)((int64_t)a.Gk * K1_SEG + (int64_t)(g - a.Gk) * chunk);
     if (REG_P > 0 && n_reg > 0) {
         // colour and intensity of the kept points: all of a lane's gathers issued back to back, before the first is used
         // (a point outside the view re-reads the chunk's first point: no branch around a load).  Issuing them before the
@@ -605,17 +624,17 @@ __device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, in
                 if (half >= 0) c0[k] = a.bh0[(int64_t)tile * a.Gr + g0 + k];     // (uniform; read before it is known to be valid: never used then)
             }
         }
-    const int64_t lo = a.frame_off[a.slot_begin], hi0 = a.frame_off[a.slot_end];
+    const int64_t lo = a.frame_off[a.slot_begin], hi0 = window_end(a);
     const int64_t n = hi0 - lo > a.max_points ? a.max_points : hi0 - lo;
     if (half >= 0 && bev_split(a, n)) {                     // (uniform) the item's own half of every piece
 #pragma unroll
         for (int k = 0; k < 4; ++k) { if (half == 0) c[k] = c0[k]; else { o[k] += c0[k]; c[k] -= c0[k]; } }
     }
-    const uint32_t chunk = (uint32_t)seg_stride(n, a.G);
+    const uint32_t chunk = (uint32_t)seg_stride(n, a.G - a.Gk);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (k < per && g0 + k < a.Gr) {
-            M.base[g0 + k] = (uint32_t)grp[k] * chunk + o[k];
+            M.base[g0 + k] = (grp[k] < a.Gk ? (uint32_t)grp[k] * K1_SEG : (uint32_t)a.Gk * K1_SEG + (uint32_t)(grp[k] - a.Gk) * chunk) + o[k];
             sum += c[k];
         }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1476,7 +1495,7 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
     // 2 x 16 B read per record of a heavy tile, 3.2 GB for 1.6 GB of records on BASELINE config 4)
     bool own = false;                                       // (uniform) OWN: compiled for it; in effect if this window's pieces are ordered
     if (OWN) {
-        const int64_t wn = a.frame_off[a.slot_end] - a.frame_off[a.slot_begin];
+        const int64_t wn = window_end(a) - a.frame_off[a.slot_begin];      // (what level 1 decided on)
         own = bev_split(a, wn > a.max_points ? a.max_points : wn);
     }
     const uint32_t r_lo = 0, r_hi = recmap_build(L.M, a, tile, H_THREADS, nullptr, OWN ? half : -1);
@@ -1557,6 +1576,60 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
     }
 }
 
+// ---- level 1 with the K1 of the newest frame in the same launch (pca_kitti_integrate deferred it: pca_common.h, K1Pending) ----
+// Workgroups [0, Gk) are K1's tiles (k1_body, FUSED form, 1024 x 4): project / sample / filter / compact, look-back among
+// themselves, append to the store, close the frame -- and then bin the points they kept straight out of their registers: same
+// key, same record as level 1 would make of them after reading them back (f32 -> f64 is exact; the newest frame owes no
+// re-transform; dyn = 0), into piece g = the workgroup's number.  Workgroups [Gk, G) are level 1 over the window up to that frame.
+struct BinK1Tail {
+    const BevArgs &a;
+    template <int PPT>
+    __device__ __forceinline__ void operator()(const float4 (&p)[PPT], const uint32_t (&packed)[PPT], const uint64_t (&km)[PPT]) const
+    {
+        extern __shared__ uint32_t s_lds[];
+        __shared__ uint32_t s_wsum[AB_THREADS / 64];
+        __shared__ uint32_t s_dyn[8];
+        const int64_t lo = a.frame_off[a.slot_begin], hi0 = window_end(a);
+        const bool split = bev_split(a, hi0 - lo > a.max_points ? a.max_points : hi0 - lo);
+        const int hs = split ? 6 : 7, n_hist = split ? 2 * a.T : a.T;
+        uint32_t *s_h = s_lds, *s_cur = s_lds + n_hist;
+        if (threadIdx.x < 8) {
+            uint32_t w = (uint32_t)a.prm.dynobj_mask[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) w = (int)threadIdx.x == i ? (uint32_t)(a.prm.dynobj_mask[i >> 1] >> (32 * (i & 1))) : w;
+            s_dyn[threadIdx.x] = w;
+        }
+        for (int t = threadIdx.x; t < n_hist; t += AB_THREADS) s_h[t] = 0;
+        __syncthreads();
+        const ViewConst vc = view_const(a);
+        const uint32_t set = a.k1_slot >= a.slot_split ? 1u : 0u;
+        const int lane = threadIdx.x & 63;
+        uint32_t rkey[PPT];
+#pragma unroll
+        for (int r = 0; r < PPT; ++r) {
+            const bool kept = (km[r] >> lane) & 1ull;
+            rkey[r] = view_key_lean(vc, (double)p[r].x, (double)p[r].y, (double)p[r].z, kept, set);
+            if (rkey[r] != KEY_INVALID) atomicAdd(&s_h[rkey[r] >> hs], 1u);
+        }
+        __syncthreads();
+        bin_scan_tables(a, s_h, s_cur, s_wsum, split, (int)blockIdx.x);
+        __syncthreads();
+        const uint32_t seg = (uint32_t)blockIdx.x * K1_SEG;
+#pragma unroll
+        for (int r = 0; r < PPT; ++r) {
+            if (rkey[r] == KEY_INVALID) continue;
+            const uint32_t pos = seg + atomicAdd(&s_cur[rkey[r] >> hs], 1u);
+            bin_store<false>(a, s_dyn, pos, rkey[r], packed[r], (double)p[r].z, 0.0, p[r].w);
+        }
+    }
+};
+static_assert(K1_SEG == 1024 * 4, "a K1 piece holds one 1024 x 4 tile");
+__global__ __launch_bounds__(AB_THREADS) __attribute__((amdgpu_waves_per_eu(BIN_WPE, BIN_WPE))) void bev_tile_bin_k1(const BevArgs a, const K1Args k)
+{
+    if ((int)blockIdx.x < a.Gk) k1_body<AB_THREADS, 4, false, false, false>(k, BinK1Tail{a});
+    else bev_tile_bin_body<false>(a);
+}
+
 // ---- the kernels: one sample per launch (arguments in the kernel-argument segment), or many (pca_bev_generate_many:
 // blockIdx.y = sample, its arguments read from a device array -- a NuScenes-size window is 108 level-1 workgroups and
 // three dependent launches of pure latency; S samples in one launch of each kernel take little longer than one) ----
@@ -1596,6 +1669,8 @@ __global__ __launch_bounds__(H_THREADS) void bev_tile_cells_heavy_many()
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+int pca_k1_prepare_pending(pca_ctx *ctx, K1Args *out, int *n_tiles, hipStream_t s);    // pca_k1.hip
+void pca_k1_pending_launched(pca_ctx *ctx, hipStream_t s);
 static inline int64_t align256(int64_t v) { return (v + 255) & ~255ll; }
 static inline int tiles_x(int px) { return (px + TS - 1) / TS; }
 static inline int n_groups(int64_t max_points)
@@ -1616,8 +1691,8 @@ int64_t pca_bev_workspace_bytes(int64_t max_points, int px)
 {
     if (max_points < 1) max_points = 1;
     const int64_t T = (int64_t)tiles_x(px) * tiles_x(px), G = n_groups(max_points);
-    return align256(max_points * 4) + 3 * align256((G + 8) * T * 4) + align256((HQ_IDS + HQ_CLASSES * T) * 4) +
-           align256((max_points + G) * 24) + 512;
+    return align256(max_points * 4) + 3 * align256((G + K1_RIDE + 8) * T * 4) + align256((HQ_IDS + HQ_CLASSES * T) * 4) +
+           align256((max_points + G + K1_RIDE + K1_SEG) * 24) + 512;
 }
 
 int pca_bev_generate(pca_ctx *ctx, const pca_store *store, const double *intensity64, const int64_t *frame_off,
@@ -1641,6 +1716,13 @@ int pca_bev_generate_ex(pca_ctx *ctx, const pca_store *store, const double *inte
 }
 
 // Checks one raster's arguments and fills the kernels' argument block (everything but the heavy-tile bookkeeping)
+static void bev_table_order(BevArgs &a)
+{   // PCA_BEV_XCD_TABLES=0: the counter tables in plain [tile][workgroup] order (A/B)
+    static int xt = -1;
+    if (xt < 0) { const char *e = getenv("PCA_BEV_XCD_TABLES"); xt = e ? atoi(e) : 1; }
+    a.Gp = (xt && a.G >= 16 && a.G <= 1016) ? (a.G + 7) / 8 : 0;   // (RecMap holds 1024 places)
+    a.Gr = a.Gp ? 8 * a.Gp : a.G;
+}
 static int bev_prepare(pca_ctx *ctx, const pca_store *store, const double *intensity64, const int64_t *frame_off,
                        int slot_begin, int slot_split, int slot_end, int64_t max_points, const pca_bev_params *prm,
                        const double *pending_Ts, const int *pending_slot_ends, int n_pending, int write_back,
@@ -1681,18 +1763,14 @@ static int bev_prepare(pca_ctx *ctx, const pca_store *store, const double *inten
     a.tx = tiles_x(prm->px);
     a.T = a.tx * a.tx;
     a.G = n_groups(max_points);
-    {   // PCA_BEV_XCD_TABLES=0: the counter tables in plain [tile][workgroup] order (A/B)
-        static int xt = -1;
-        if (xt < 0) { const char *e = getenv("PCA_BEV_XCD_TABLES"); xt = e ? atoi(e) : 1; }
-        a.Gp = (xt && a.G >= 16 && a.G <= 1016) ? (a.G + 7) / 8 : 0;   // (RecMap holds 1024 places)
-        a.Gr = a.Gp ? 8 * a.Gp : a.G;
-    }
+    bev_table_order(a);
     char *w = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     a.key = reinterpret_cast<uint32_t *>(w); w += align256(max_points * 4);
-    a.bh = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.G + 8) * a.T * 4);
-    a.boff = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.G + 8) * a.T * 4);
-    a.bh0 = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.G + 8) * a.T * 4);
+    a.bh = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.G + K1_RIDE + 8) * a.T * 4);
+    a.boff = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.G + K1_RIDE + 8) * a.T * 4);
+    a.bh0 = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.G + K1_RIDE + 8) * a.T * 4);
     a.split = 0;
+    a.Gk = 0; a.k1_slot = -1; a.k1_n = 0;
     a.heavy = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(HQ_IDS + HQ_CLASSES * (int64_t)a.T) * 4);
     a.recs = w;
     a.planes = planes;
@@ -1725,6 +1803,7 @@ static int bev_set_lds_attributes(pca_ctx *ctx)
 #undef PCA_BEV_HEAVY_ATTR
     PCA_BEV_LDS_ATTR(bev_tile_cells_heavy_many<false>, HEAVY_LDS_BYTES);
     PCA_BEV_LDS_ATTR(bev_tile_cells_heavy_many<true>, HEAVY_LDS_BYTES);
+    PCA_BEV_LDS_ATTR(bev_tile_bin_k1, 80 * 1024);
     PCA_BEV_LDS_ATTR(bev_tile_bin<false>, 128 * 1024);
     PCA_BEV_LDS_ATTR(bev_tile_bin<true>, 128 * 1024);
     PCA_BEV_LDS_ATTR(bev_tile_bin_many<false>, 128 * 1024);
@@ -1771,6 +1850,24 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
     { static int sp = -1; if (sp < 0) { const char *e = getenv("PCA_BEV_SPLIT"); sp = e ? atoi(e) : 1; }
       a.split = (sp && a.heavy_launched && !intensity64 && (size_t)a.T * 16 <= 128 * 1024) ? (sp == 2 ? 2 : 1) : 0; }
     const size_t lds = (size_t)a.T * 8 * (a.split ? 2 : 1);  // bev_tile_bin: histogram + cursors
+    // A K1 that pca_kitti_integrate left for this raster (the window's last frame, same store, same stream) rides in level 1's
+    // launch as its first workgroups; any other deferred K1 runs now, on its own.  PCA_FUSE_K1=0: always on its own (A/B).
+    bool fuse = false;
+    K1Args k1a;
+    if (ctx->k1_pend.valid) {
+        static int fk = -1;
+        if (fk < 0) { const char *e = getenv("PCA_FUSE_K1"); fk = e ? atoi(e) : 1; }
+        const pca_ctx::K1Pending &pd = ctx->k1_pend;
+        int nt = 0;
+        bool owed_ok = true;                                // (a transform owed by the riding frame itself: its end is not written yet)
+        for (int k = 0; k < n_pending; ++k) owed_ok = owed_ok && pending_slot_ends[k] <= pd.slot;
+        fuse = fk && owed_ok && !intensity64 && pd.stream == s && pd.slot == slot_end - 1 && pd.slot >= slot_begin && pd.frame_off == frame_off &&
+               pd.store.x == store->x && lds <= 80 * 1024 && pd.fr.n <= K1_RIDE * K1_SEG &&
+               pca_k1_prepare_pending(ctx, &k1a, &nt, s) == 0 && nt <= K1_RIDE;
+        // K1's tiles are pieces 0 .. nt-1, the window's G pieces follow (the workspace is sized for G + K1_RIDE)
+        if (fuse) { a.Gk = nt; a.G += nt; bev_table_order(a); a.k1_slot = pd.slot; a.k1_n = pd.fr.n; }
+        else if (pca_k1_flush_pending(ctx)) return -1;
+    }
     if (ctx->profiling == 2) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
     // (Running the two tile kernels side by side was tried: a second stream with fork / join events costs ~20 us per
     // call, and hipExtAnyOrderLaunch is not honoured on gfx9 -- see DESIGN.md.)
@@ -1785,7 +1882,12 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
         PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_tile_cells<true>, dim3(a.T), dim3(C_THREADS), s, a);
         if (a.heavy_launched) PCA_BEV_HEAVY_PICK(true);
     } else {
-        PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_bin<false>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
+        if (fuse) {
+            PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_bin_k1, dim3(a.G), dim3(AB_THREADS), lds, s, a, k1a);
+            pca_k1_pending_launched(ctx, s);
+        } else {
+            PCA_LAUNCH_SHM(ctx, PCA_K_BEV_BIN, bev_tile_bin<false>, dim3(a.G), dim3(AB_THREADS), lds, s, a);
+        }
         PCA_LAUNCH(ctx, PCA_K_BEV_CELLS, bev_tile_cells<false>, dim3(a.T), dim3(C_THREADS), s, a);
         if (a.heavy_launched) PCA_BEV_HEAVY_PICK(false);
     }
@@ -1805,6 +1907,7 @@ int pca_bev_generate_many(pca_ctx *ctx, const pca_store *store, const double *in
                           int64_t workspace_bytes, void *stream)
 {
     if (!ctx) return -1;
+    if (pca_k1_flush_pending(ctx)) return -1;               // a deferred K1 of this context comes first
     if (!jobs || n_jobs < 1) { ctx->err = "bev: bad job list"; return -1; }
     if (n_jobs > 65535) { ctx->err = "bev: at most 65535 rasters per call"; return -1; }
     if (max_points < 1) max_points = 1;

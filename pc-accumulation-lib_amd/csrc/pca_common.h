@@ -84,6 +84,24 @@ struct pca_ctx {
     double *icp_host = nullptr;       // pinned + mapped [32]: T, fitness, rmse, iterations, flag; [31] = (call << 8 | pass) tag
     double *icp_host_dev = nullptr;
     uint32_t icp_call = 0;
+    // K1 deferred into the next raster (round 5): pca_kitti_integrate leaves the frame's K1 here when the mode is on; the next
+    // pca_bev_generate_chain on this context whose window ends with that frame runs it INSIDE level 1's launch (K1 alone is a
+    // 9 us latency-bound launch of 118 small workgroups in front of a 55 us kernel; as 30 of level 1's 512 workgroups it costs
+    // ~1.5 us); every other entry point that touches a store runs it first, on its own (pca_k1_flush_pending).
+    struct K1Pending {
+        bool valid = false;
+        pca_kitti_frame fr;
+        double P[12];
+        int H = 0, W = 0;
+        uint64_t filt[4] = {0, 0, 0, 0};
+        pca_store store;
+        int64_t *frame_off = nullptr;
+        int slot = 0, sample_mode = 0;
+        hipStream_t stream = nullptr;
+        int stage_idx = -1;           // the staging block K1 reads (its `done` event is recorded behind the K1 that does), or -1
+    };
+    bool k1_defer = false;
+    K1Pending k1_pend;
     uint32_t *status_host = nullptr;  // pinned
     uint32_t *heavy_hint = nullptr;   // pinned, device-visible: heavy-tile count of the latest rasteriser call
     uint32_t *heavy_hint_dev = nullptr;
@@ -117,6 +135,9 @@ void pca_prof_end(pca_ctx *ctx, hipStream_t s);
         }                                                                                      \
     } while (0)
 
+// internal (pca_k1.hip): runs a deferred K1 now, on its own (no-op without one).  Every entry point that reads or writes a
+// store, frame_off or the status word calls it first.
+int pca_k1_flush_pending(pca_ctx *ctx);
 // internal (pca_api.hip)
 // Small argument blocks (frame descriptors, raster parameters: a few KB) from MAPPED host memory into device memory by a
 // KERNEL that reads the host block over PCIe: a copy command of that size costs 13-17 us on this stack (measured as the gap

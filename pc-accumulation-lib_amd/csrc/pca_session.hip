@@ -28,6 +28,7 @@ int pca_kitti_integrate(pca_ctx *ctx, const pca_kitti_obs *obs, const double P[1
     if (track && (!T_new_prev || !evicted || !path_length)) { ctx->err = "kitti_integrate: the pose track needs T_new_prev and its outputs"; return -1; }
     hipStream_t s = (hipStream_t)stream;
     PCA_CHECK(ctx, hipSetDevice(ctx->device));
+    if (pca_k1_flush_pending(ctx)) return -1;               // the frame before this one, if its K1 is still owed
     const void *in[4] = {obs->pts, obs->rgb, obs->sem, obs->sem_gt};
     const int64_t size[4] = {16ll * obs->n, 3ll * H * W, 1ll * H * W, 1ll * obs->n};
     const void *dev[4] = {in[0], in[1], in[2], in[3]};
@@ -83,18 +84,33 @@ int pca_kitti_integrate(pca_ctx *ctx, const pca_kitti_obs *obs, const double P[1
     pca_kitti_frame fr;
     fr.pts = (const float *)dev[0]; fr.rgb = (const uint8_t *)dev[1]; fr.sem = (const uint8_t *)dev[2];
     fr.sem_gt = (const uint8_t *)dev[3]; fr.n = obs->n; fr.reserved = 0;
-    const int rc = pca_kitti_project_sample_filter_ex(ctx, &fr, 1, P, H, W, filter_mask, store, frame_off, slot, sample_mode, stream);
-    if (slot_st) {                                         // the blocks are free again once K1 has read them
-        const hipError_t e = hipEventRecord(slot_st->done, s);
-        if (e == hipSuccess) slot_st->busy = true;
-        else {
-            // no event to wait for: the block must not be staged into again while K1 may still read it -- wait here, once,
-            // and say what happened
-            (void)hipStreamSynchronize(s);
-            if (rc == 0) { ctx->err = std::string("kitti_integrate: hipEventRecord(stage done): ") + hipGetErrorString(e); return -1; }
+    // Deferred (pca_k1_defer): K1 is left for the next raster of this context, which runs it inside level 1's launch -- or for
+    // whoever touches a store first (pca_k1_flush_pending).  Only the plain case: points there, nearest sampling, a real image.
+    const bool plain = obs->n > 0 && sample_mode == PCA_SAMPLE_NEAREST && (fr.sem_gt || ((int64_t)H * W * 3 >= 4 && fr.rgb && fr.sem)) &&
+                       obs->n <= (1 << 20);
+    if (ctx->k1_defer && plain) {
+        pca_ctx::K1Pending &pd = ctx->k1_pend;
+        pd.fr = fr;
+        for (int i = 0; i < 12; ++i) pd.P[i] = P[i];
+        pd.H = H; pd.W = W;
+        for (int i = 0; i < 4; ++i) pd.filt[i] = filter_mask[i];
+        pd.store = *store; pd.frame_off = frame_off; pd.slot = slot; pd.sample_mode = sample_mode; pd.stream = s;
+        pd.stage_idx = slot_st ? (int)(slot_st - ctx->stage) : -1;
+        pd.valid = true;
+    } else {
+        const int rc = pca_kitti_project_sample_filter_ex(ctx, &fr, 1, P, H, W, filter_mask, store, frame_off, slot, sample_mode, stream);
+        if (slot_st) {                                     // the blocks are free again once K1 has read them
+            const hipError_t e = hipEventRecord(slot_st->done, s);
+            if (e == hipSuccess) slot_st->busy = true;
+            else {
+                // no event to wait for: the block must not be staged into again while K1 may still read it -- wait here, once,
+                // and say what happened
+                (void)hipStreamSynchronize(s);
+                if (rc == 0) { ctx->err = std::string("kitti_integrate: hipEventRecord(stage done): ") + hipGetErrorString(e); return -1; }
+            }
         }
+        if (rc != 0) return rc;
     }
-    if (rc != 0) return rc;
     if (track) *evicted = pca_host_track_step(track, T_new_prev, horizon, path_length);
     return 0;
 }

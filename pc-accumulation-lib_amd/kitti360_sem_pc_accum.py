@@ -30,6 +30,9 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         self._cobs = None                # the observation as the library takes it (reused)
         import os
         self._fast = os.environ.get('PCA_FAST_CALLS', '1') != '0'      # one library call per driver call (0: the general path)
+        # K1 of integrate() left for the generate_bev() that follows it (it rides in the raster's first kernel: pca_k1_defer);
+        # 0: K1 runs inside integrate()
+        self._defer_k1 = self._fast and os.environ.get('PCA_FUSE_K1', '1') != '0'
         self._prev_sweep = None
         self._sweep_dev = None           # (host sweep, its device copy) of the frame the device ICP has just registered
         self.pose_provider = self._default_pose_provider()
@@ -227,8 +230,10 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
             # ONE library call: staging + upload of the host arrays, K1, and the pose bookkeeping of the frame (update_poses,
             # the new pose [0,0,0], the newest path segment, the horizon eviction: sem_pc_accum.py:156-228)
             obs, semseg, H, W, keep = fast
+            if self._defer_k1 != getattr(self.store.ctx, 'k1_defer', False):
+                self.store.set_defer_k1(self._defer_k1)
             idx, path_length = self.store.append_kitti_obs(obs, self.P_velo_frame, H, W, self.semseg_filters, self.sample_mode,
-                                                           self._track, T_new_prev, self.horizon_dist)
+                                                           self._track, T_new_prev, self.horizon_dist, keep=keep)
             del keep
             if idx is None:                # a numpy pose track: its step stays here
                 idx, path_length = self._track.step(T_new_prev, self.horizon_dist)

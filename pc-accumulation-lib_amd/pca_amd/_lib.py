@@ -26,7 +26,7 @@ EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error',
            'pca_host_track_poses', 'pca_host_track_segments', 'pca_host_track_set', 'pca_host_track_transform',
            'pca_host_track_append', 'pca_host_track_push_segment', 'pca_host_track_incr', 'pca_host_track_evict_beyond',
            'pca_host_track_step', 'pca_host_track_trigger', 'pca_host_stage_h2d', 'pca_host_d2h_async', 'pca_host_d2h_wait',
-           'pca_kitti_integrate', 'pca_kitti_generate_bev',
+           'pca_kitti_integrate', 'pca_kitti_generate_bev', 'pca_k1_defer', 'pca_k1_flush',
            'pca_profile_enable', 'pca_profile_read')
 
 KERNEL_IDS = ('kitti_project_sample_filter', 'nusc_sample_filter_transform', 'nusc_project_cams', 'retransform',
@@ -195,6 +195,8 @@ def load():
                                         C.POINTER(C.c_double), vp]
     lib.pca_kitti_generate_bev.argtypes = [vp, C.POINTER(PcaStore), vp, i32, i32, i32, i64, C.POINTER(PcaBevParams), vp, vp,
                                            i32, i32, vp, i64, vp, vp, vp, vp, vp, C.POINTER(C.c_int32), vp]
+    lib.pca_k1_defer.argtypes = [vp, i32]
+    lib.pca_k1_flush.argtypes = [vp]
     lib.pca_profile_enable.argtypes = [vp, i32]
     lib.pca_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = lib

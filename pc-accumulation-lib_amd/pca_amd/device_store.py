@@ -46,6 +46,7 @@ class DeviceStore:
         self._ws_points, self._ws_px = 0, 0
         self._dedup_ws = None
         self._obs_out = None
+        self._k1_noted = None    # what the K1 noted by the last append_kitti_obs still reads (device tensors), or None
         self._pend_T = (C.c_double * (16 * self.CHAIN_MAX))()      # the owed chain as the C calls take it
         self._pend_T_np = np.frombuffer(self._pend_T, dtype=np.float64)
         self._pend_ends = (C.c_int * self.CHAIN_MAX)()
@@ -76,8 +77,24 @@ class DeviceStore:
     def n_frames(self):
         return self.tail - self.head
 
+    def set_defer_k1(self, on):
+        """pca_k1_defer for this store's context: the K1 of append_kitti_obs is left for the raster that follows it (it rides in
+        that raster's first kernel; see include/pca.h).  Every library call that touches a store runs a noted K1 first; the
+        methods of this class that read the arrays with torch (offsets, rows, reserve, ...) call flush_k1() themselves.  Code
+        that reads self.x ... self.frame_off directly must call flush_k1() first."""
+        self.ctx.check(self.ctx.lib.pca_k1_defer(self.ctx.h, 1 if on else 0))
+        self.ctx.k1_defer = bool(on)              # (the switch belongs to the context: every store on it sees it)
+        if not on:
+            self._k1_noted = None
+
+    def flush_k1(self):
+        if self._k1_noted is not None:
+            self.ctx.check(self.ctx.lib.pca_k1_flush(self.ctx.h))
+            self._k1_noted = None
+
     def offsets(self):
         """Exact segment boundaries of the live frames (host numpy int64, length n_frames+1).  Synchronises."""
+        self.flush_k1()
         off = self.frame_off[self.head:self.tail + 1].cpu().numpy()
         self.lb_head = int(off[0])
         self.ub_tail = int(off[-1])
@@ -133,6 +150,7 @@ class DeviceStore:
         return max(self._ub_sum, 1)
 
     def clear(self):
+        self.flush_k1()
         self.head = self.tail = 0
         self.ub_tail = self.lb_head = 0
         self._ub = []
@@ -179,11 +197,12 @@ class DeviceStore:
         self._ub += [int(f['pts'].shape[0]) for f in frames]
         self._ub_sum += n_in
 
-    def append_kitti_obs(self, obs, P, H, W, filters, sample_mode='nearest', track=None, T_new_prev=None, horizon=0.):
+    def append_kitti_obs(self, obs, P, H, W, filters, sample_mode='nearest', track=None, T_new_prev=None, horizon=0., keep=None):
         """One observation through pca_kitti_integrate: `obs` is a _lib.PcaKittiObs whose pointers are device pointers or --
         where its host_mask says so -- host arrays (staged by the library: one pinned block, one H2D copy).  With `track` (a
         host_logic.CPoseTrack) the pose bookkeeping of the frame happens in the same call: returns (evicted frames, path
-        length | None); without, (None, None) and the caller steps its own track.  The caller evicts."""
+        length | None); without, (None, None) and the caller steps its own track.  The caller evicts.
+        keep: the objects behind the struct's device pointers; with set_defer_k1 they are held until the noted K1 has run."""
         lib, ctx = self.ctx.lib, self.ctx
         n = int(obs.n)
         self.reserve(n, 1)
@@ -203,6 +222,7 @@ class DeviceStore:
                                           self.frame_off.data_ptr(), self.tail, _lib.SAMPLE_MODES[sample_mode], th,
                                           None if Tc is None else Tc.ctypes.data, float(horizon), C.byref(ev), C.byref(pl),
                                           ctx.stream()))
+        self._k1_noted = (keep, ) if getattr(ctx, 'k1_defer', False) else None      # (the K1 noted by the call before has run by now)
         self.tail += 1
         self.ub_tail += n
         self._ub.append(n)

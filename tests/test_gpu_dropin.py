@@ -1433,3 +1433,108 @@ def test_one_call_integrate_edge_cases():
         accs[0].integrate([(big, rng.uniform(1, 9, (10, 3)).astype(np.float32), None)])          # (N,3) points
     assert accs[0].store.n_frames == n_before and len(accs[0].poses) == n_before
     accs[0].store.check_status()
+
+
+def test_k1_riding_in_the_raster_equals_k1_on_its_own():
+    """integrate() notes its K1 and the generate_bev() that follows runs it as the first workgroups of the raster's first kernel
+    (pca_k1_defer; `_defer_k1 = False`: K1 is a launch of its own inside integrate()).  Same planes, stored rows, offsets and
+    polylines, step for step, on full-size frames (30 K1 tiles riding along) and at the edges: a frame of which nothing is
+    kept, a one-point frame, two integrate() in a row (the first K1 runs on its own), reading the store between integrate()
+    and generate_bev() (the noted K1 runs first), host and device inputs, the image path and the per-point-label path."""
+    import torch
+
+    import sem_pc_accum
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    from pca_amd import _lib
+    H, W, N = 376, 1408, 120_000
+    cam_to_velo = np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418],
+                            [-0.999004371, 0.007784614041, 0.04392796942, 0.2993489574],
+                            [-0.01162548558, -0.9960641394, -0.08786966659, -0.1770225824], [0, 0, 0, 1]])
+    P = np.array([[552.554261, 0, 682.049453, 0], [0, 552.554261, 238.769549, 0], [0, 0, 1, 0]]) @ np.linalg.inv(cam_to_velo)
+    rng = np.random.default_rng(77)
+
+    def frame(n, spread=60.):
+        pc = np.stack([rng.uniform(-spread, spread, n), rng.uniform(-spread, spread, n), rng.uniform(-2, 3, n),
+                       rng.uniform(0, 1, n)], 1).astype(np.float32)
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        sem = rng.integers(0, 19, (H, W)).astype(np.uint8)
+        sem[rng.random((H, W)) < 0.01] = 255
+        return pc, img, sem
+    frames = [frame(N) for _ in range(3)]
+    frames.append(frame(1))                                               # one point
+    behind = frame(5000)
+    behind[0][:, 0] = -np.abs(behind[0][:, 0]) - 1.0                      # everything behind the camera: nothing kept
+    frames.append(behind)
+    frames.append(frame(70_000, 20.))                                     # dense near the sensor: most of it in view
+    dev = [(torch.from_numpy(i).cuda(), torch.from_numpy(p).cuda(), torch.from_numpy(s).cuda()) for p, i, s in frames]
+    by_ptr = {d[0].data_ptr(): d[2] for d in dev}
+    by_id = {}
+
+    class Resident:
+        def pred(self, rgb):
+            if isinstance(rgb, torch.Tensor):
+                return by_ptr[rgb.data_ptr()][None, None]
+            return by_id[id(rgb)][None, None]
+    for (p, i, s) in frames:
+        by_id[id(i)] = s
+    sem_pc_accum.SemSegONNX = lambda path: Resident()
+    a = -0.004
+    T = np.array([[np.cos(a), -np.sin(a), 0, 0], [np.sin(a), np.cos(a), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.]]) @ \
+        np.array([[1, 0, 0, -1.0], [0, 1, 0, 0.01], [0, 0, 1, 0.002], [0, 0, 0, 1.]])
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': P}
+    ctx = _lib.Context.get()
+    for use_gt in (False, True):
+        accs = []
+        for defer in (True, False):
+            acc = Kitti360SemanticPointCloudAccumulator(40., calib, 1e3, 'resident', KITTI_FILTERS, SEM_IDXS, use_gt,
+                                                        dict(BEV_KITTI, view_size=80, pixel_size=256))
+            acc._store_args = dict(capacity=1 << 22, max_frames=64)
+            acc.pose_provider = lambda pc: T
+            assert acc._defer_k1                                             # the default
+            acc._defer_k1 = defer
+            accs.append(acc)
+        order = [0, 1, 2, 0, 3, 1, 4, 2, 5, 0, 1, 5, 2, 4, 4, 0, 1, 2, 0, 1, 2, 5, 0, 1]
+        launches = [{}, {}]
+        for k, f in enumerate(order):
+            pc, img, sem = frames[f]
+            if use_gt:
+                sem_gt = by_ptr[dev[f][0].data_ptr()].cpu().numpy()          # any labels will do: one per point
+                sem_gt = np.resize(sem_gt.ravel(), (len(pc), 1)).astype(np.int64)
+                obs = (img, pc if k % 2 else dev[f][1], sem_gt)
+            else:
+                obs = (img, pc, None) if k % 4 == 3 else (dev[f][0], dev[f][1], None)    # host arrays every fourth step
+            for w, acc in enumerate(accs):
+                ctx.profile(True)
+                removed = acc.integrate([obs])
+                if k in (6, 13):                                             # two integrate() in a row
+                    launches[w][k] = ctx.profile_read()['kitti_project_sample_filter'][1]
+                    ctx.profile(False)
+                    continue
+                if k == 9:                                                   # a reader between integrate() and the raster
+                    acc.store.offsets()
+                n = len(acc.poses)
+                out = acc.generate_bev(n - 2 - (k % 2), 1, gen_future=True)[0] if n >= 3 else None
+                launches[w][k] = ctx.profile_read()['kitti_project_sample_filter'][1]
+                ctx.profile(False)
+                if w == 0:
+                    first = (removed, out)
+                else:
+                    assert removed == first[0]
+                    if out is not None:
+                        for key in out.keys():
+                            if key.startswith('trajs_'):
+                                assert all(np.array_equal(x, y) for x, y in zip(out[key], first[1][key])), key
+                            else:
+                                assert np.array_equal(out[key].view(np.uint16), first[1][key].view(np.uint16)), (use_gt, k, key)
+        ra, rb = (np.concatenate(acc.sem_pcs) for acc in accs)
+        assert ra.shape[0] > 100_000 and np.array_equal(ra, rb)
+        assert np.array_equal(accs[0].store.offsets(), accs[1].store.offsets())
+        # K1 launches of its own: in every step without deferral; with it, none in a step whose K1 the raster of the same step
+        # took (every step but the first three, the two pairs and the steps after them, and the reader at k = 9)
+        assert all(v >= 1 for v in launches[1].values()), launches
+        clean = [k for k in range(3, len(order)) if k not in (6, 7, 9, 13, 14)]
+        assert [launches[0][k] for k in clean] == [0] * len(clean), launches
+        assert launches[0][9] >= 1, launches          # (the K1s of the pairs are run by the OTHER accumulator's next call: same context)
+        for acc in accs:
+            acc.store.check_status()
+        accs[0].store.set_defer_k1(False)
