@@ -1673,13 +1673,18 @@ int pca_k1_prepare_pending(pca_ctx *ctx, K1Args *out, int *n_tiles, hipStream_t 
 void pca_k1_pending_launched(pca_ctx *ctx, hipStream_t s);
 static inline int64_t align256(int64_t v) { return (v + 255) & ~255ll; }
 static inline int tiles_x(int px) { return (px + TS - 1) / TS; }
+// PCA_BEV_G / PCA_BEV_CHUNK: tuning overrides, read on every call (tests switch them to force the memory path)
+static inline int max_groups()
+{
+    const char *e = getenv("PCA_BEV_G");
+    const int max_g = e ? atoi(e) : MAX_G;
+    return (max_g < 1 || max_g > 1024) ? MAX_G : max_g;
+}
 static inline int n_groups(int64_t max_points)
 {
-    // PCA_BEV_G / PCA_BEV_CHUNK: tuning overrides, read on every call (tests switch them to force the memory path)
-    const char *e = getenv("PCA_BEV_G"), *c = getenv("PCA_BEV_CHUNK");
-    int max_g = e ? atoi(e) : MAX_G;
+    const char *c = getenv("PCA_BEV_CHUNK");
+    const int max_g = max_groups();
     int per_g = c ? atoi(c) : 8192;
-    if (max_g < 1 || max_g > 1024) max_g = MAX_G;
     if (per_g < 1024) per_g = 8192;
     int64_t g = (max_points + per_g - 1) / per_g;
     return (int)(g < 1 ? 1 : (g > max_g ? max_g : g));
@@ -1864,8 +1869,16 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
         fuse = fk && owed_ok && !intensity64 && pd.stream == s && pd.slot == slot_end - 1 && pd.slot >= slot_begin && pd.frame_off == frame_off &&
                pd.store.x == store->x && lds <= 80 * 1024 && pd.fr.n <= K1_RIDE * K1_SEG &&
                pca_k1_prepare_pending(ctx, &k1a, &nt, s) == 0 && nt <= K1_RIDE;
-        // K1's tiles are pieces 0 .. nt-1, the window's G pieces follow (the workspace is sized for G + K1_RIDE)
-        if (fuse) { a.Gk = nt; a.G += nt; bev_table_order(a); a.k1_slot = pd.slot; a.k1_n = pd.fr.n; }
+        // K1's tiles are pieces 0 .. nt-1, the window's pieces follow: G of them on top (the workspace is sized for G + K1_RIDE) --
+        // unless that exceeds the cap, 512 = two rounds of one workgroup per CU: then the launch stays within those two rounds
+        // and the nt CUs that run a K1 tile first take one window piece less (cap - 2 nt window pieces).  Measured on the
+        // headline, one box, us of level 1 for window pieces + K1 tiles: 512 + 30 63.3 (the 30 start a third round), 482 + 30
+        // 58.0, 450 + 30 56.0, 418 + 30 56.3, 386 + 30 60.4; ring model flat from 354 to 482 (tools/experiments/bev_g_sweep.sh).
+        if (fuse) {
+            const int cap = max_groups(), G0 = a.G;
+            a.G = (G0 + nt <= cap || (cap - 2 * nt) * 4 < 3 * G0) ? G0 + nt : cap - nt;
+            a.Gk = nt; bev_table_order(a); a.k1_slot = pd.slot; a.k1_n = pd.fr.n;
+        }
         else if (pca_k1_flush_pending(ctx)) return -1;
     }
     if (ctx->profiling == 2) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);

@@ -92,6 +92,15 @@ class DeviceStore:
             self.ctx.check(self.ctx.lib.pca_k1_flush(self.ctx.h))
             self._k1_noted = None
 
+    def __del__(self):
+        # a K1 noted for THIS store must not outlive its arrays (the context would run it later, into memory that torch has
+        # handed to someone else by then)
+        try:
+            if self._k1_noted is not None:
+                self.flush_k1()
+        except Exception:
+            pass
+
     def offsets(self):
         """Exact segment boundaries of the live frames (host numpy int64, length n_frames+1).  Synchronises."""
         self.flush_k1()
