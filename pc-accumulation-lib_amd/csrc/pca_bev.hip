@@ -385,7 +385,7 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     if ((int)blockIdx.x == a.Gk) {                          // (the first workgroup that reads the store)
         // (with a K1 in the launch the window's end is not written yet: its input points bound it)
         const int64_t end_ub = a.Gk ? a.frame_off[a.k1_slot] + a.k1_n : a.frame_off[a.slot_end];
-        if (threadIdx.x == 0 && end_ub - w.lo > a.max_points) pca_raise(a.status, PCA_STATUS_STORE_OVERFLOW);
+        if (threadIdx.x == 0 && end_ub - w.lo > a.max_points + a.k1_n) pca_raise(a.status, PCA_STATUS_STORE_OVERFLOW);   // (a.max_points: the store's part)
         if (threadIdx.x < HQ_IDS) a.heavy[threadIdx.x] = 0;  // the heavy queue of this call starts empty
     }
     for (int t = threadIdx.x; t < n_hist; t += AB_THREADS) s_h[t] = 0;
@@ -1867,7 +1867,7 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
         bool owed_ok = true;                                // (a transform owed by the riding frame itself: its end is not written yet)
         for (int k = 0; k < n_pending; ++k) owed_ok = owed_ok && pending_slot_ends[k] <= pd.slot;
         fuse = fk && owed_ok && !intensity64 && pd.stream == s && pd.slot == slot_end - 1 && pd.slot >= slot_begin && pd.frame_off == frame_off &&
-               pd.store.x == store->x && lds <= 80 * 1024 && pd.fr.n <= K1_RIDE * K1_SEG &&
+               pd.store.x == store->x && lds <= 80 * 1024 && pd.fr.n <= K1_RIDE * K1_SEG && pd.fr.n <= max_points &&
                pca_k1_prepare_pending(ctx, &k1a, &nt, s) == 0 && nt <= K1_RIDE;
         // K1's tiles are pieces 0 .. nt-1, the window's pieces follow: G of them on top (the workspace is sized for G + K1_RIDE) --
         // unless that exceeds the cap, 512 = two rounds of one workgroup per CU: then the launch stays within those two rounds
@@ -1878,6 +1878,7 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
             const int cap = max_groups(), G0 = a.G;
             a.G = (G0 + nt <= cap || (cap - 2 * nt) * 4 < 3 * G0) ? G0 + nt : cap - nt;
             a.Gk = nt; bev_table_order(a); a.k1_slot = pd.slot; a.k1_n = pd.fr.n;
+            a.max_points = max_points - pd.fr.n;            // the store's part of the window: the riding frame's records come on top
         }
         else if (pca_k1_flush_pending(ctx)) return -1;
     }

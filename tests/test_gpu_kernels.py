@@ -1021,3 +1021,95 @@ def test_ab_switches_of_round5_change_no_result():
     assert int(got['default'][2]) > 20000
     for name, v in got.items():
         assert v == got['default'], name
+
+
+def test_k1_defer_semantics_at_the_c_abi(T, orc):
+    """pca_k1_defer at the store level: a noted K1 rides only in a raster whose window ends with its slot (same store, 5-plane
+    f32-intensity layout); any other call -- a raster of another window, an f64-intensity raster, a re-transform, a second
+    observation, offsets() -- runs it first, on its own.  Store and planes equal a store that never defers, call by call,
+    and the oracle at the end."""
+    import ctypes as C
+
+    from pca_amd import _lib
+    from pca_amd.device_store import make_bev_params
+    rng = np.random.default_rng(5)
+    H, W = 64, 96
+    P = np.array([[40., 0, 48, 0], [0, 40., 32, 0], [0, 0, 1, 0]]) @ np.array(
+        [[0., -1, 0, 0], [0, 0, -1, 0], [1, 0, 0, 0], [0, 0, 0, 1]])
+
+    def frame(n):
+        pc = np.stack([rng.uniform(0.5, 20, n), rng.uniform(-9, 9, n), rng.uniform(-1, 2, n), rng.uniform(0, 1, n)],
+                      1).astype(np.float32)
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        sem = rng.integers(0, 19, (H, W)).astype(np.uint8)
+        return pc, img, sem
+    frames = [frame(int(n)) for n in (3000, 1, 9000, 200, 5000, 7000, 4097, 4096)]
+    dev = [tuple(T.from_numpy(a).cuda() for a in f) for f in frames]
+    stores = [dev_store(capacity=1 << 17, max_frames=32) for _ in range(2)]
+    ctx = stores[0].ctx
+    prm = make_bev_params((3.0, 0.5, 0.0), np.eye(3), 0., 0., 40., 64, None, 20., 20., 0.5, 0, DYNOBJ, False)
+    Tm = np.eye(4)
+    Tm[:3, 3] = [-0.5, 0.01, 0.0]
+
+    def obs_of(k, host):
+        pc, img, sem = frames[k] if host else dev[k]
+        o = _lib.PcaKittiObs()
+        ptr = (lambda a: a.ctypes.data) if host else (lambda a: a.data_ptr())
+        o.pts, o.rgb, o.sem, o.sem_gt, o.n, o.host_mask = ptr(pc), ptr(img), ptr(sem), None, len(pc), (7 if host else 0)
+        return o, (pc, img, sem)
+
+    def planes(st, **kw):
+        p16, p64 = st.bev(max(st.n_frames - 2, 1), prm, **kw)
+        return p16.cpu().numpy().view(np.uint16), None if p64 is None else p64.cpu().numpy()
+
+    def step(st, k):
+        if st.n_frames:
+            st.retransform(Tm, defer=True)
+        o, alive = obs_of(k, host=(k % 3 == 2))
+        st.append_kitti_obs(o, P, H, W, KITTI_FILTERS, keep=alive)
+        if k == 1:
+            return None                                   # no raster: the next observation runs this K1
+        if k == 3:
+            return planes(st, last_frame=st.n_frames - 1)  # a window that ends BEFORE the noted frame
+        if k == 4:
+            return planes(st, want_f64=True)              # rides (the f64 planes are the tile kernel's business)
+        if k == 5:
+            st.flush_pending()                            # the owed re-transform, eagerly: K1 first
+            return planes(st)
+        if k == 6:
+            return planes(st, first_frame=2)              # a shorter window (the owed re-transforms are applied first: K1 too)
+        return planes(st)
+    results, rows, launches = [], [], []
+    for w, st in enumerate(stores):                       # the whole sequence with deferral, then without
+        st.set_defer_k1(w == 0)
+        per_step, res = [], []
+        for k in range(len(frames)):
+            ctx.profile(True)
+            res.append(step(st, k))
+            per_step.append(ctx.profile_read()['kitti_project_sample_filter'][1])
+            ctx.profile(False)
+        results.append(res)
+        rows.append(st.rows())
+        launches.append(per_step)
+    stores[0].set_defer_k1(False)
+    for a, b in zip(*results):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert np.array_equal(a[0], b[0])
+            assert (a[1] is None) == (b[1] is None) and (a[1] is None or np.array_equal(a[1], b[1], equal_nan=True))
+    # K1 launches of its own, step by step: without deferral one per step; with it none where the K1 rode (k = 0, 4, 7),
+    # the K1 of the step before at k = 2 (k = 1 had no raster), this step's at k = 3 (another window), k = 5 (re-transform)
+    # and k = 6 (a window that starts later: DeviceStore applies the owed re-transforms eagerly first)
+    assert all(v >= 1 for v in launches[1]), launches
+    assert [launches[0][k] for k in (0, 1, 4, 7)] == [0] * 4 and all(launches[0][k] >= 1 for k in (2, 3, 5, 6)), launches
+    assert np.array_equal(rows[0], rows[1]) and rows[0].shape[0] > 5000
+    assert np.array_equal(stores[0].offsets(), stores[1].offsets())
+    # ... and the oracle on the final store
+    ost = orc.Store(1 << 17)
+    for k, (pc, img, sem) in enumerate(frames):
+        if k:
+            orc.retransform(ost, Tm, 0, ost.n)
+        orc.kitti_project_sample_filter(ost, pc, P, img, sem, None, H, W, KITTI_FILTERS)
+    assert np.array_equal(rows[0], ost.rows(0))
+    for st in stores:
+        st.check_status()
