@@ -1869,6 +1869,11 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
         fuse = fk && owed_ok && !intensity64 && pd.stream == s && pd.slot == slot_end - 1 && pd.slot >= slot_begin && pd.frame_off == frame_off &&
                pd.store.x == store->x && lds <= 80 * 1024 && pd.fr.n <= K1_RIDE * K1_SEG && pd.fr.n <= max_points &&
                pca_k1_prepare_pending(ctx, &k1a, &nt, s) == 0 && nt <= K1_RIDE;
+        { static int fd = -1; if (fd < 0) { const char *e = getenv("PCA_FUSE_DBG"); fd = e ? atoi(e) : 0; }       // diagnostics: why a noted K1 ran on its own
+          if (fd && !fuse)
+              fprintf(stderr, "bev: K1 of slot %d not taken along: switch %d owed_ok %d i64 %d stream %d slot %d (window %d..%d) frame_off %d store %d lds %zu n %d max_points %lld nt %d\n",
+                      pd.slot, fk, (int)owed_ok, intensity64 != nullptr, pd.stream == s, pd.slot == slot_end - 1, slot_begin, slot_end,
+                      pd.frame_off == frame_off, pd.store.x == store->x, lds, pd.fr.n, (long long)max_points, nt); }
         // K1's tiles are pieces 0 .. nt-1, the window's pieces follow: G of them on top (the workspace is sized for G + K1_RIDE) --
         // unless that exceeds the cap, 512 = two rounds of one workgroup per CU: then the launch stays within those two rounds
         // and the nt CUs that run a K1 tile first take one window piece less (cap - 2 nt window pieces).  Measured on the

@@ -440,8 +440,10 @@ class DeviceStore:
         return n_pend, self._pend_T, self._pend_ends, (1 if n_pend >= self.CHAIN_K else 0)
 
     def bev_done(self, write_back):
+        """After a raster call of this store has returned."""
         if self._pending and write_back:
             self._pending = []
+        self._k1_noted = None                      # (a raster takes a noted K1 along or runs it first: nothing is noted any more)
 
     def bev_many(self, jobs, out16):
         """jobs: [(split_frame, prm, first_frame, last_frame | None)]; out16: cuda float16 [len(jobs),21,px,px].  All rasters
