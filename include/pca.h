@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PCA_VERSION 1
+#define PCA_VERSION 2
 
 typedef struct pca_ctx pca_ctx;
 
@@ -45,6 +45,13 @@ typedef struct {
     int32_t *inst;       /* dev */
     uint8_t *dyn;        /* dev */
     int64_t capacity;    /* points */
+    /* Optional (version 2; NULL = absent): dev, six words per slot, ZEROED by the caller whenever a slot is (re)used.  K1 (one-frame
+     * launches) leaves there the box of the points the frame kept, in the frame's own coordinates: words 2k / 2k+1 = lower /
+     * upper bound of coordinate k as an order-preserving code of the f32 (pca_f32_box_decode turns a row into six floats;
+     * upper word 0 = the frame kept nothing, or K1 has not run yet).  A caller that reads rows back -- whenever it likes: a row
+     * it has not seen only means "unknown" -- can tell which frames cannot reach a raster's view (pca_host_view_hull,
+     * pca_bev_bin_range). */
+    uint32_t *frame_box;
 } pca_store;
 
 /* status bits accumulated on the device, read back with pca_status() */
@@ -349,6 +356,29 @@ int pca_kitti_integrate(pca_ctx *ctx, const pca_kitti_obs *obs, const double P[1
                         const uint64_t filter_mask[4], const pca_store *store, int64_t *frame_off /*dev*/, int slot,
                         int sample_mode, pca_host_track *track, const double *T_new_prev, double horizon, int64_t *evicted,
                         double *path_length, void *stream);
+/* Frames that cannot reach the view, skipped by a raster.  The window of a sample spans the accumulation horizon, the view a
+ * part of it: the frames far ahead of the sample's pose and the oldest ones put no point into any plane, yet the raster's
+ * first kernel loads and transforms them.  The CALLER knows where every frame is:
+ * pca_host_view_hull (host only, no GPU): frame f of F (oldest first) was created when the product of all transforms applied to
+ *     the store was then[f] (3x4 row-major; the caller multiplies every T onto its running product `now`: the reference's
+ *     update_sem_pcs, sem_pc_accum.py:168-183), so its points are, now, at  now * inverse(then[f]) * (where K1 put them);
+ *     K1 only keeps points in front of the camera whose pixel lies in the image, i.e. inside the cone `cone` (apex, then the four
+ *     rays through the image corners, in the sensor's frame: pca_host_camera_cone; NULL: no camera test, e.g. per-point
+ *     labels) and inside box[f] (six floats lo/hi per coordinate, what K1 left in pca_store.frame_box; lo > hi = unknown).  Returns in
+ *     *first / *last the first and the last frame for which neither the cone nor the box proves that it misses the view square of prm (1 cm of
+ *     margin; -1 / -1: none); every frame outside [first, last] is certain to fail the raster's crop with all its points.
+ * pca_bev_bin_range: the NEXT pca_bev_generate_chain / pca_kitti_generate_bev of the context bins the slots [slot_first,
+ *     slot_last_plus1) only (clamped to its window; ignored, and forgotten, if that call writes owed transforms back or is a
+ *     different kind of raster).  Results do not change when every frame outside has no point in the view. */
+void pca_host_camera_cone(const double P[12], int H, int W, double cone[15]);
+int pca_host_view_hull(int F, const double *then /*[F][12]*/, const float *box /*[F][6]*/, const double *cone /*[15] or NULL*/,
+                       const double now[12], const pca_bev_params *prm, int *first, int *last);
+int pca_bev_bin_range(pca_ctx *ctx, int slot_first, int slot_last_plus1);
+/* the two in one call (frame 0 of the F frames sits in slot0): 1 = a narrower range was set, 0 = every frame may reach the view */
+int pca_bev_view_hint(pca_ctx *ctx, int slot0, int F, const double *then, const float *box, const double *cone, const double now[12],
+                      const pca_bev_params *prm);
+void pca_f32_box_decode(const uint32_t *rows /*[n][6]*/, int n, float *box /*[n][6]: lo x, hi x, lo y, ...; lo > hi = empty*/);
+
 /* K1 of pca_kitti_integrate left for the raster that follows it.  The reference's driver integrates a frame and, when its
  * trigger fires, rasterises the window that ends with that frame (run_kitti360_bev_gen.py:186-273): with on = 1, a
  * pca_kitti_integrate whose inputs are the plain kind (nearest sampling, rgb + class map) does the pose bookkeeping and the

@@ -1,5 +1,6 @@
 // pca_api.hip -- context, error reporting and look-back workspace management (C ABI, include/pca.h).
 #include <stdio.h>
+#include <cmath>
 #include "pca_common.h"
 
 __global__ __launch_bounds__(256) void pca_fetch_block_kernel(const uint4 *src, uint4 *dst, int64_t n16)
@@ -79,6 +80,127 @@ extern "C" {
 //   numpy / Python-float form in pca_amd/host_logic.py (bev_generator.py:207-371, :737-747 of the reference).
 //   rows: [<= 2 (F-1)][3]; start: [F] first output row of every edge, start[F-1] = number of rows.  Returns that number.
 // ---------------------------------------------------------------------------------------------------------------
+// ---- which frames of a window can reach a raster's view (pca.h) -- host only ----------------------------------------------------
+// Camera cone in the sensor's frame from P = [M | p4] (pixels = P (x, 1) / depth, depth = third row): centre C = -inverse(M) p4,
+// ray through pixel (u, v) = inverse(M) (u, v, 1) (depth grows along it).  K1 keeps a point if rint(u), rint(v) land in the image
+// and depth > 0: the pixel lies in [-0.5, W - 0.5] x [-0.5, H - 0.5]; the corners are taken one pixel further out.
+void pca_host_camera_cone(const double P[12], int H, int W, double cone[15])
+{
+    const double a00 = P[0], a01 = P[1], a02 = P[2], a10 = P[4], a11 = P[5], a12 = P[6], a20 = P[8], a21 = P[9], a22 = P[10];
+    const double c00 = a11 * a22 - a12 * a21, c01 = a02 * a21 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const double c10 = a12 * a20 - a10 * a22, c11 = a00 * a22 - a02 * a20, c12 = a02 * a10 - a00 * a12;
+    const double c20 = a10 * a21 - a11 * a20, c21 = a01 * a20 - a00 * a21, c22 = a00 * a11 - a01 * a10;
+    const double id = 1.0 / (a00 * c00 + a01 * c10 + a02 * c20);
+    const double inv[9] = {c00 * id, c01 * id, c02 * id, c10 * id, c11 * id, c12 * id, c20 * id, c21 * id, c22 * id};
+    for (int r = 0; r < 3; ++r) cone[r] = -(inv[3 * r] * P[3] + inv[3 * r + 1] * P[7] + inv[3 * r + 2] * P[11]);
+    const double us[2] = {-1.5, (double)W + 0.5}, vs[2] = {-1.5, (double)H + 0.5};
+    for (int k = 0; k < 4; ++k) {
+        const double u = us[k & 1], v = vs[k >> 1];
+        for (int r = 0; r < 3; ++r) cone[3 + 3 * k + r] = inv[3 * r] * u + inv[3 * r + 1] * v + inv[3 * r + 2];
+    }
+}
+
+void pca_f32_box_decode(const uint32_t *rows, int n, float *box)
+{
+    for (int f = 0; f < n; ++f)
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t l = rows[6 * f + 2 * k], h = rows[6 * f + 2 * k + 1];
+            const bool have = h != 0u;
+            box[6 * f + 2 * k] = have ? pca_f32_from_ordered(~l) : 1.0f;
+            box[6 * f + 2 * k + 1] = have ? pca_f32_from_ordered(h) : -1.0f;
+        }
+}
+
+// Frame f misses the view for sure if its points all lie beyond ONE of the four lines that bound the view square (plus 1 cm):
+// either the camera cone does (its apex does, and none of its four edge rays comes back), or the box of the kept points does
+// (the linear function at the better end of every coordinate).  Both are affine images under  now inverse(then[f])  and the
+// raster's view transform; a number that is not finite proves nothing (the frame counts as visible).
+int pca_host_view_hull(int F, const double *then, const float *box, const double *cone, const double now[12],
+                       const pca_bev_params *prm, int *first, int *last)
+{
+    if (F < 0 || !then || !now || !prm || !first || !last) return -1;
+    const double h = 0.5 * prm->view + 0.01;
+    auto visible = [&](int f) -> bool {
+        const double *m = then + 12 * (size_t)f;
+        const double a00 = m[0], a01 = m[1], a02 = m[2], a10 = m[4], a11 = m[5], a12 = m[6], a20 = m[8], a21 = m[9], a22 = m[10];
+        const double c00 = a11 * a22 - a12 * a21, c01 = a02 * a21 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+        const double c10 = a12 * a20 - a10 * a22, c11 = a00 * a22 - a02 * a20, c12 = a02 * a10 - a00 * a12;
+        const double c20 = a10 * a21 - a11 * a20, c21 = a01 * a20 - a00 * a21, c22 = a00 * a11 - a01 * a10;
+        const double id = 1.0 / (a00 * c00 + a01 * c10 + a02 * c20);
+        const double inv[9] = {c00 * id, c01 * id, c02 * id, c10 * id, c11 * id, c12 * id, c20 * id, c21 * id, c22 * id};
+        // rows x, y of M = now inverse(then), then the view transform on top: u = Q c + q for a point c of the frame
+        double Q[6], q[2];
+        {
+            double Mr[6], Mt[2];
+            for (int r = 0; r < 2; ++r) {
+                for (int c = 0; c < 3; ++c) Mr[3 * r + c] = now[4 * r] * inv[c] + now[4 * r + 1] * inv[3 + c] + now[4 * r + 2] * inv[6 + c];
+                Mt[r] = now[4 * r + 3] - (Mr[3 * r] * m[3] + Mr[3 * r + 1] * m[7] + Mr[3 * r + 2] * m[11]);
+            }
+            const double tx = Mt[0] - prm->origin[0], ty = Mt[1] - prm->origin[1];
+            q[0] = prm->R[0] * tx + prm->R[1] * ty + prm->dx;
+            q[1] = prm->R[3] * tx + prm->R[4] * ty + prm->dy;
+            for (int c = 0; c < 3; ++c) {
+                Q[c] = prm->R[0] * Mr[c] + prm->R[1] * Mr[3 + c];
+                Q[3 + c] = prm->R[3] * Mr[c] + prm->R[4] * Mr[3 + c];
+            }
+        }
+        for (int k = 0; k < 6; ++k) if (!std::isfinite(Q[k])) return true;
+        if (!std::isfinite(q[0]) || !std::isfinite(q[1])) return true;
+        for (int axis = 0; axis < 2; ++axis)
+            for (int side = 0; side < 2; ++side) {
+                const double s = side ? -1.0 : 1.0;             // beyond the line  s u[axis] = h ?
+                const double *row = Q + 3 * axis;
+                if (cone) {
+                    const double ua = s * (row[0] * cone[0] + row[1] * cone[1] + row[2] * cone[2] + q[axis]);
+                    bool out = ua >= h;
+                    for (int k = 0; k < 4 && out; ++k) {
+                        const double *d = cone + 3 + 3 * k;
+                        out = s * (row[0] * d[0] + row[1] * d[1] + row[2] * d[2]) >= 0.0;
+                    }
+                    if (out) return false;
+                }
+                if (box) {
+                    const float *b = box + 6 * (size_t)f;
+                    if (b[0] <= b[1] && b[2] <= b[3] && b[4] <= b[5]) {
+                        double lo = s * q[axis];
+                        for (int c = 0; c < 3; ++c) {
+                            const double x0 = s * row[c] * (double)b[2 * c], x1 = s * row[c] * (double)b[2 * c + 1];
+                            lo += x0 < x1 ? x0 : x1;
+                        }
+                        if (lo >= h) return false;
+                    }
+                }
+            }
+        return true;
+    };
+    int a = 0, b = F - 1;
+    while (a <= b && !visible(a)) ++a;
+    while (b >= a && !visible(b)) --b;
+    if (a > b) { *first = -1; *last = -1; } else { *first = a; *last = b; }
+    return 0;
+}
+
+// pca_host_view_hull + pca_bev_bin_range in one call (frame 0 of the F frames sits in slot0).  Returns 1 if a range narrower
+// than the F frames was set, 0 if every frame may reach the view (nothing set), -1 on bad arguments.
+int pca_bev_view_hint(pca_ctx *ctx, int slot0, int F, const double *then, const float *box, const double *cone, const double now[12],
+                      const pca_bev_params *prm)
+{
+    if (!ctx) return -1;
+    int first = 0, last = 0;
+    if (pca_host_view_hull(F, then, box, cone, now, prm, &first, &last)) return -1;
+    if (first == 0 && last == F - 1) return 0;
+    if (first < 0) { first = 0; last = -1; }
+    ctx->bin_first = slot0 + first; ctx->bin_end = slot0 + last + 1; ctx->bin_valid = true;
+    return 1;
+}
+
+int pca_bev_bin_range(pca_ctx *ctx, int slot_first, int slot_last_plus1)
+{
+    if (!ctx) return -1;
+    ctx->bin_first = slot_first; ctx->bin_end = slot_last_plus1; ctx->bin_valid = slot_last_plus1 >= slot_first;
+    return 0;
+}
+
 static inline bool box_inside(double x, double y, double lo, double hi) { return lo < x && x < hi && lo < y && y < hi; }
 
 int pca_host_ego_to_grid(const double *full, int F, const double R[9], double dx, double dy, double view, int px,
@@ -163,10 +285,11 @@ int pca_ctx_create(int device, pca_ctx **out)
     PCA_CREATE_STEP(hipMemset(ctx->ticket, 0, sizeof(PcaStatusBlock)));
     PCA_CREATE_STEP(hipHostMalloc(&ctx->status_host, sizeof(uint32_t)));
     PCA_CREATE_STEP(hipHostMalloc(&ctx->status_mirror, PCA_STATUS_BITS * sizeof(uint32_t), hipHostMallocMapped));
-    PCA_CREATE_STEP(hipHostMalloc(&ctx->heavy_hint, sizeof(uint32_t), hipHostMallocMapped));
+    PCA_CREATE_STEP(hipHostMalloc(&ctx->heavy_hint, 4 * sizeof(uint32_t), hipHostMallocMapped));    // [0] heavy tiles, [1] points binned by the last raster with a bin range
     int n_cu = 0;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) ctx->n_cu = n_cu;
     *ctx->heavy_hint = 1;            // first call: assume heavy tiles exist
+    ctx->heavy_hint[1] = ctx->heavy_hint[2] = ctx->heavy_hint[3] = 0;
     for (int b = 0; b < PCA_STATUS_BITS; ++b) ctx->status_mirror[b] = 0;
     PCA_CREATE_STEP(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->heavy_hint_dev), ctx->heavy_hint, 0));
     PCA_CREATE_STEP(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->status_mirror_dev), ctx->status_mirror, 0));

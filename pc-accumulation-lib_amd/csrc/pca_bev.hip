@@ -83,6 +83,8 @@ struct alignas(16) BevArgs {                             // (16: pca_fetch_block
     uint32_t *bh;         // [T][G] kept records per (tile, workgroup)
     uint32_t *boff;       // [T][G] exclusive scan of bh in that order
     int Gk;               // the first Gk of the G pieces are the tiles of a K1 that rides in level 1's launch (0: none), see bev_tile_bin_k1
+    int bin_first, bin_end;   // the slots level 1 bins: the window, or what the caller proved to be all that can reach the view
+                          // (pca_bev_bin_range; never with a write-back: a skipped frame could not receive the transforms it owes)
     int k1_slot, k1_n;    // its slot (the window's last: the pieces behind Gk cover the window up to it) and its input points
     uint32_t *bh0;        // [T][G] with `split`: how many of a (tile, workgroup) piece's records belong to the tile's cells 0..31
     int split;            // level 1 orders every piece by HALF of the tile (cells 0..31, then 32..63), so that an item (tile, half)
@@ -90,6 +92,8 @@ struct alignas(16) BevArgs {                             // (16: pca_fetch_block
                           // level 1's register path (bev_split: decided by the kernels, which know the window), 2 always
     uint32_t *heavy_hint; // host-visible word: the heavy count of this call, read by the host before the next one
     uint32_t heavy_hint_known;   // its value when this call was made
+    uint32_t *span_hint;  // host-visible word: the points (in units of 1024) this call's level 1 binned, written when the call came
+    uint32_t span_hint_known;    // with a bin range; the host sizes the NEXT such launch by it (any piece count gives the same result)
     int heavy_launched;   // a bev_tile_cells_heavy launch follows (else the light kernel's last workgroup drains the queue)
     uint32_t *heavy;      // [64 + 32 T]: [0..32) tiles per size class (class 0 = largest), [32] item cursor, then the
                           // classes' tile ids [class][T] -- the queue of bev_tile_cells_heavy, filled by bev_tile_cells
@@ -120,11 +124,16 @@ __device__ __forceinline__ int chunk_index(const BevArgs &a, int64_t lo, int64_t
 #define K1_RIDE 32                // K1 tiles that may ride in a level-1 launch (frames of up to 131 072 points): they come ON TOP of
                                   // the window's G pieces, so the counter tables and the record buffer are sized for G + K1_RIDE
 // the window level 1 reads from the store: up to the frame whose K1 rides along (its points come out of K1's registers), else all
-__device__ __forceinline__ int64_t window_end(const BevArgs &a) { return a.frame_off[a.Gk ? a.k1_slot : a.slot_end]; }
+__device__ __forceinline__ int64_t window_end(const BevArgs &a)
+{
+    const int e = a.Gk ? a.k1_slot : a.slot_end;
+    return a.frame_off[a.bin_end < e ? a.bin_end : e];
+}
+__device__ __forceinline__ int64_t window_begin(const BevArgs &a) { return a.frame_off[a.bin_first]; }
 __device__ __forceinline__ Window chunk_of(const BevArgs &a, int &g)
 {
     Window w;
-    w.lo = a.frame_off[a.slot_begin];
+    w.lo = window_begin(a);
     const int64_t hi0 = window_end(a);
     // (with a K1 in the launch frame_off[k1_slot + 1] is not written yet: a split behind that frame = everything the store holds)
     w.sp = (a.Gk && a.slot_split > a.k1_slot) ? hi0 : a.frame_off[a.slot_split];
@@ -385,8 +394,12 @@ __device__ __forceinline__ void bev_tile_bin_body(const BevArgs &a)
     if ((int)blockIdx.x == a.Gk) {                          // (the first workgroup that reads the store)
         // (with a K1 in the launch the window's end is not written yet: its input points bound it)
         const int64_t end_ub = a.Gk ? a.frame_off[a.k1_slot] + a.k1_n : a.frame_off[a.slot_end];
-        if (threadIdx.x == 0 && end_ub - w.lo > a.max_points + a.k1_n) pca_raise(a.status, PCA_STATUS_STORE_OVERFLOW);   // (a.max_points: the store's part)
+        if (threadIdx.x == 0 && end_ub - a.frame_off[a.slot_begin] > a.max_points + a.k1_n) pca_raise(a.status, PCA_STATUS_STORE_OVERFLOW);   // (a.max_points: the store's part)
         if (threadIdx.x < HQ_IDS) a.heavy[threadIdx.x] = 0;  // the heavy queue of this call starts empty
+        if (threadIdx.x == 0 && a.span_hint) {
+            const uint32_t kp = (uint32_t)((w.hi - w.lo + 1023) >> 10);
+            if (kp != a.span_hint_known) *a.span_hint = kp;
+        }
     }
     for (int t = threadIdx.x; t < n_hist; t += AB_THREADS) s_h[t] = 0;
     __syncthreads();
@@ -624,7 +637,7 @@ __device__ __forceinline__ uint32_t recmap_build(RecMap &M, const BevArgs &a, in
                 if (half >= 0) c0[k] = a.bh0[(int64_t)tile * a.Gr + g0 + k];     // (uniform; read before it is known to be valid: never used then)
             }
         }
-    const int64_t lo = a.frame_off[a.slot_begin], hi0 = window_end(a);
+    const int64_t lo = window_begin(a), hi0 = window_end(a);
     const int64_t n = hi0 - lo > a.max_points ? a.max_points : hi0 - lo;
     if (half >= 0 && bev_split(a, n)) {                     // (uniform) the item's own half of every piece
 #pragma unroll
@@ -1495,7 +1508,7 @@ __device__ __forceinline__ void bev_tile_cells_heavy_body(const BevArgs &a)
     // 2 x 16 B read per record of a heavy tile, 3.2 GB for 1.6 GB of records on BASELINE config 4)
     bool own = false;                                       // (uniform) OWN: compiled for it; in effect if this window's pieces are ordered
     if (OWN) {
-        const int64_t wn = window_end(a) - a.frame_off[a.slot_begin];      // (what level 1 decided on)
+        const int64_t wn = window_end(a) - window_begin(a);                // (what level 1 decided on)
         own = bev_split(a, wn > a.max_points ? a.max_points : wn);
     }
     const uint32_t r_lo = 0, r_hi = recmap_build(L.M, a, tile, H_THREADS, nullptr, OWN ? half : -1);
@@ -1589,7 +1602,7 @@ struct BinK1Tail {
         extern __shared__ uint32_t s_lds[];
         __shared__ uint32_t s_wsum[AB_THREADS / 64];
         __shared__ uint32_t s_dyn[8];
-        const int64_t lo = a.frame_off[a.slot_begin], hi0 = window_end(a);
+        const int64_t lo = window_begin(a), hi0 = window_end(a);
         const bool split = bev_split(a, hi0 - lo > a.max_points ? a.max_points : hi0 - lo);
         const int hs = split ? 6 : 7, n_hist = split ? 2 * a.T : a.T;
         uint32_t *s_h = s_lds, *s_cur = s_lds + n_hist;
@@ -1776,6 +1789,7 @@ static int bev_prepare(pca_ctx *ctx, const pca_store *store, const double *inten
     a.bh0 = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(a.G + K1_RIDE + 8) * a.T * 4);
     a.split = 0;
     a.Gk = 0; a.k1_slot = -1; a.k1_n = 0;
+    a.bin_first = slot_begin; a.bin_end = slot_end;
     a.heavy = reinterpret_cast<uint32_t *>(w); w += align256((int64_t)(HQ_IDS + HQ_CLASSES * (int64_t)a.T) * 4);
     a.recs = w;
     a.planes = planes;
@@ -1793,6 +1807,7 @@ static int bev_prepare(pca_ctx *ctx, const pca_store *store, const double *inten
         a.tile_mult = m < 1 ? 1 : m;
     }
     a.heavy_hint = nullptr; a.heavy_hint_known = 0; a.heavy_launched = 1;
+    a.span_hint = nullptr; a.span_hint_known = 0;
     return 0;
 }
 
@@ -1825,6 +1840,9 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
                            double *extra_planes, void *stream)
 {
     if (!ctx) return -1;
+    const bool bin_given = ctx->bin_valid;                  // (pca_bev_bin_range: for this call, whatever becomes of it)
+    const int bin_first = ctx->bin_first, bin_end = ctx->bin_end;
+    ctx->bin_valid = false;
     if (max_points < 1) max_points = 1;
     hipStream_t s = (hipStream_t)stream;
     PCA_CHECK(ctx, hipSetDevice(ctx->device));
@@ -1855,6 +1873,27 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
     { static int sp = -1; if (sp < 0) { const char *e = getenv("PCA_BEV_SPLIT"); sp = e ? atoi(e) : 1; }
       a.split = (sp && a.heavy_launched && !intensity64 && (size_t)a.T * 16 <= 128 * 1024) ? (sp == 2 ? 2 : 1) : 0; }
     const size_t lds = (size_t)a.T * 8 * (a.split ? 2 : 1);  // bev_tile_bin: histogram + cursors
+    // The caller's proof of which slots can reach the view (pca_bev_bin_range): good for this call only, and not when this call
+    // writes owed transforms back (a skipped frame could not receive them).  PCA_BEV_CULL=0: ignored (A/B; same results).
+    // With a bin range, ONE round of workgroups if the last such call binned few enough points for level 1's register path at one
+    // piece per CU: a piece costs ~15 us before its first point, two rounds of half-size pieces take almost twice as long as
+    // one (profiles/r05_experiments/bev_cull_frames_out_of_view.txt).  The count comes from the device through a host-visible
+    // word and only sizes the launch: a window that turns out larger goes through the memory path as ever.
+    int one_round = 0;
+    if (bin_given) {
+        static int cu = -1;
+        static int64_t pts = -1;
+        if (cu < 0) { const char *e = getenv("PCA_BEV_CULL"); cu = e ? atoi(e) : 1; }
+        if (pts < 0) { const char *e = getenv("PCA_BEV_ONE_ROUND_PTS"); pts = e ? atoll(e) : 14500; }
+        if (cu && !(n_pending > 0 && write_back)) {
+            int f = bin_first > slot_begin ? bin_first : slot_begin, e = bin_end < slot_end ? bin_end : slot_end;
+            if (e < f) e = f;
+            a.bin_first = f; a.bin_end = e;
+            a.span_hint = ctx->heavy_hint_dev + 1;
+            a.span_hint_known = ctx->heavy_hint[1];
+            if (pts > 0 && a.span_hint_known != 0 && (int64_t)a.span_hint_known * 1024 <= pts * ctx->n_cu && a.G > ctx->n_cu) one_round = ctx->n_cu;
+        }
+    }
     // A K1 that pca_kitti_integrate left for this raster (the window's last frame, same store, same stream) rides in level 1's
     // launch as its first workgroups; any other deferred K1 runs now, on its own.  PCA_FUSE_K1=0: always on its own (A/B).
     bool fuse = false;
@@ -1881,12 +1920,14 @@ int pca_bev_generate_chain(pca_ctx *ctx, const pca_store *store, const double *i
         // 58.0, 450 + 30 56.0, 418 + 30 56.3, 386 + 30 60.4; ring model flat from 354 to 482 (tools/experiments/bev_g_sweep.sh).
         if (fuse) {
             const int cap = max_groups(), G0 = a.G;
-            a.G = (G0 + nt <= cap || (cap - 2 * nt) * 4 < 3 * G0) ? G0 + nt : cap - nt;
+            if (one_round) one_round -= nt;                     // (K1's tiles hold nt of the CUs when the launch starts)
+            a.G = one_round > 0 ? one_round + nt : (G0 + nt <= cap || (cap - 2 * nt) * 4 < 3 * G0) ? G0 + nt : cap - nt;
             a.Gk = nt; bev_table_order(a); a.k1_slot = pd.slot; a.k1_n = pd.fr.n;
             a.max_points = max_points - pd.fr.n;            // the store's part of the window: the riding frame's records come on top
         }
         else if (pca_k1_flush_pending(ctx)) return -1;
     }
+    if (one_round > 0 && !fuse) { a.G = one_round; bev_table_order(a); }
     if (ctx->profiling == 2) pca_prof_begin(ctx, PCA_K_BEV_UNIT, s);
     // (Running the two tile kernels side by side was tried: a second stream with fork / join events costs ~20 us per
     // call, and hipExtAnyOrderLaunch is not honoured on gfx9 -- see DESIGN.md.)
@@ -1927,6 +1968,7 @@ int pca_bev_generate_many(pca_ctx *ctx, const pca_store *store, const double *in
 {
     if (!ctx) return -1;
     if (pca_k1_flush_pending(ctx)) return -1;               // a deferred K1 of this context comes first
+    ctx->bin_valid = false;                                 // (a bin range is for a single raster)
     if (!jobs || n_jobs < 1) { ctx->err = "bev: bad job list"; return -1; }
     if (n_jobs > 65535) { ctx->err = "bev: at most 65535 rasters per call"; return -1; }
     if (max_points < 1) max_points = 1;

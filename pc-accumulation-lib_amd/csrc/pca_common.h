@@ -105,6 +105,8 @@ struct pca_ctx {
     uint32_t *status_host = nullptr;  // pinned
     uint32_t *heavy_hint = nullptr;   // pinned, device-visible: heavy-tile count of the latest rasteriser call
     uint32_t *heavy_hint_dev = nullptr;
+    int bin_first = 0, bin_end = 0;   // pca_bev_bin_range: the slots the next single raster bins (bin_valid); forgotten by that call
+    bool bin_valid = false;
     // optional per-kernel event timing
     struct Ev { hipEvent_t a, b; int kid; };
     int profiling = 0;                // 0 off, 1 every kernel launch, 2 whole units only (pca_profile_enable)
@@ -248,6 +250,19 @@ __device__ __forceinline__ uint16_t f64_to_f16_bits_reference(double d)
     uint32_t h = (he > 0) ? (uint32_t)((he - 1) << 10) + (uint32_t)keep : (uint32_t)keep;
     if (h >= 0x7c00u) h = 0x7c00u;
     return (uint16_t)(sign | h);
+}
+
+// f32 -> u32, order-preserving (a < b  <=>  ordered(a) < ordered(b)), never 0 for a number: the frame boxes of
+// pca_store.frame_box are atomic maxima of ordered(v) (upper bound) and ~ordered(v) (lower bound), 0 = nothing yet
+__host__ __device__ __forceinline__ uint32_t pca_f32_ordered(float v)
+{
+    union { float f; uint32_t u; } c; c.f = v;
+    return c.u ^ ((c.u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__host__ __device__ __forceinline__ float pca_f32_from_ordered(uint32_t o)
+{
+    union { float f; uint32_t u; } c; c.u = o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu);
+    return c.f;
 }
 
 // Raises a PCA_STATUS_* bit: the device word (read and cleared by pca_status, which synchronises) and its host-visible

@@ -227,6 +227,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const Tail &tail = Tail
     __shared__ uint32_t s_cnt[NC];         // per (row, wave) counts: candidates, later kept points
     __shared__ uint32_t s_filt[8];         // 256-bit class filter
     __shared__ long long s_excl;           // FUSED: exclusive prefix of the tile
+    __shared__ uint32_t s_box[6];          // FUSED: the box of the tile's kept points (ordered encodings; pca_store.frame_box)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     K1_STAMP(0);
@@ -424,6 +425,7 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const Tail &tail = Tail
 #pragma unroll
     for (int r = 0; r < PPT; ++r)
         if (lane == 0) s_cnt[r * NW + wave] = (uint32_t)__popcll(km[r]);
+    if (!SPLIT && threadIdx.x < 6) s_box[threadIdx.x] = 0u;
     __syncthreads();
     K1_STAMP(4);
     uint32_t koff[PPT], total;
@@ -461,12 +463,37 @@ __device__ __forceinline__ void k1_body(const K1Args &a, const Tail &tail = Tail
     }
 
     // ---------------- FUSED: look-back, then append the kept records ----------------
+    // The box of the frame's kept points, in the frame's own coordinates (pca.h: pca_store.frame_box): six atomic max on
+    // order-preserving encodings of the f32 values (upper bounds) and their complements (lower bounds); 0 = nothing yet.  Per wave
+    // in registers, per tile through LDS, six global atomics per TILE -- per wave they were 2 880 same-address atomics per frame,
+    // and the L2 channel they hit served nobody else for ~20 us (every first-round workgroup of level 1 beside it took 43 us
+    // instead of 25).
+    if (a.st.frame_box) {                                   // (uniform)
+        uint32_t lo[3] = {0u, 0u, 0u}, hi[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < PPT; ++r)
+            if ((km[r] >> lane) & 1ull) {
+                const float c[3] = {p[r].x, p[r].y, p[r].z};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const uint32_t o = pca_f32_ordered(c[k]);
+                    hi[k] = hi[k] > o ? hi[k] : o;
+                    lo[k] = lo[k] > ~o ? lo[k] : ~o;
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t l = wave_reduce_max(lo[k]), h = wave_reduce_max(hi[k]);
+            if (lane == 0 && h) { atomicMax(&s_box[2 * k], l); atomicMax(&s_box[2 * k + 1], h); }
+        }
+    }
     if (wave == 0) {
         const uint64_t e = lb_exclusive_prefix(a.state, tile, (uint64_t)total, a.epoch, a.status);
         if (lane == 0) s_excl = (long long)e;
     }
     __syncthreads();
     K1_STAMP(5);
+    if (a.st.frame_box && threadIdx.x < 6 && s_box[threadIdx.x]) atomicMax(a.st.frame_box + (size_t)(a.first_slot + fr.f) * 6 + threadIdx.x, s_box[threadIdx.x]);
     const int64_t tile_base = a.frame_off[a.first_slot] + k1_uniform_i64(s_excl);
     const int64_t room64 = a.st.capacity - tile_base;
     const uint32_t room = room64 <= 0 ? 0u : (room64 > 0x7fffffffll ? 0x7fffffffu : (uint32_t)room64);

@@ -387,6 +387,7 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         start = np.zeros(max(n, 1), dtype=np.int32)
         n_rows = C.c_int32(0)
         cst = st.c_store()
+        st.view_hint(prm, 0, n, n_pend > 0 and write_back)      # (right in front of the call it is meant for: one use)
         ticket = ctx.lib.pca_kitti_generate_bev(ctx.h, C.byref(cst), st.frame_off.data_ptr(), st.head, st.head + split,
                                                 st.head + n, max_points, C.byref(prm), pend_T, pend_ends, n_pend, write_back,
                                                 st._ws.data_ptr(), st._ws.numel(), out.data_ptr(),

@@ -26,7 +26,7 @@ EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error',
            'pca_host_track_poses', 'pca_host_track_segments', 'pca_host_track_set', 'pca_host_track_transform',
            'pca_host_track_append', 'pca_host_track_push_segment', 'pca_host_track_incr', 'pca_host_track_evict_beyond',
            'pca_host_track_step', 'pca_host_track_trigger', 'pca_host_stage_h2d', 'pca_host_d2h_async', 'pca_host_d2h_wait',
-           'pca_kitti_integrate', 'pca_kitti_generate_bev', 'pca_k1_defer', 'pca_k1_flush',
+           'pca_kitti_integrate', 'pca_kitti_generate_bev', 'pca_k1_defer', 'pca_k1_flush', 'pca_host_camera_cone', 'pca_host_view_hull', 'pca_bev_bin_range', 'pca_bev_view_hint', 'pca_f32_box_decode',
            'pca_profile_enable', 'pca_profile_read')
 
 KERNEL_IDS = ('kitti_project_sample_filter', 'nusc_sample_filter_transform', 'nusc_project_cams', 'retransform',
@@ -36,7 +36,8 @@ BEV_EXTRA_PLANES = ('elevation_max', 'elevation_mean', 'intensity_mean')
 
 class PcaStore(C.Structure):
     _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('z', C.c_void_p), ('intensity', C.c_void_p),
-                ('rgbs', C.c_void_p), ('inst', C.c_void_p), ('dyn', C.c_void_p), ('capacity', C.c_int64)]
+                ('rgbs', C.c_void_p), ('inst', C.c_void_p), ('dyn', C.c_void_p), ('capacity', C.c_int64),
+                ('frame_box', C.c_void_p)]
 
 
 class PcaKittiObs(C.Structure):
@@ -195,6 +196,13 @@ def load():
                                         C.POINTER(C.c_double), vp]
     lib.pca_kitti_generate_bev.argtypes = [vp, C.POINTER(PcaStore), vp, i32, i32, i32, i64, C.POINTER(PcaBevParams), vp, vp,
                                            i32, i32, vp, i64, vp, vp, vp, vp, vp, C.POINTER(C.c_int32), vp]
+    lib.pca_host_camera_cone.argtypes = [vp, i32, i32, vp]
+    lib.pca_host_camera_cone.restype = None
+    lib.pca_host_view_hull.argtypes = [i32, vp, vp, vp, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.pca_bev_bin_range.argtypes = [vp, i32, i32]
+    lib.pca_bev_view_hint.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.pca_f32_box_decode.argtypes = [vp, i32, vp]
+    lib.pca_f32_box_decode.restype = None
     lib.pca_k1_defer.argtypes = [vp, i32]
     lib.pca_k1_flush.argtypes = [vp]
     lib.pca_profile_enable.argtypes = [vp, i32]

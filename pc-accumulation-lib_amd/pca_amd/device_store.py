@@ -17,6 +17,9 @@ import torch
 from . import _lib
 from ._lib import PcaBevParams, PcaKittiFrame, PcaStore
 
+# PCA_BEV_CULL=0: no raster is told which frames cannot reach its view (A/B -- results are identical)
+CULL = os.environ.get('PCA_BEV_CULL', '1') != '0'
+
 
 class DeviceStore:
     """The accumulated points in HBM (SoA) with the host-side bookkeeping of slots and owed re-transforms.
@@ -33,6 +36,9 @@ class DeviceStore:
         self.max_frames = int(max_frames)
         self._alloc(int(capacity))
         self.frame_off = torch.zeros(self.max_frames + 1, dtype=torch.int64, device=self.device)
+        self._moved = np.eye(4)  # product of every transform applied to all live frames so far (newest on the left)
+        self.cull = CULL         # tell the rasters which slots can reach their view (view_hint)
+        self._alloc_frame_tables(self.max_frames)
         self.head = 0            # first live slot
         self.tail = 0            # one past the last live slot
         self.ub_tail = 0         # upper bound of frame_off[tail]
@@ -67,10 +73,94 @@ class DeviceStore:
     def _arrays(self):
         return (self.x, self.y, self.z, self.intensity, self.rgbs, self.inst, self.dyn)
 
+    # ---- where the frames are (for pca_host_view_hull: include/pca.h) --------------------------
+    BOX_EVERY = 8            # the frames' boxes are read back every so many append_kitti_obs (asynchronously)
+
+    def _alloc_frame_tables(self, max_frames, keep=None):
+        """Per slot: the box K1 leaves on the device (frame_box), what the host has seen of it (_box: lo > hi = not seen), the
+        store's `moved` matrix when the frame was created (_then; NaN = unknown: the frame always counts as visible) and
+        whether K1's camera test applied to it (_has_cone).  keep = (first, n): those rows move to the front."""
+        n1 = max_frames + 1
+        box = torch.zeros((n1, 6), dtype=torch.int32, device=self.device)
+        then = np.full((n1, 12), np.nan)
+        seen = np.tile(np.array([1, -1] * 3, dtype=np.float32), (n1, 1))
+        cone = np.zeros(n1, dtype=bool)
+        if keep is not None:
+            a, n = keep
+            box[:n] = self.frame_box[a:a + n]
+            then[:n], seen[:n], cone[:n] = self._then[a:a + n], self._box[a:a + n], self._has_cone[a:a + n]
+        self.frame_box, self._then, self._box, self._has_cone = box, then, seen, cone
+        self._then_addr, self._box_addr = then.ctypes.data, seen.ctypes.data
+        self._box_pin = None     # pinned landing block of the read-backs
+        self._box_copy = None    # (event, first slot, slots) of the read-back in flight
+        self._since_box = 0
+        self._cone = None        # (key, 15 doubles) of the camera the live frames were taken with
+        self._n_nocone = 0 if keep is None else int(np.count_nonzero(~cone[:keep[1]] & np.isfinite(then[:keep[1], 0])))   # noted frames without the camera test
+        self._cstore = None
+
+    def _note_moved(self, Ts):
+        """Ts (k,16): transforms applied -- now or owed -- to EVERY live frame, in order."""
+        for T in Ts:
+            self._moved = T.reshape(4, 4) @ self._moved
+
+    def _note_frame(self, slot, cone_key):
+        """A frame K1 is about to put into `slot`, created under the current `moved`; cone_key: (P bytes, H, W) if K1's camera
+        test applies to it, else None."""
+        self._then[slot] = self._moved[:3].reshape(12)      # (its row of _box says "not seen": every slot is used once between slides)
+        if cone_key is not None:
+            if self._cone is None or self._cone[0] != cone_key:
+                if self._cone is not None:                  # another camera: the frames taken with the old one lose their cone
+                    self._has_cone[self.head:self.tail] = False
+                    self._n_nocone = self.tail - self.head
+                out = np.empty(15)
+                Pm = np.frombuffer(cone_key[0], dtype=np.float64)
+                self.ctx.lib.pca_host_camera_cone(Pm.ctypes.data, int(cone_key[1]), int(cone_key[2]), out.ctypes.data)
+                self._cone = (cone_key, out, out.ctypes.data)
+            self._has_cone[slot] = True
+        else:
+            self._n_nocone += 1
+        self._since_box += 1
+        self._poll_boxes()
+        if self._since_box >= self.BOX_EVERY and self._box_copy is None:
+            n = self.tail - self.head
+            if n > 0:
+                if self._box_pin is None or self._box_pin.shape[0] < self.frame_box.shape[0]:
+                    self._box_pin = torch.empty(tuple(self.frame_box.shape), dtype=torch.int32, pin_memory=True)
+                self._box_pin[:n].copy_(self.frame_box[self.head:self.tail], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._box_copy = (ev, self.head, n)
+                self._since_box = 0
+
+    def _poll_boxes(self):
+        """Takes in a finished read-back: the rows K1 had filled by then (a row of zeros stays unknown)."""
+        if self._box_copy is None or not self._box_copy[0].query():
+            return
+        _, first, n = self._box_copy
+        self._box_copy = None
+        rows = self._box_pin[:n].numpy()
+        dec = np.empty((n, 6), dtype=np.float32)
+        self.ctx.lib.pca_f32_box_decode(rows.ctypes.data, n, dec.ctypes.data)
+        known = dec[:, 0] <= dec[:, 1]
+        tgt = self._box[first:first + n]
+        tgt[known] = dec[known]
+
+    def view_hint(self, prm, first_frame, last_frame, write_back):
+        """Tells the context which slots of live frames [first_frame, last_frame) can reach the view of `prm` (pca_bev_view_hint)
+        before a raster that writes nothing back.  Returns 1 if frames will be left out."""
+        n = last_frame - first_frame
+        if not self.cull or write_back or n < 4:
+            return 0
+        a = self.head + first_frame
+        cone = self._cone[2] if (self._cone is not None and self._n_nocone == 0) else None
+        return self.ctx.lib.pca_bev_view_hint(self.ctx.h, a, n, self._then_addr + 96 * a, self._box_addr + 24 * a, cone,
+                                              self._moved.ctypes.data, C.addressof(prm))
+
     def c_store(self):
         if self._cstore is None:
             self._cstore = PcaStore(self.x.data_ptr(), self.y.data_ptr(), self.z.data_ptr(), self.intensity.data_ptr(),
-                                    self.rgbs.data_ptr(), self.inst.data_ptr(), self.dyn.data_ptr(), self.capacity)
+                                    self.rgbs.data_ptr(), self.inst.data_ptr(), self.dyn.data_ptr(), self.capacity,
+                                    self.frame_box.data_ptr())
         return self._cstore
 
     @property
@@ -147,11 +237,18 @@ class DeviceStore:
         new_off = torch.zeros(new_maxf + 1, dtype=torch.int64, device=self.device)
         new_off[:nf + 1] = torch.from_numpy(off - a).to(self.device)
         self.frame_off = new_off
+        cone = self._cone
+        self._alloc_frame_tables(new_maxf, keep=(self.head, nf))   # the live frames keep their rows, every other slot starts empty
+        self._cone = cone
         self.head, self.tail = 0, nf
         self.lb_head, self.ub_tail = 0, live
 
     def evict(self, k):
-        self.head += int(k)
+        k = int(k)
+        if self._n_nocone and k:                   # (frames K1 noted without its camera test: the others have no `then` at all)
+            sl = slice(self.head, self.head + k)
+            self._n_nocone -= int(np.count_nonzero(~self._has_cone[sl] & np.isfinite(self._then[sl, 0])))
+        self.head += k
         self._ub_sum -= sum(self._ub[:int(k)])
         del self._ub[:int(k)]
 
@@ -166,6 +263,8 @@ class DeviceStore:
         self._ub_sum = 0
         self._pending = []
         self.frame_off.zero_()
+        self._alloc_frame_tables(self.max_frames)
+        self._moved = np.eye(4)
 
     # ---- K1: KITTI ------------------------------------------------------------------------
     @staticmethod
@@ -232,6 +331,7 @@ class DeviceStore:
                                           None if Tc is None else Tc.ctypes.data, float(horizon), C.byref(ev), C.byref(pl),
                                           ctx.stream()))
         self._k1_noted = (keep, ) if getattr(ctx, 'k1_defer', False) else None      # (the K1 noted by the call before has run by now)
+        self._note_frame(self.tail, (key[0], int(H), int(W)) if obs.sem_gt is None else None)
         self.tail += 1
         self.ub_tail += n
         self._ub.append(n)
@@ -313,6 +413,7 @@ class DeviceStore:
         if self.n_frames == 0:
             return
         Ts = np.ascontiguousarray(Ts, dtype=np.float64).reshape(-1, 16)
+        self._note_moved(Ts)
         if defer and Ts.shape[0] == 1:
             if len(self._pending) >= self.CHAIN_MAX:
                 self.flush_pending()
@@ -334,6 +435,7 @@ class DeviceStore:
         Ts = np.ascontiguousarray(Ts, dtype=np.float64).reshape(-1, 16)
         assert Ts.shape[0] == n_new
         self.flush_pending()
+        self._note_moved(Ts)                      # (the batch's own frames have no `then`: they always count as visible)
         first_new = self.tail - n_new
         if first_new > self.head:
             st, ctx = self.c_store(), self.ctx
@@ -400,6 +502,7 @@ class DeviceStore:
         if extra is not None:
             assert extra.dtype == torch.float64 and extra.is_contiguous() \
                 and tuple(extra.shape) == (3, len(_lib.BEV_EXTRA_PLANES), px, px)
+        self.view_hint(prm, first_frame, last_frame, n_pend > 0 and write_back)     # (right in front of the call it is meant for)
         ctx.check(lib.pca_bev_generate_chain(ctx.h, C.byref(st), None if intensity64 is None else intensity64.data_ptr(),
                                              self.frame_off.data_ptr(), self.head + first_frame, self.head + split_frame,
                                              self.head + last_frame, max_points, C.byref(prm), pend_T, pend_ends, n_pend,
@@ -507,6 +610,7 @@ class DeviceStore:
             self.max_frames = max(self.max_frames, len(rows_list))
             self._alloc(max(total, 1))
             self.frame_off = torch.zeros(self.max_frames + 1, dtype=torch.int64, device=self.device)
+            self._alloc_frame_tables(self.max_frames)
         rows = np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, 10) for r in rows_list]) if rows_list \
             else np.zeros((0, 10))
         c = rows[:, 4:8]

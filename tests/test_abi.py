@@ -20,7 +20,7 @@ def test_header_symbols_exported():
     assert len(names) >= 14
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.pca_version() == 1
+    assert lib.pca_version() == 2
     lib.pca_bev_workspace_bytes.restype = ctypes.c_int64
     lib.pca_bev_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int]
     assert lib.pca_bev_workspace_bytes(1000, 256) > 1000 * 20

@@ -1542,3 +1542,95 @@ def test_k1_riding_in_the_raster_equals_k1_on_its_own():
         for acc in accs:
             acc.store.check_status()
         accs[0].store.set_defer_k1(False)
+
+
+def test_frames_that_cannot_reach_the_view_are_left_out_and_nothing_changes(monkeypatch):
+    """The raster is told which slots can reach its view (DeviceStore.view_hint -> pca_bev_view_hint: the frames' boxes read back
+    from K1, the camera cone for the frames whose box has not been seen yet, the product of the transforms applied since).  With
+    the hint and without (`store.cull = False`): the same planes, sample for sample, on a winding path with tilting transforms
+    -- a 24 m view inside a 60 m horizon, so frames at both ends of the window are left out --, through window slides, with the
+    camera test and with per-point labels (no cone: boxes only), host and device inputs."""
+    import torch
+
+    import sem_pc_accum
+    from kitti360_sem_pc_accum import Kitti360SemanticPointCloudAccumulator
+    from pca_amd import host_logic as hl
+    from pca_amd.device_store import DeviceStore
+    H, W, N = 96, 320, 6000
+    cam_to_velo = np.array([[0.04307104361, -0.08829286498, 0.995162929, 0.8043914418],
+                            [-0.999004371, 0.007784614041, 0.04392796942, 0.2993489574],
+                            [-0.01162548558, -0.9960641394, -0.08786966659, -0.1770225824], [0, 0, 0, 1]])
+    P = np.array([[130.0, 0, 160.0, 0], [0, 130.0, 48.0, 0], [0, 0, 1, 0]]) @ np.linalg.inv(cam_to_velo)
+    rng = np.random.default_rng(12)
+    monkeypatch.setattr(DeviceStore, 'BOX_EVERY', 2)          # boxes come back quickly: both ends of the window get cut
+
+    def frame():
+        pc = np.stack([rng.uniform(-25, 25, N), rng.uniform(-25, 25, N), rng.uniform(-2, 3, N), rng.uniform(0, 1, N)],
+                      1).astype(np.float32)
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        sem = rng.integers(0, 19, (H, W)).astype(np.uint8)
+        return pc, img, sem
+    frames = [frame() for _ in range(5)]
+    by_id = {id(f[1]): f[2] for f in frames}
+
+    class Resident:
+        def pred(self, rgb):
+            return by_id[id(rgb)][None, None]
+    sem_pc_accum.SemSegONNX = lambda path: Resident()
+
+    def T_of(k):                                              # ~1 m steps on a curve that turns left, then right, with a little tilt
+        yaw = 0.03 * np.sin(k / 9.0) + 0.01
+        pitch = 0.004 * np.cos(k / 5.0)
+        R = hl.rotation_matrix_3d(yaw)
+        Rp = np.array([[np.cos(pitch), 0, np.sin(pitch)], [0, 1, 0], [-np.sin(pitch), 0, np.cos(pitch)]])
+        T = np.eye(4)
+        T[:3, :3] = Rp @ R
+        T[:3, 3] = [-(0.8 + 0.4 * ((k * 7) % 5) / 5.0), 0.02 * np.sin(k), 0.003]
+        return T
+    calib = {'h_velo_cam': None, 'p_cam_frame': None, 'p_velo_frame': P}
+    for use_gt in (False, True):
+        accs, hints = [], [0, 0]
+        for cull in (True, False):
+            acc = Kitti360SemanticPointCloudAccumulator(60., calib, 1e3, 'resident', KITTI_FILTERS, SEM_IDXS, use_gt,
+                                                        dict(BEV_KITTI, view_size=24, pixel_size=64))
+            acc._store_args = dict(capacity=1 << 19, max_frames=48)       # slides while the stream runs
+            accs.append(acc)
+        for w, acc in enumerate(accs):
+            Ts = iter([T_of(k) for k in range(400)])
+            acc.pose_provider = lambda pc, Ts=Ts: next(Ts)
+            acc.store.cull = w == 0
+            real = acc.store.view_hint
+
+            def counted(*a, w=w, real=real, **kw):
+                r = real(*a, **kw)
+                hints[w] += 1 if r else 0
+                return r
+            acc.store.view_hint = counted
+        n_samples = 0
+        for k in range(150):
+            pc, img, sem = frames[k % 5]
+            if use_gt:
+                obs = (img, pc if k % 2 else torch.from_numpy(pc).cuda(), (np.arange(len(pc))[:, None] * 7 + k) % 19)
+            else:
+                obs = (img, pc, None)
+            outs = []
+            for acc in accs:
+                acc.integrate([obs])
+                d = acc.get_incremental_path_dists()
+                ok = len(d) > 3 and d[-1] > 22.0
+                if ok and k % 3 != 2:                                    # (a step without a raster now and then: longer owed chains)
+                    pidx = int(((d - (d[-1] - 20.0)) > 0).argmax())          # the pose ~20 m of path behind the newest
+                    pidx = min(max(pidx, 1), len(d) - 2)
+                    outs.append(acc.generate_bev(pidx, 1, gen_future=True)[0])
+            if len(outs) == 2:
+                n_samples += 1
+                for key in outs[0].keys():
+                    if key.startswith('trajs_'):
+                        assert all(np.array_equal(x, y) for x, y in zip(outs[0][key], outs[1][key])), key
+                    else:
+                        assert np.array_equal(outs[0][key].view(np.uint16), outs[1][key].view(np.uint16)), (use_gt, k, key)
+        assert n_samples > 60
+        assert hints[0] >= 8 and hints[1] == 0, (hints, n_samples)    # frames really were left out (never in a call that writes back)
+        assert np.array_equal(np.concatenate(accs[0].sem_pcs), np.concatenate(accs[1].sem_pcs))
+        for acc in accs:
+            acc.store.check_status()
