@@ -1437,7 +1437,11 @@ def main():
     roofline = {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                 'algorithmic_bytes_per_launch': alg[dominant], 'avg_launch_us': units[dominant],
-                'retransform_fused_into_bev': k2_fused, 'k1_fused_into_bev': k1_fused, 'bev_unit_sum_of_per_kernel_events_us': bev_us_sum,
+                'retransform_fused_into_bev': k2_fused, 'k1_fused_into_bev': k1_fused,
+                'view_culling': ('on: in calls that write nothing back (3 of 4) level 1 does not read the frames that cannot reach '
+                                 'the view; the algorithmic bytes still count every window point (SURVEY 8d), the physical ones '
+                                 '(traffic) are what is moved') if os.environ.get('PCA_BEV_CULL', '1') != '0' else 'off',
+                'bev_unit_sum_of_per_kernel_events_us': bev_us_sum,
                 'all': {k: {'avg_us': units[k], 'alg_bytes': alg[k],
                             'GBps': alg[k] / (units[k] * 1e-6) / 1e9,
                             'frac': alg[k] / (units[k] * 1e-6) / 1e9 / HBM_PEAK_GBS} for k in units},
