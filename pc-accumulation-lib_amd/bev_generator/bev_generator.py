@@ -12,6 +12,8 @@ import os
 import time
 from abc import ABC, abstractmethod
 
+import ctypes
+
 import numpy as np
 
 from pca_amd import host_logic as hl
@@ -127,13 +129,11 @@ class BEVGenerator(ABC):
     def _raster_params(self, origin, rot_mat, dx, dy, aug_view_size, intensity_div255):
         """pca_bev_params of one sample.  The constant part (grid, intensity transform, class sets) is built once per
         generator; origin / rotation / shift / view -- the first 15 doubles of the struct -- are copied in per call."""
-        import ctypes
-
-        from pca_amd.device_store import make_bev_params
         key = ('prm', bool(intensity_div255), self.pixel_size, self.height_filter, self.int_scaler,
                self.int_sep_scaler, self.int_mid_threshold, getattr(self, 'rgb_fill', 0))
         prm = self._tmp.get(key)
         if prm is None:
+            from pca_amd.device_store import make_bev_params
             sem_idxs = getattr(self, 'sem_idxs', None) or {}
             dyn_cls = [sem_idxs[k] for k in ('car', 'truck', 'bus', 'motorcycle') if k in sem_idxs]
             prm = self._tmp[key] = make_bev_params(np.zeros(3), np.eye(3), 0., 0., 1., self.pixel_size,

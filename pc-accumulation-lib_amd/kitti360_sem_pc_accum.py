@@ -11,9 +11,28 @@ The default provider issues the same Open3D call; without ``open3d`` the first i
 source is named (PCA_KITTI_T_FILE, PCA_POSE_PROVIDER=<module>:<callable>, or PCA_POSE_PROVIDER=gpu_icp for the device
 ICP of pca_amd/icp.py, which is NOT the reference's Open3D registration: parity with it is unpinned).
 """
+import os
+
 import numpy as np
 
 from sem_pc_accum import SemanticPointCloudAccumulator
+
+_MODS = None
+
+
+def _mods():
+    """What the per-frame calls need from modules that are imported on first use (an `import` statement inside a function that
+    runs ten thousand times a second is a dictionary lookup and a rebinding each: ~4 us of the step, all of them together)."""
+    global _MODS
+    if _MODS is None:
+        import ctypes
+
+        import torch
+        from bev_generator.sem_bev import LazyBev, SemBEVGenerator, _PendingCopy
+        from pca_amd import host_logic
+        from pca_amd._lib import PcaKittiObs
+        _MODS = (ctypes, torch, LazyBev, _PendingCopy, SemBEVGenerator, host_logic, PcaKittiObs)
+    return _MODS
 
 
 class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
@@ -28,7 +47,6 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         self._gpu_icp = None
         self._uploader = None            # pinned staging of host-array observations (pca_amd.ingest.PinnedUploader)
         self._cobs = None                # the observation as the library takes it (reused)
-        import os
         self._fast = os.environ.get('PCA_FAST_CALLS', '1') != '0'      # one library call per driver call (0: the general path)
         # K1 of integrate() left for the generate_bev() that follows it (it rides in the raster's first kernel: pca_k1_defer);
         # 0: K1 runs inside integrate()
@@ -151,8 +169,7 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         """The observation as pca_kitti_integrate takes it: (PcaKittiObs, semseg, H, W, what must stay alive), host arrays
         named in the struct's host_mask (the library stages them: one pinned block, ONE H2D copy), device tensors passed as
         they are.  None if this observation needs the general path (a model that wants the image on the device first)."""
-        import torch
-        from pca_amd._lib import PcaKittiObs
+        _, torch, _, _, _, _, PcaKittiObs = _mods()
         dev = self.store.device
         obs = self._cobs
         if obs is None:
@@ -342,11 +359,8 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         return self.sem_bev_generator.generate(pcs, trajs, device_only=True, out=out)
 
     def _fast_bev_ok(self, present_idx):
-        import os
-
-        from bev_generator.sem_bev import SemBEVGenerator
         gen = self.sem_bev_generator
-        if not self._fast or type(gen) is not SemBEVGenerator or gen.do_aug or gen.do_warp or self._store is None \
+        if not self._fast or type(gen) is not _mods()[4] or gen.do_aug or gen.do_warp or self._store is None \
                 or getattr(self._track, '_h', None) is None or os.environ.get('PCA_SYNC_BEV'):
             return False
         if not isinstance(present_idx, (int, np.integer)):
@@ -359,11 +373,7 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         """One un-augmented sample through ONE library call (pca_kitti_generate_bev): ego polylines, raster with the owed
         re-transforms riding along, and the planes' way to the host.  Same numbers as the general path (_window_inputs ->
         generate -> rasterise -> to_host_async), which stays for everything else (augmentation, warp, bev_num > 1, ...)."""
-        import ctypes as C
-
-        import torch
-        from bev_generator.sem_bev import LazyBev, _PendingCopy
-        from pca_amd import host_logic as hl
+        C, torch, LazyBev, _PendingCopy, _, hl, _ = _mods()
         st, gen, track = self.store, self.sem_bev_generator, self._track
         ctx = st.ctx
         st.poll_status()

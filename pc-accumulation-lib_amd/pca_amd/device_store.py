@@ -47,6 +47,7 @@ class DeviceStore:
         self._ub_sum = 0         # sum(self._ub), kept incrementally
         self._pending = []       # [(T 16 doubles, end slot)], oldest first: re-transforms owed to slots [head, end slot)
         self._k1_cache = None
+        self._k1_src = None      # (P object, filters object, their values) of the last append_kitti_obs
         self._ws = None
         self._ws_many = None
         self._ws_points, self._ws_px = 0, 0
@@ -314,7 +315,14 @@ class DeviceStore:
         lib, ctx = self.ctx.lib, self.ctx
         n = int(obs.n)
         self.reserve(n, 1)
-        key = (np.asarray(P, dtype=np.float64).tobytes(), tuple(int(c) for c in (filters or ())))
+        # keyed on VALUES (a calibration or filter list mutated in place is seen); the same objects as last time take the short way
+        src = self._k1_src
+        if src is not None and src[0] is P and src[1] is filters and P.tobytes() == src[2] and tuple(filters or ()) == src[3]:
+            key = self._k1_cache[0]
+        else:
+            key = (np.asarray(P, dtype=np.float64).tobytes(), tuple(int(c) for c in (filters or ())))
+            ok = isinstance(P, np.ndarray) and P.dtype == np.float64 and all(type(c) is int for c in (filters or ()))
+            self._k1_src = (P, filters, key[0], key[1]) if ok else None
         if self._k1_cache is None or self._k1_cache[0] != key:
             self._k1_cache = (key, _lib.f64_array(P, 12), _lib.class_mask(filters))
         Pc, fmask = self._k1_cache[1], self._k1_cache[2]
