@@ -102,7 +102,9 @@ class DeviceStore:
     def _note_moved(self, Ts):
         """Ts (k,16): transforms applied -- now or owed -- to EVERY live frame, in order."""
         for T in Ts:
-            self._moved = T.reshape(4, 4) @ self._moved
+            M = T.reshape(4, 4) @ self._moved
+            M[3] = (0., 0., 0., 1.)                 # (the kernels apply rows 0..2 only: whatever a T's last row says, it is not applied)
+            self._moved = M
 
     def _note_frame(self, slot, cone_key):
         """A frame K1 is about to put into `slot`, created under the current `moved`; cone_key: (P bytes, H, W) if K1's camera
