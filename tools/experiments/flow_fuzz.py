@@ -78,7 +78,22 @@ while time.time() < t_end:
         return r
     accs[0].store.view_hint = counted
     plan = [(int(rng.integers(0, 4)), rng.random() < 0.75, rng.random(), rng.random() < 0.5) for _ in range(steps)]
+    # now and then the stream changes its camera (another calibration: the frames taken before lose their cone) or switches
+    # between the camera's class map and per-point labels (frames with and without a cone in one window)
+    switch_cam = int(rng.integers(5, steps)) if rng.random() < 0.3 else -1
+    switch_gt = int(rng.integers(5, steps)) if rng.random() < 0.3 else -1
     for k, (fi, raster, where, host) in enumerate(plan):
+        if k == switch_cam:
+            f2 = rng.uniform(20, 200)
+            P2 = np.array([[f2, 0, W / 2, 0], [0, f2, H / 2, 0], [0, 0, 1, 0]]) @ np.linalg.inv(cam_to_velo)
+            for acc in accs:
+                acc.P_velo_frame = P2
+        if k == switch_gt:
+            use_gt = not use_gt
+            for acc in accs:
+                acc.use_gt_sem = use_gt
+                if getattr(acc, 'semseg_model', None) is None:
+                    acc.semseg_model = Model()
         pc, img, sem, gt = pool[fi]
         pin = pc if host else torch.from_numpy(pc).cuda()
         obs = (img, pin, gt if use_gt else None)
