@@ -398,6 +398,27 @@ int pca_kitti_generate_bev(pca_ctx *ctx, const pca_store *store, const int64_t *
                            void *host_planes /*pinned or NULL*/, const pca_host_track *track, double *traj_rows,
                            int32_t *traj_start, int32_t *n_rows, void *stream);
 
+/* The same two calls with their arguments in a block the caller keeps between calls: a binding in an interpreted language
+ * (ctypes: ~0.2 us per converted argument, 45 arguments per step) rewrites the few fields that change -- slot numbers, the
+ * pose, the output pointers -- and passes two pointers.  Members as the parameters of the same name; `evicted`, `path_length`,
+ * `n_rows` are outputs.  pca_kitti_generate_bev_v also takes the view hint (hint_F > 0: the arguments of pca_bev_view_hint;
+ * it is skipped, like the hint itself, when the call writes owed transforms back).  Returns what the plain form returns. */
+typedef struct {
+    const pca_kitti_obs *obs; const double *P; int32_t H, W; const uint64_t *filter_mask; const pca_store *store;
+    int64_t *frame_off; int32_t slot, sample_mode; pca_host_track *track; const double *T_new_prev; double horizon;
+    int64_t evicted; double path_length; void *stream;
+} pca_kitti_integrate_args;
+int pca_kitti_integrate_v(pca_ctx *ctx, pca_kitti_integrate_args *a);
+typedef struct {
+    const pca_store *store; const int64_t *frame_off; int32_t slot_begin, slot_split, slot_end, pad0; int64_t max_points;
+    const pca_bev_params *prm; const double *pending_Ts; const int *pending_slot_ends; int32_t n_pending, write_back;
+    void *workspace; int64_t workspace_bytes; uint16_t *planes_f16; void *host_planes; const pca_host_track *track;
+    double *traj_rows; int32_t *traj_start; int32_t n_rows, pad1; void *stream;
+    int32_t hint_slot0, hint_F; const double *hint_then; const float *hint_box; const double *hint_cone; const double *hint_now;
+    int32_t hinted, pad2;          /* out: 1 if the hint left frames out */
+} pca_kitti_generate_bev_args;
+int pca_kitti_generate_bev_v(pca_ctx *ctx, pca_kitti_generate_bev_args *a);
+
 /* ------------------------------------------------------------------------------------------------
  * Host arrays -> device for callers that hold their observations in pageable host memory -- what the reference's drivers
  * pass to integrate() (run_kitti360_bev_gen.py:173-190: numpy arrays straight from the loader).  src[k] (pageable, bytes[k]

@@ -147,4 +147,28 @@ int pca_kitti_generate_bev(pca_ctx *ctx, const pca_store *store, const int64_t *
     return pca_host_d2h_async(ctx, planes_f16, host_planes, 21ll * prm->px * prm->px * 2, stream);
 }
 
+int pca_kitti_integrate_v(pca_ctx *ctx, pca_kitti_integrate_args *a)
+{
+    if (!ctx) return -1;
+    if (!a) { ctx->err = "kitti_integrate_v: no argument block"; return -1; }
+    return pca_kitti_integrate(ctx, a->obs, a->P, a->H, a->W, a->filter_mask, a->store, a->frame_off, a->slot, a->sample_mode,
+                               a->track, a->T_new_prev, a->horizon, &a->evicted, &a->path_length, a->stream);
+}
+
+int pca_kitti_generate_bev_v(pca_ctx *ctx, pca_kitti_generate_bev_args *a)
+{
+    if (!ctx) return -1;
+    if (!a) { ctx->err = "kitti_generate_bev_v: no argument block"; return -1; }
+    a->hinted = 0;
+    if (a->hint_F > 0 && !(a->n_pending > 0 && a->write_back)) {
+        const int rc = pca_bev_view_hint(ctx, a->hint_slot0, a->hint_F, a->hint_then, a->hint_box, a->hint_cone, a->hint_now, a->prm);
+        if (rc < 0) { ctx->err = "kitti_generate_bev_v: bad view hint"; return -1; }
+        a->hinted = rc;
+    }
+    return pca_kitti_generate_bev(ctx, a->store, a->frame_off, a->slot_begin, a->slot_split, a->slot_end, a->max_points, a->prm,
+                                  a->pending_Ts, a->pending_slot_ends, a->n_pending, a->write_back, a->workspace,
+                                  a->workspace_bytes, a->planes_f16, a->host_planes, a->track, a->traj_rows, a->traj_start,
+                                  &a->n_rows, a->stream);
+}
+
 }  // extern "C"

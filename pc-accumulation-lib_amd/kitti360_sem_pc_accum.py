@@ -47,6 +47,7 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         self._gpu_icp = None
         self._uploader = None            # pinned staging of host-array observations (pca_amd.ingest.PinnedUploader)
         self._cobs = None                # the observation as the library takes it (reused)
+        self._ga = None                  # argument block of pca_kitti_generate_bev_v, kept between calls
         self._fast = os.environ.get('PCA_FAST_CALLS', '1') != '0'      # one library call per driver call (0: the general path)
         # K1 of integrate() left for the generate_bev() that follows it (it rides in the raster's first kernel: pca_k1_defer);
         # 0: K1 runs inside integrate()
@@ -395,18 +396,35 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         host = torch.empty((1, 21, px, px), dtype=torch.float16, pin_memory=True) if to_host else None
         rows = np.empty((max(2 * (n - 1), 1), 3))
         start = np.zeros(max(n, 1), dtype=np.int32)
-        n_rows = C.c_int32(0)
         cst = st.c_store()
-        st.view_hint(prm, 0, n, n_pend > 0 and write_back)      # (right in front of the call it is meant for: one use)
-        ticket = ctx.lib.pca_kitti_generate_bev(ctx.h, C.byref(cst), st.frame_off.data_ptr(), st.head, st.head + split,
-                                                st.head + n, max_points, C.byref(prm), pend_T, pend_ends, n_pend, write_back,
-                                                st._ws.data_ptr(), st._ws.numel(), out.data_ptr(),
-                                                None if host is None else host.data_ptr(), track._h, rows.ctypes.data,
-                                                start.ctypes.data, C.byref(n_rows), ctx.stream())
+        # the call's arguments live in a block kept between calls (pca_kitti_generate_bev_v): store, parameter block, owed-chain
+        # buffers, scratch and track are written when one of them is replaced, the slots / outputs / view hint per call
+        a = self._ga
+        if a is None:
+            from pca_amd._lib import PcaKittiGenerateBevArgs
+            a = self._ga = PcaKittiGenerateBevArgs()
+            self._ga_const = None
+        pend_T, pend_ends = st._pend_T, st._pend_ends          # (the store's buffers, whether or not anything is owed)
+        const = (id(cst), id(st.frame_off), id(prm), id(pend_T), id(pend_ends), id(st._ws), track._h)
+        if const != self._ga_const:
+            a.store, a.frame_off, a.prm = C.addressof(cst), st.frame_off.data_ptr(), C.addressof(prm)
+            a.pending_Ts, a.pending_slot_ends = C.addressof(pend_T), C.addressof(pend_ends)
+            a.workspace, a.workspace_bytes = st._ws.data_ptr(), st._ws.numel()
+            a.track = getattr(track._h, 'value', track._h)
+            self._ga_const = const
+            self._ga_keep = (cst, st.frame_off, prm, pend_T, pend_ends, st._ws)      # (what the addresses point into)
+        a.slot_begin, a.slot_split, a.slot_end, a.max_points = st.head, st.head + split, st.head + n, max_points
+        a.n_pending, a.write_back = n_pend, write_back
+        a.planes_f16, a.host_planes = out.data_ptr(), (None if host is None else host.data_ptr())
+        a.traj_rows, a.traj_start = rows.ctypes.data, start.ctypes.data
+        a.stream = ctx.stream_int() or None
+        a.hint_F = st.view_hint_into(a, 0, n)                  # (the library skips it if this call writes owed transforms back)
+        ticket = ctx.lib.pca_kitti_generate_bev_v(ctx.h, C.addressof(a))
         if ticket < 0:
             ctx.check(ticket)
+        st.hints_taken += a.hinted
         st.bev_done(write_back)
-        rows = rows[:n_rows.value]
+        rows = rows[:a.n_rows]
         empty = np.zeros((0, 3))
         ego_p = rows[:start[split - 1]].copy() if split >= 2 else empty      # edges 0 .. split-2 belong to the present polyline
         ego_f = rows[start[split]:].copy() if n - split >= 2 else empty

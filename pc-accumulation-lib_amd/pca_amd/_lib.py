@@ -26,7 +26,7 @@ EXPORTS = ('pca_version', 'pca_ctx_create', 'pca_ctx_destroy', 'pca_last_error',
            'pca_host_track_poses', 'pca_host_track_segments', 'pca_host_track_set', 'pca_host_track_transform',
            'pca_host_track_append', 'pca_host_track_push_segment', 'pca_host_track_incr', 'pca_host_track_evict_beyond',
            'pca_host_track_step', 'pca_host_track_trigger', 'pca_host_stage_h2d', 'pca_host_d2h_async', 'pca_host_d2h_wait',
-           'pca_kitti_integrate', 'pca_kitti_generate_bev', 'pca_k1_defer', 'pca_k1_flush', 'pca_host_camera_cone', 'pca_host_view_hull', 'pca_bev_bin_range', 'pca_bev_view_hint', 'pca_f32_box_decode',
+           'pca_kitti_integrate', 'pca_kitti_generate_bev', 'pca_k1_defer', 'pca_k1_flush', 'pca_host_camera_cone', 'pca_host_view_hull', 'pca_bev_bin_range', 'pca_bev_view_hint', 'pca_kitti_integrate_v', 'pca_kitti_generate_bev_v', 'pca_f32_box_decode',
            'pca_profile_enable', 'pca_profile_read')
 
 KERNEL_IDS = ('kitti_project_sample_filter', 'nusc_sample_filter_transform', 'nusc_project_cams', 'retransform',
@@ -38,6 +38,24 @@ class PcaStore(C.Structure):
     _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('z', C.c_void_p), ('intensity', C.c_void_p),
                 ('rgbs', C.c_void_p), ('inst', C.c_void_p), ('dyn', C.c_void_p), ('capacity', C.c_int64),
                 ('frame_box', C.c_void_p)]
+
+
+class PcaKittiIntegrateArgs(C.Structure):
+    _fields_ = [('obs', C.c_void_p), ('P', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32), ('filter_mask', C.c_void_p),
+                ('store', C.c_void_p), ('frame_off', C.c_void_p), ('slot', C.c_int32), ('sample_mode', C.c_int32),
+                ('track', C.c_void_p), ('T_new_prev', C.c_void_p), ('horizon', C.c_double), ('evicted', C.c_int64),
+                ('path_length', C.c_double), ('stream', C.c_void_p)]
+
+
+class PcaKittiGenerateBevArgs(C.Structure):
+    _fields_ = [('store', C.c_void_p), ('frame_off', C.c_void_p), ('slot_begin', C.c_int32), ('slot_split', C.c_int32),
+                ('slot_end', C.c_int32), ('pad0', C.c_int32), ('max_points', C.c_int64), ('prm', C.c_void_p),
+                ('pending_Ts', C.c_void_p), ('pending_slot_ends', C.c_void_p), ('n_pending', C.c_int32), ('write_back', C.c_int32),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('planes_f16', C.c_void_p), ('host_planes', C.c_void_p),
+                ('track', C.c_void_p), ('traj_rows', C.c_void_p), ('traj_start', C.c_void_p), ('n_rows', C.c_int32),
+                ('pad1', C.c_int32), ('stream', C.c_void_p), ('hint_slot0', C.c_int32), ('hint_F', C.c_int32),
+                ('hint_then', C.c_void_p), ('hint_box', C.c_void_p), ('hint_cone', C.c_void_p), ('hint_now', C.c_void_p),
+                ('hinted', C.c_int32), ('pad2', C.c_int32)]
 
 
 class PcaKittiObs(C.Structure):
@@ -203,6 +221,8 @@ def load():
     lib.pca_bev_view_hint.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     lib.pca_f32_box_decode.argtypes = [vp, i32, vp]
     lib.pca_f32_box_decode.restype = None
+    lib.pca_kitti_integrate_v.argtypes = [vp, vp]
+    lib.pca_kitti_generate_bev_v.argtypes = [vp, vp]
     lib.pca_k1_defer.argtypes = [vp, i32]
     lib.pca_k1_flush.argtypes = [vp]
     lib.pca_profile_enable.argtypes = [vp, i32]
@@ -217,6 +237,7 @@ class Context:
     sequence at a time).  All calls are enqueued on torch's current stream."""
 
     _by_device = {}
+    _raw_stream = None
     _tls = threading.local()              # .lane: the Context this THREAD works on while inside `with Lane(...)`
 
     def __init__(self, device_index):
@@ -255,11 +276,18 @@ class Context:
 
     def stream(self):
         """Raw handle of torch's current stream on this device (every call targets it)."""
-        import torch
-        raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)      # ~10x cheaper than current_stream()
-        if raw is not None:
-            return C.c_void_p(raw(self.device_index))
-        return C.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream)
+        return C.c_void_p(self.stream_int())
+
+    def stream_int(self):
+        """The same as a plain integer (0 = the default stream), e.g. for a field of an argument block."""
+        raw = self._raw_stream
+        if raw is None:
+            import torch
+            raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)      # ~10x cheaper than current_stream()
+            if raw is None:
+                return torch.cuda.current_stream(self.device_index).cuda_stream
+            self._raw_stream = raw
+        return raw(self.device_index)
 
     def check(self, rc):
         if rc != 0:

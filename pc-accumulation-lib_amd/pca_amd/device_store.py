@@ -38,6 +38,7 @@ class DeviceStore:
         self.frame_off = torch.zeros(self.max_frames + 1, dtype=torch.int64, device=self.device)
         self._moved = np.eye(4)  # product of every transform applied to all live frames so far (newest on the left)
         self.cull = CULL         # tell the rasters which slots can reach their view (view_hint)
+        self.hints_taken = 0     # rasters of this store that were told to leave frames out
         self._alloc_frame_tables(self.max_frames)
         self.head = 0            # first live slot
         self.tail = 0            # one past the last live slot
@@ -48,6 +49,7 @@ class DeviceStore:
         self._pending = []       # [(T 16 doubles, end slot)], oldest first: re-transforms owed to slots [head, end slot)
         self._k1_cache = None
         self._k1_src = None      # (P object, filters object, their values) of the last append_kitti_obs
+        self._ia = None          # argument block of pca_kitti_integrate_v, kept between calls
         self._ws = None
         self._ws_many = None
         self._ws_points, self._ws_px = 0, 0
@@ -148,6 +150,19 @@ class DeviceStore:
         tgt = self._box[first:first + n]
         tgt[known] = dec[known]
 
+    def view_hint_into(self, args, first_frame, last_frame):
+        """The arguments of pca_bev_view_hint for live frames [first_frame, last_frame) written into the hint_* fields of an
+        argument block (pca_kitti_generate_bev_v); returns hint_F (0: no hint)."""
+        n = last_frame - first_frame
+        if not self.cull or n < 4:
+            return 0
+        a = self.head + first_frame
+        args.hint_slot0 = a
+        args.hint_then, args.hint_box = self._then_addr + 96 * a, self._box_addr + 24 * a
+        args.hint_cone = self._cone[2] if (self._cone is not None and self._n_nocone == 0) else None
+        args.hint_now = self._moved.ctypes.data
+        return n
+
     def view_hint(self, prm, first_frame, last_frame, write_back):
         """Tells the context which slots of live frames [first_frame, last_frame) can reach the view of `prm` (pca_bev_view_hint)
         before a raster that writes nothing back.  Returns 1 if frames will be left out."""
@@ -156,8 +171,12 @@ class DeviceStore:
             return 0
         a = self.head + first_frame
         cone = self._cone[2] if (self._cone is not None and self._n_nocone == 0) else None
-        return self.ctx.lib.pca_bev_view_hint(self.ctx.h, a, n, self._then_addr + 96 * a, self._box_addr + 24 * a, cone,
-                                              self._moved.ctypes.data, C.addressof(prm))
+        return self._count_hint(self.ctx.lib.pca_bev_view_hint(self.ctx.h, a, n, self._then_addr + 96 * a, self._box_addr + 24 * a, cone,
+                                              self._moved.ctypes.data, C.addressof(prm)))
+
+    def _count_hint(self, r):
+        self.hints_taken += 1 if r > 0 else 0
+        return r
 
     def c_store(self):
         if self._cstore is None:
@@ -330,16 +349,29 @@ class DeviceStore:
         Pc, fmask = self._k1_cache[1], self._k1_cache[2]
         st = self.c_store()
         th = getattr(track, '_h', None)
-        Tc = None
+        # the call's arguments live in a block that is kept between calls (pca_kitti_integrate_v): what does not change from
+        # frame to frame -- calibration, filter, store, track -- is written when it changes, the rest per call
+        a = self._ia
+        if a is None:
+            a = self._ia = _lib.PcaKittiIntegrateArgs()
+            self._ia_T = np.zeros(16)
+            self._ia_T_addr = self._ia_T.ctypes.data
+            self._ia_const = None
+        const = (id(obs), id(Pc), int(H), int(W), id(st), id(self.frame_off), sample_mode, th, float(horizon))
+        if const != self._ia_const:
+            a.obs, a.P, a.H, a.W, a.filter_mask = C.addressof(obs), C.addressof(Pc), int(H), int(W), C.addressof(fmask)
+            a.store, a.frame_off, a.sample_mode = C.addressof(st), self.frame_off.data_ptr(), _lib.SAMPLE_MODES[sample_mode]
+            a.track, a.horizon = getattr(th, 'value', th), float(horizon)
+            self._ia_const = const
+            self._ia_keep = (obs, Pc, fmask, st, self.frame_off)     # (what the addresses point into)
+        a.slot = self.tail
         if th is not None:
-            Tc = np.ascontiguousarray(T_new_prev, dtype=np.float64)
-        if self._obs_out is None:
-            self._obs_out = (C.c_int64(0), C.c_double(0.0))
-        ev, pl = self._obs_out
-        ctx.check(lib.pca_kitti_integrate(ctx.h, C.byref(obs), Pc, int(H), int(W), fmask, C.byref(st),
-                                          self.frame_off.data_ptr(), self.tail, _lib.SAMPLE_MODES[sample_mode], th,
-                                          None if Tc is None else Tc.ctypes.data, float(horizon), C.byref(ev), C.byref(pl),
-                                          ctx.stream()))
+            self._ia_T[:] = np.asarray(T_new_prev, dtype=np.float64).reshape(16)
+            a.T_new_prev = self._ia_T_addr
+        else:
+            a.T_new_prev = None
+        a.stream = ctx.stream_int() or None
+        ctx.check(lib.pca_kitti_integrate_v(ctx.h, C.addressof(a)))
         self._k1_noted = (keep, ) if getattr(ctx, 'k1_defer', False) else None      # (the K1 noted by the call before has run by now)
         self._note_frame(self.tail, (key[0], int(H), int(W)) if obs.sem_gt is None else None)
         self.tail += 1
@@ -348,8 +380,8 @@ class DeviceStore:
         self._ub_sum += n
         if th is None:
             return None, None
-        v = pl.value
-        return int(ev.value), (None if v != v else np.float64(v))
+        v = a.path_length
+        return int(a.evicted), (None if v != v else np.float64(v))
 
     # ---- K1n: NuScenes --------------------------------------------------------------------
     def append_nusc(self, pc, cam_idx, imgs, sems, T, filters, sample_mode='nearest'):

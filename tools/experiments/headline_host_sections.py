@@ -24,13 +24,13 @@ def wrap(obj, name, key):
 wrap(acc.store, 'append_kitti_obs', '  store.append_kitti_obs (C: pca_kitti_integrate inside)')
 wrap(acc, '_obs_pointers', '  _obs_pointers')
 wrap(acc, 'update_sem_pcs', '  update_sem_pcs')
-wrap(acc.store, 'view_hint', '  store.view_hint (C: pca_bev_view_hint)')
+wrap(acc.store, 'view_hint_into', '  store.view_hint_into')
 wrap(acc.store, 'bev_pending', '  store.bev_pending')
 wrap(acc.sem_bev_generator, '_raster_params', '  _raster_params')
 lib = acc.store.ctx.lib
 class L:  # time the two fat C calls
     pass
-for nm in ('pca_kitti_integrate', 'pca_kitti_generate_bev'):
+for nm in ('pca_kitti_integrate_v', 'pca_kitti_generate_bev_v'):
     f = getattr(lib, nm)
     def g(*a, f=f, nm=nm):
         t0 = pc(); r = f(*a); inner['    C ' + nm] = inner.get('    C ' + nm, 0.0) + pc() - t0; return r
