@@ -77,7 +77,8 @@ class DeviceStore:
         return (self.x, self.y, self.z, self.intensity, self.rgbs, self.inst, self.dyn)
 
     # ---- where the frames are (for pca_host_view_hull: include/pca.h) --------------------------
-    BOX_EVERY = 8            # the frames' boxes are read back every so many append_kitti_obs (asynchronously)
+    BOX_EVERY = 16           # the frames' boxes are read back every so many append_kitti_obs (asynchronously; the frames that
+                             # need their box are the OLD ones behind the view -- the new ones ahead of it are out by their cone)
 
     def _alloc_frame_tables(self, max_frames, keep=None):
         """Per slot: the box K1 leaves on the device (frame_box), what the host has seen of it (_box: lo > hi = not seen), the
