@@ -381,10 +381,11 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         n = st.n_frames
         present_idx = int(present_idx)
         split = present_idx if present_idx >= 0 else n + present_idx
-        poses = track.as_array()
-        origin = poses[split].copy()
+        lo = max(split - 2, 0)
+        near = track.poses_window(lo, split + 1)                # the sample's pose and the two before it
+        origin = near[split - lo]
         # heading from the last two PRESENT poses (bev_generator.py:87-93), evaluated with numpy as the general path does
-        rot_mat = hl.rotation_matrix_3d(hl.heading_rot_ang(poses[max(split - 2, 0):split] - origin))
+        rot_mat = hl.rotation_matrix_3d(hl.heading_rot_ang(near[:split - lo] - origin))
         px = gen.pixel_size
         prm = gen._raster_params(origin, rot_mat, 0., 0., 1. * gen.view_size, st.intensity_div255)
         max_points = st.bev_workspace(px)

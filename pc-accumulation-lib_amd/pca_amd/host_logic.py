@@ -214,6 +214,7 @@ class CPoseTrack:
             raise RuntimeError('pca_host_track_create failed')
         self._h = h
         self._pl = C.c_double(0.0)
+        self._win = None         # (address, poses, view) behind poses_window
 
     def __del__(self):
         try:
@@ -233,6 +234,16 @@ class CPoseTrack:
     def as_array(self):
         n = len(self)
         return self._view(self._lib.pca_host_track_poses(self._h), n, 4)[:, :3].copy()
+
+    def poses_window(self, first, last):
+        """Copies of poses [first, last) (rows of x, y, z) without a copy of the whole track: a view over the library's buffer is
+        kept while the buffer stays where it is (the address is asked for on every call; a grown track gets a new view)."""
+        n = len(self)
+        ptr = self._lib.pca_host_track_poses(self._h)
+        c = self._win
+        if c is None or c[0] != ptr or c[1] < n:
+            c = self._win = (ptr, n, self._view(ptr, n, 4))
+        return c[2][first:last, :3].copy()
 
     def pose(self, idx):
         n = len(self)
