@@ -140,11 +140,12 @@ class BEVGenerator(ABC):
                                                    self.height_filter, self.int_scaler, self.int_sep_scaler,
                                                    self.int_mid_threshold, sem_idxs.get('road', -1), dyn_cls,
                                                    intensity_div255, getattr(self, 'rgb_fill', 0))
-        head = np.empty(15)
+        head = self._tmp.get(id(prm))                   # the struct's first 15 doubles as a numpy array over the same memory
+        if head is None:
+            head = self._tmp[id(prm)] = np.frombuffer((ctypes.c_double * 15).from_address(ctypes.addressof(prm)), dtype=np.float64)
         head[0:3] = origin
         head[3:12] = np.asarray(rot_mat, dtype=np.float64).reshape(9)
         head[12], head[13], head[14] = dx, dy, aug_view_size
-        ctypes.memmove(ctypes.addressof(prm), head.ctypes.data, 120)
         return prm
 
     def _tmp_store(self, key):

@@ -48,6 +48,7 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         self._uploader = None            # pinned staging of host-array observations (pca_amd.ingest.PinnedUploader)
         self._cobs = None                # the observation as the library takes it (reused)
         self._ga = None                  # argument block of pca_kitti_generate_bev_v, kept between calls
+        self._ga_traj = None
         self._fast = os.environ.get('PCA_FAST_CALLS', '1') != '0'      # one library call per driver call (0: the general path)
         # K1 of integrate() left for the generate_bev() that follows it (it rides in the raster's first kernel: pca_k1_defer);
         # 0: K1 runs inside integrate()
@@ -395,8 +396,11 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         else:
             assert out.dtype == torch.float16 and out.is_contiguous() and tuple(out.shape) == (21, px, px)
         host = torch.empty((1, 21, px, px), dtype=torch.float16, pin_memory=True) if to_host else None
-        rows = np.empty((max(2 * (n - 1), 1), 3))
-        start = np.zeros(max(n, 1), dtype=np.int32)
+        tb = self._ga_traj                                      # landing buffers of the polylines, kept between calls
+        if tb is None or tb[0].shape[0] < 2 * n or tb[1].shape[0] < n + 1:
+            tb = self._ga_traj = (np.empty((4 * n + 64, 3)), np.zeros(2 * n + 64, dtype=np.int32))
+            self._ga_traj_addr = (tb[0].ctypes.data, tb[1].ctypes.data)
+        start = tb[1]
         cst = st.c_store()
         # the call's arguments live in a block kept between calls (pca_kitti_generate_bev_v): store, parameter block, owed-chain
         # buffers, scratch and track are written when one of them is replaced, the slots / outputs / view hint per call
@@ -417,7 +421,7 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
         a.slot_begin, a.slot_split, a.slot_end, a.max_points = st.head, st.head + split, st.head + n, max_points
         a.n_pending, a.write_back = n_pend, write_back
         a.planes_f16, a.host_planes = out.data_ptr(), (None if host is None else host.data_ptr())
-        a.traj_rows, a.traj_start = rows.ctypes.data, start.ctypes.data
+        a.traj_rows, a.traj_start = self._ga_traj_addr
         a.stream = ctx.stream_int() or None
         a.hint_F = st.view_hint_into(a, 0, n)                  # (the library skips it if this call writes owed transforms back)
         ticket = ctx.lib.pca_kitti_generate_bev_v(ctx.h, C.addressof(a))
@@ -425,7 +429,7 @@ class Kitti360SemanticPointCloudAccumulator(SemanticPointCloudAccumulator):
             ctx.check(ticket)
         st.hints_taken += a.hinted
         st.bev_done(write_back)
-        rows = rows[:a.n_rows]
+        rows = tb[0][:a.n_rows].copy()
         empty = np.zeros((0, 3))
         ego_p = rows[:start[split - 1]].copy() if split >= 2 else empty      # edges 0 .. split-2 belong to the present polyline
         ego_f = rows[start[split]:].copy() if n - split >= 2 else empty
