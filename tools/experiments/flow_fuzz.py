@@ -69,6 +69,9 @@ while time.time() < t_end:
         acc._defer_k1 = new
         accs.append(acc)
     accs[0].store.cull, accs[1].store.cull = True, False
+    if os.environ.get('FLOW_FUZZ_GENERAL_BEV'):               # integrate() through the one-call path, generate_bev() through the general one
+        for acc in accs:
+            acc._fast_bev_ok = lambda idx: False
     plan = [(int(rng.integers(0, 4)), rng.random() < 0.75, rng.random(), rng.random() < 0.5) for _ in range(steps)]
     # now and then the stream changes its camera (another calibration: the frames taken before lose their cone) or switches
     # between the camera's class map and per-point labels (frames with and without a cone in one window)
